@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Headline benchmark: shift-and-stack trajectory search on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): trajectory-epoch evaluations / second (+ achieved GB/s of
+algorithmic bytes against the HBM roofline) on a 64-frame 512x512 float32 stack,
+full per-pixel start grid x 1024 (v, theta) candidates, sigma-G off (configs[1]).
+
+A "step" is one pass of the hot path -- kb_device_search_filter through the C
+ABI of libkbmod_hip.so -- over one batch of synthetic input that is already
+resident in HBM (the psi/phi array is built on the device by the HIP builder
+before the timed region).  torch is plumbing only: device memory, the stream,
+and torch.distributed (RCCL) for the multi-GPU gather.
+
+Multi-GPU (N > 1): one process per GPU; the candidate list is sharded into N
+contiguous (v, theta) slices (weak scaling: every rank searches the full start
+grid over `--cands` candidates of its own, so per-GPU work is fixed), psi/phi is
+replicated, and the per-rank per-pixel top-K lists are exchanged with ONE RCCL
+all_gather followed by a per-pixel K-way merge on the device.
+"""
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+class Meta(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("num_times", "width", "height", "pixels_per_image", "num_entries",
+                                          "block_size", "total_array_size")] + [
+        ("num_bytes", C.c_int32), ("psi_min_val", C.c_float), ("psi_max_val", C.c_float), ("psi_scale", C.c_float),
+        ("phi_min_val", C.c_float), ("phi_max_val", C.c_float), ("phi_scale", C.c_float)]
+
+
+class Params(C.Structure):
+    _fields_ = [("min_observations", C.c_int32), ("min_lh", C.c_float), ("do_sigmag_filter", C.c_uint8),
+                ("sgl_L", C.c_float), ("sgl_H", C.c_float), ("sigmag_coeff", C.c_float),
+                ("encode_num_bytes", C.c_int32), ("x_start_min", C.c_int32), ("x_start_max", C.c_int32),
+                ("y_start_min", C.c_int32), ("y_start_max", C.c_int32), ("results_per_pixel", C.c_uint32),
+                ("total_results", C.c_ulonglong)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("search_kernel_ms", C.c_float), ("table_kernel_ms", C.c_float), ("num_evals", C.c_uint64),
+                ("algorithmic_bytes", C.c_uint64), ("kernel_variant", C.c_int32), ("num_search_launches", C.c_int32)]
+
+
+def load_lib():
+    path = os.path.join(ROOT, "kbmod_amd", "lib", "libkbmod_hip.so")
+    if not os.path.exists(path):
+        raise RuntimeError("libkbmod_hip.so is not built (run __graft_entry__.build()); there is no fallback path")
+    lib = C.CDLL(path)
+    lib.kb_last_error.restype = C.c_char_p
+    lib.kb_build_psi_phi_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                                 C.c_int32, C.c_int32, C.POINTER(Meta), C.POINTER(C.c_void_p), C.c_void_p]
+    lib.kb_device_search_filter.argtypes = [C.POINTER(Meta), C.c_void_p, C.c_void_p, Params, C.c_void_p, C.c_uint64,
+                                            C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
+    lib.kb_merge_topk.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.kb_free_gpu_block.argtypes = [C.c_void_p]
+    lib.kb_copy_block_to_cpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    return lib
+
+
+def check(lib, rc):
+    if rc != 0:
+        raise RuntimeError(lib.kb_last_error().decode())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--vel-steps", type=int, default=32)
+    ap.add_argument("--ang-steps", type=int, default=32)
+    ap.add_argument("--num-bytes", type=int, default=-1, choices=[-1, 1, 2, 4])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from kbmod_amd import fake_data as fd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU: the search has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+
+    lib = load_lib()
+    T, H, W = args.frames, args.size, args.size
+    K = 8
+
+    # ---- synthetic stack, generated on the device (same distributions as
+    # fake_data.make_fake_image_stack: sci ~ N(0, 2^2), var = 4, Gaussian PSF sigma = 1) ----
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)  # identical stack on every rank (psi/phi replicated)
+    sci = torch.randn((T, H, W), generator=gen, device=dev, dtype=torch.float32) * 2.0
+    var = torch.full((T, H, W), 4.0, device=dev, dtype=torch.float32)
+    times = torch.arange(T, dtype=torch.float64, device=dev) / T
+    psf = fd.make_gaussian_kernel(1.0)
+    # ~10 injected movers (x, y, vx, vy, flux)
+    obj_rng = np.random.default_rng(99)
+    tcpu = times.cpu().numpy()
+    for _ in range(10):
+        x0, y0 = obj_rng.integers(20, W - 60), obj_rng.integers(20, H - 60)
+        v, ang = obj_rng.uniform(8, 35), obj_rng.uniform(0.1, 1.3)
+        for t in range(T):
+            px = int(x0 + v * np.cos(ang) * tcpu[t] + 0.5)
+            py = int(y0 + v * np.sin(ang) * tcpu[t] + 0.5)
+            r = psf.shape[0] // 2
+            if r <= px < W - r and r <= py < H - r:
+                sci[t, py - r:py + r + 1, px - r:px + r + 1] += torch.from_numpy(300.0 * psf).to(dev)
+
+    psf_all = np.ascontiguousarray(np.tile(psf.ravel(), T), dtype=np.float32)
+    psf_dims = np.full(T, psf.shape[0], dtype=np.int32)
+    meta = Meta()
+    arr = C.c_void_p()
+    stream = torch.cuda.current_stream().cuda_stream
+    t0 = time.perf_counter()
+    check(lib, lib.kb_build_psi_phi_from_device(sci.data_ptr(), var.data_ptr(), psf_all.ctypes.data, psf_dims.ctypes.data,
+                                                T, H, W, args.num_bytes, C.byref(meta), C.byref(arr), stream))
+    torch.cuda.synchronize()
+    build_ms = (time.perf_counter() - t0) * 1e3
+    del sci, var
+
+    # ---- candidates: KBMODV1Search(32, 5, 40, 32, 0, 1.5) = 1024 per GPU; rank r
+    # takes the r-th contiguous slice of an N*1024 candidate (v, theta) grid ----
+    vx, vy = fd.kbmod_v1_candidates(args.vel_steps, 5.0, 40.0, args.ang_steps * world, 0.0, 1.5)
+    n_local = args.vel_steps * args.ang_steps
+    sl = slice(rank * n_local, (rank + 1) * n_local)
+    cands_np = np.zeros((n_local, 7), dtype=np.float32)
+    cands_np[:, 0], cands_np[:, 1] = vx[sl], vy[sl]
+    cands = torch.from_numpy(cands_np).to(dev)
+
+    S = H * W
+    results = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
+    params = Params(0, 0.0, 0, 0.25, 0.75, -1.0, -1 if args.num_bytes in (-1, 4) else args.num_bytes, 0, W, 0, H, K, 0)
+    gathered = torch.empty((world, S * K, 7), dtype=torch.float32, device=dev) if world > 1 else None
+    merged = torch.empty((S * K, 7), dtype=torch.float32, device=dev) if world > 1 else None
+
+    kernel_ms = []
+
+    def step(record):
+        st = Stats()
+        check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), n_local,
+                                               results.data_ptr(), S * K, 0, stream, C.byref(st)))
+        if world > 1:
+            dist.all_gather_into_tensor(gathered.view(-1), results.view(-1))
+            check(lib, lib.kb_merge_topk(gathered.data_ptr(), world, S, K, merged.data_ptr(), stream))
+        if record:
+            kernel_ms.append(st.search_kernel_ms)
+        return st
+
+    for _ in range(args.warmup):
+        step(False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    evals_per_step_rank = int(last.num_evals)
+    total_evals = evals_per_step_rank * world * args.steps
+    value = total_evals / elapsed
+    k_ms = float(np.mean(kernel_ms))
+    achieved = float(last.algorithmic_bytes) / (k_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "trajectory-epoch evals/sec",
+        "value": value,
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": {-1: "f32", 4: "f32", 1: "u8", 2: "u16"}[args.num_bytes],
+        "data": "synthetic",
+        "config": {
+            "workload": f"{T}x{H}x{W} psi/phi ({'float32' if args.num_bytes in (-1, 4) else 'uint%d' % (8 * args.num_bytes)}), "
+                        f"full {W}x{H} start grid x {n_local} (v,theta) candidates per GPU, K=8, sigma-G off "
+                        "(BASELINE configs[1])",
+            "frames": T, "height": H, "width": W, "candidates_per_gpu": n_local, "results_per_pixel": K,
+            "sharding": "candidates (v,theta) by rank; psi/phi replicated; one RCCL all_gather + per-pixel merge"
+                        if world > 1 else "none",
+            "psi_phi_build_ms": build_ms,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "kernel": "kb_search_tiles",
+            "kernel_ms": k_ms,
+            "algorithmic_bytes_per_launch": int(last.algorithmic_bytes),
+            "kernel_evals_per_s": evals_per_step_rank / (k_ms * 1e-3),
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(lib, meta, arr, tcpu, vx[sl], vy[sl], args.cpu_seconds)
+
+    if rank == 0:
+        print(json.dumps(out))
+    lib.kb_free_gpu_block(arr)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(lib, meta, arr, times, vx, vy, target_s):
+    """The oracle's restatement of the reference CPU search (cpu_search_algorithms.cpp:93-124),
+    OpenMP over the host cores, on a bounded start-pixel window of the SAME stack and candidates."""
+    from oracle import oracle as orc
+
+    host = np.empty(int(meta.num_entries), dtype={4: np.float32, 2: np.uint16, 1: np.uint8}[meta.num_bytes])
+    check(lib, lib.kb_copy_block_to_cpu(host.ctypes.data, arr, meta.total_array_size))
+    pp = orc.PsiPhi.__new__(orc.PsiPhi)
+    pp.meta = orc.Meta(meta.num_times, meta.width, meta.height, meta.num_bytes, meta.psi_min_val, meta.psi_max_val,
+                       meta.psi_scale, meta.phi_min_val, meta.phi_max_val, meta.phi_scale)
+    pp.array = host
+    pp.times = np.ascontiguousarray(times, dtype=np.float64)
+    pp.T, pp.H, pp.W, pp.nb = int(meta.num_times), int(meta.height), int(meta.width), int(meta.num_bytes)
+    cands = orc.make_candidates(vx, vy)
+    H, W, T = pp.H, pp.W, pp.T
+
+    def run(rows):
+        y0 = (H - rows) // 2
+        p = pp.default_params(y_start_min=y0, y_start_max=y0 + rows)
+        t0 = time.perf_counter()
+        pp.search_cpu(cands, p)
+        return time.perf_counter() - t0, rows * W * len(cands) * T
+
+    dt, ev = run(4)  # calibration
+    rate = ev / dt
+    rows = int(max(4, min(H, target_s * rate / (W * len(cands) * T))))
+    dt, ev = run(rows)
+    return {
+        "value": ev / dt,
+        "unit": "evals/s",
+        "cores": orc.num_threads(),
+        "kind": "port",
+        "sample": f"{rows} of {H} start rows (full width) x {len(cands)} candidates x {T} epochs of the same stack, "
+                  f"{dt:.1f} s, oracle/kbmod_oracle.c orc_search_cpu (OpenMP)",
+    }
+
+
+if __name__ == "__main__":
+    main()

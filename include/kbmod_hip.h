@@ -1,0 +1,139 @@
+/*
+ * kbmod_hip.h -- C ABI of libkbmod_hip.so, the MI355X (gfx950) device library
+ * behind the shift-and-stack search path.
+ *
+ * This is the drop-in boundary for the reference's host<->device seam: every
+ * entry point below names the reference interface it replaces (file:line
+ * relative to /root/reference/src/kbmod/search/).  Plain pointers and sizes
+ * only; no C++ types, no torch types.  All functions that can fail return a
+ * status (0 = ok) and leave a message retrievable with kb_last_error(); the
+ * host layer turns a non-zero status into std::runtime_error (the reference's
+ * convention: kernels/kernel_memory.cu:93-136 throw std::runtime_error).
+ *
+ * Memory spaces are spelled out in the parameter names: *_host / *_dev.
+ */
+#ifndef KBMOD_HIP_H_
+#define KBMOD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The search refuses stacks deeper than this (the reference's device limit is
+ * MAX_NUM_IMAGES = 200, common.h:31; its tests require an error at T = 1000,
+ * tests/test_search.py:279-304; BASELINE config 5 needs T = 512). */
+#define KB_MAX_NUM_IMAGES 999
+
+/* common.h:55-68 -- 28-byte POD, same field order as search::Trajectory. */
+typedef struct kb_trajectory {
+    float vx, vy, lh, flux;
+    int32_t x, y, obs_count;
+} kb_trajectory;
+
+/* common.h:119-143 -- same field order and types as search::SearchParameters. */
+typedef struct kb_search_params {
+    int32_t min_observations;
+    float min_lh;
+    uint8_t do_sigmag_filter; /* bool */
+    float sgl_L, sgl_H, sigmag_coeff;
+    int32_t encode_num_bytes; /* -1, 1 or 2 */
+    int32_t x_start_min, x_start_max, y_start_min, y_start_max;
+    uint32_t results_per_pixel;
+    unsigned long long total_results;
+} kb_search_params;
+
+/* psi_phi_array_ds.h:50-69 -- same field order as search::PsiPhiArrayMeta. */
+typedef struct kb_psi_phi_meta {
+    uint64_t num_times, width, height, pixels_per_image, num_entries, block_size, total_array_size;
+    int32_t num_bytes; /* 1, 2 or 4 */
+    float psi_min_val, psi_max_val, psi_scale;
+    float phi_min_val, phi_max_val, phi_scale;
+} kb_psi_phi_meta;
+
+/* Optional per-call measurements, filled when a non-NULL pointer is passed. */
+typedef struct kb_search_stats {
+    float search_kernel_ms;   /* HIP-event time of the search kernel(s) on the launch stream */
+    float table_kernel_ms;    /* HIP-event time of the shift-table kernel */
+    uint64_t num_evals;       /* S * N_c * T */
+    uint64_t algorithmic_bytes; /* num_evals*2*bs + S*K*28 + N_c*28 + T*8 */
+    int32_t kernel_variant;   /* which template instance ran */
+    int32_t num_search_launches;
+} kb_search_stats;
+
+const char* kb_last_error(void);
+
+/* ---- device / memory helpers: kernels/kernel_memory.cu:15-136 ------------ */
+int kb_device_count(void);                  /* cuda_device_count      :15 */
+void kb_print_stats(void);                  /* cuda_print_stats       :23 */
+size_t kb_gpu_total_memory(void);           /* gpu_total_memory       :50 */
+size_t kb_gpu_free_memory(void);            /* gpu_free_memory        :60 */
+int kb_check_gpu(size_t req_memory);        /* cuda_check_gpu         :70  (1 = ok) */
+int kb_allocate_gpu_block(uint64_t memory_size, void** out_dev);                     /* :93  */
+int kb_free_gpu_block(void* ptr_dev);                                                /* :105 */
+int kb_copy_block_to_gpu(const void* src_host, void* dst_dev, uint64_t memory_size); /* :112 */
+int kb_copy_block_to_cpu(void* dst_host, const void* src_dev, uint64_t memory_size); /* :124 */
+int kb_device_synchronize(void);
+
+/* ---- PSF convolution: kernels/image_kernels.cu:68-108 (deviceConvolve) --- */
+/* Host image in, host image out, one image.  empty_is_nan = 0 reproduces the
+ * reference device kernel (empty PSF footprint -> 0.0, image_kernels.cu:61);
+ * 1 gives the reference CPU value (NaN, image_utils_cpp.cpp:60-61). */
+int kb_device_convolve(const float* src_host, float* dst_host, int width, int height, const float* psf_host,
+                       int psf_radius, int empty_is_nan);
+
+/* ---- psi/phi builder: replaces the per-image generate_psi / generate_phi /
+ * deviceConvolve loop + fill_psi_phi_array of psi_phi_array.cpp:321-410 with
+ * one fused device pass that leaves the encoded array resident in HBM. ------ */
+/* sci_dev / var_dev: [T][H][W] float32 in device memory.  psf_host: the T PSF
+ * kernels concatenated (kernel t is psf_dims[t] x psf_dims[t], row-major).
+ * num_bytes: -1/4 float, 1 uint8, 2 uint16.  On success *meta_out is filled
+ * (incl. min/max/scale) and *psi_phi_dev_out owns total_array_size bytes
+ * (release with kb_free_gpu_block). */
+int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, const float* psf_host,
+                                 const int32_t* psf_dims, int32_t num_times, int32_t height, int32_t width,
+                                 int32_t num_bytes, kb_psi_phi_meta* meta_out, void** psi_phi_dev_out,
+                                 void* stream);
+/* Same, from host images (sci_host[t] / var_host[t] are H*W float32 each). */
+int kb_build_psi_phi_from_host(const float* const* sci_host, const float* const* var_host,
+                               const float* psf_host, const int32_t* psf_dims, int32_t num_times,
+                               int32_t height, int32_t width, int32_t num_bytes, kb_psi_phi_meta* meta_out,
+                               void** psi_phi_dev_out);
+/* psi-only / phi-only images for one epoch (generate_psi / generate_phi,
+ * image_utils_cpp.cpp:126-177), host in / host out. */
+int kb_generate_psi_phi_host(const float* sci_host, const float* var_host, int width, int height,
+                             const float* psf_host, int psf_dim, float* psi_out_host, float* phi_out_host);
+
+/* ---- the search: kernels/kernels.cu:334-397 (deviceSearchFilter) --------- */
+/* psi_phi_dev: encoded [t][row][col][psi,phi] array (meta->total_array_size
+ * bytes); times_dev: double[T]; cands_dev: n_cands trajectories (vx, vy read);
+ * results_dev: at least K*search_w*search_h trajectories, fully overwritten
+ * (slot layout kernels.cu:286: ((y-y_min)*search_w + (x-x_min))*K + s).
+ * flags: bit 0 = force the per-lane exact-position path (debug / self-check). */
+int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
+                            kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
+                            kb_trajectory* results_dev, uint64_t n_results, uint32_t flags, void* stream,
+                            kb_search_stats* stats_out);
+
+/* ---- multi-GPU: merge of per-rank top-K lists (new; the reference is single-GPU).
+ * lists_dev: [n_lists][n_pixels][K] as gathered by one RCCL all_gather of each
+ * rank's kb_device_search_filter output over its candidate slice; out_dev:
+ * [n_pixels][K].  Ties go to the lower list, then the lower slot. */
+int kb_merge_topk(const kb_trajectory* lists_dev, int32_t n_lists, uint64_t n_pixels, int32_t K,
+                  kb_trajectory* out_dev, void* stream);
+
+/* ---- host instantiations of the device functions ------------------------- */
+/* kernels.cu:154-242 evaluateTrajectory called with host pointers
+ * (stack_search.cpp:203-204). */
+int kb_evaluate_trajectory_host(const kb_psi_phi_meta* meta, const void* psi_phi_host, const double* times_host,
+                                kb_search_params params, kb_trajectory* candidate);
+/* kernels.cu:77-147 SigmaGFilteredIndicesCU (kernel_helpers.cpp:94). */
+void kb_sigmag_filtered_indices(const float* values, int num_values, float sgl0, float sgl1, float sigmag_coeff,
+                                float width, int* idx_array, int* min_keep_idx, int* max_keep_idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KBMOD_HIP_H_ */

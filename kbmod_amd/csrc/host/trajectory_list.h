@@ -1,0 +1,162 @@
+// TrajectoryList: host vector of Trajectory + an HBM mirror.
+// Mirrors trajectory_list.{h,cpp}:18-239 and gpu_array.h:27-192 of the
+// reference (state machine, bounds errors, filters, extract helpers).
+#ifndef KBH_TRAJECTORY_LIST_H_
+#define KBH_TRAJECTORY_LIST_H_
+
+#include <algorithm>
+#ifdef _OPENMP
+#include <parallel/algorithm>
+#endif
+
+#include "common.h"
+#include "image_utils.h"
+
+namespace search {
+
+class TrajectoryList {
+public:
+    explicit TrajectoryList(uint64_t max_list_size) {  // trajectory_list.cpp:18-28
+        max_size = max_list_size;
+        cpu_list.resize(max_size);
+        reset_all();
+    }
+    explicit TrajectoryList(const std::vector<Trajectory>& prev_list) {  // :30-40
+        max_size = prev_list.size();
+        cpu_list = prev_list;
+        assert_valid();
+    }
+    virtual ~TrajectoryList() { free_device(); }
+    TrajectoryList(const TrajectoryList&) = delete;
+    TrajectoryList& operator=(const TrajectoryList&) = delete;
+
+    inline uint64_t get_size() const { return max_size; }
+    inline uint64_t get_memory() const { return max_size * sizeof(Trajectory); }
+    static uint64_t estimate_memory(uint64_t num_elements) { return num_elements * sizeof(Trajectory); }
+
+    inline Trajectory& get_trajectory(uint64_t index) {
+        if (index >= max_size) throw std::runtime_error("Index out of bounds.");
+        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        return cpu_list[index];
+    }
+    inline std::vector<Trajectory>& get_list() {
+        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        return cpu_list;
+    }
+    void reset_all() {  // :62-67
+        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        for (uint64_t i = 0; i < max_size; ++i) cpu_list[i].clear();
+    }
+    inline void set_trajectory(uint64_t index, const Trajectory& new_value) {
+        if (index >= max_size) throw std::runtime_error("Index out of bounds.");
+        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        cpu_list[index] = new_value;
+    }
+    void set_trajectories(const std::vector<Trajectory>& new_values) {  // :69-80
+        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        const uint64_t new_size = new_values.size();
+        resize(new_size);
+        for (uint64_t i = 0; i < new_size; ++i) cpu_list[i] = new_values[i];
+        assert_valid();
+    }
+    void resize(uint64_t new_size) {  // :48-60 (vector::resize value-initialises == clear())
+        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        cpu_list.resize(new_size);
+        max_size = new_size;
+    }
+    std::vector<Trajectory> get_batch(uint64_t start, uint64_t count) {  // :82-94
+        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        if (count == 0) throw std::runtime_error("count must be greater than 0");
+        if (start >= max_size) return std::vector<Trajectory>();
+        if (start + count >= max_size) return std::vector<Trajectory>(cpu_list.begin() + start, cpu_list.end());
+        return std::vector<Trajectory>(cpu_list.begin() + start, cpu_list.begin() + start + count);
+    }
+
+    // :96-107.  The reference's sort is unstable; a stable sort is one of the
+    // orders it may produce and makes results reproducible.
+    void sort_by_likelihood() {
+        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        auto cmp = [](const Trajectory& a, const Trajectory& b) { return b.lh < a.lh; };
+#ifdef _OPENMP
+        __gnu_parallel::stable_sort(cpu_list.begin(), cpu_list.end(), cmp);
+#else
+        std::stable_sort(cpu_list.begin(), cpu_list.end(), cmp);
+#endif
+    }
+    void filter_by_likelihood(float min_lh) {  // :109-116
+        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        auto new_end = std::remove_if(cpu_list.begin(), cpu_list.end(),
+                                      [min_lh](const Trajectory& a) { return (a.lh < min_lh); });
+        cpu_list.erase(new_end, cpu_list.end());
+        resize(cpu_list.size());
+    }
+    void filter_by_obs_count(int min_obs_count) {  // :118-126
+        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        auto new_end = std::remove_if(cpu_list.begin(), cpu_list.end(), [min_obs_count](const Trajectory& a) {
+            return (a.obs_count < min_obs_count);
+        });
+        cpu_list.erase(new_end, cpu_list.end());
+        resize(cpu_list.size());
+    }
+
+    inline bool on_gpu() const { return data_on_gpu; }
+    void move_to_gpu() {  // :128-138
+        if (data_on_gpu) return;
+        if (!has_gpu()) throw std::runtime_error("GPU not available for TrajectoryList");
+        free_device();
+        if (max_size > 0) {
+            check_status(kb_allocate_gpu_block(get_memory(), &gpu_ptr));
+            check_status(kb_copy_block_to_gpu(cpu_list.data(), gpu_ptr, get_memory()));
+        }
+        data_on_gpu = true;
+    }
+    void move_to_cpu() {  // :140-153
+        if (!data_on_gpu) return;
+        if (max_size > 0) check_status(kb_copy_block_to_cpu(cpu_list.data(), gpu_ptr, get_memory()));
+        free_device();
+        data_on_gpu = false;
+        assert_valid();
+    }
+    inline Trajectory* get_gpu_list_ptr() { return reinterpret_cast<Trajectory*>(gpu_ptr); }
+
+    void assert_valid() const {  // :155-164
+        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        for (size_t i = 0; i < cpu_list.size(); ++i) {
+            if (!cpu_list[i].is_valid()) {
+                throw std::runtime_error("Invalid trajectory detected at index " + std::to_string(i) + ": " +
+                                         cpu_list[i].to_string());
+            }
+        }
+    }
+
+private:
+    void free_device() {
+        if (gpu_ptr != nullptr) {
+            (void)kb_free_gpu_block(gpu_ptr);
+            gpu_ptr = nullptr;
+        }
+    }
+    uint64_t max_size = 0;
+    bool data_on_gpu = false;
+    std::vector<Trajectory> cpu_list;
+    void* gpu_ptr = nullptr;
+};
+
+// trajectory_list.cpp:171-239
+#define KBH_EXTRACT(NAME, TYPE, FIELD)                                                       \
+    inline std::vector<TYPE> extract_all_trajectory_##NAME(const std::vector<Trajectory>& t) { \
+        std::vector<TYPE> result(t.size());                                                  \
+        for (size_t i = 0; i < t.size(); ++i) result[i] = t[i].FIELD;                        \
+        return result;                                                                       \
+    }
+KBH_EXTRACT(x, int, x)
+KBH_EXTRACT(y, int, y)
+KBH_EXTRACT(vx, float, vx)
+KBH_EXTRACT(vy, float, vy)
+KBH_EXTRACT(lh, float, lh)
+KBH_EXTRACT(flux, float, flux)
+KBH_EXTRACT(obs_count, int, obs_count)
+#undef KBH_EXTRACT
+
+}  // namespace search
+#endif

@@ -1,0 +1,493 @@
+// psi/phi builder for MI355X (gfx950): fused pixel preparation + masked PSF
+// correlation + (optional) uint8/uint16 encoding, leaving the interleaved
+// PsiPhiArray resident in HBM.
+//
+// Replaces, for the device path, the reference's
+//   generate_psi / generate_phi / square_psf_values   image_utils_cpp.cpp:110-177
+//   convolve_psf kernel + deviceConvolve               kernels/image_kernels.cu:29-108
+//   compute_scale_params_from_image_vect, set_*_cpu_psi_phi_array, fill_psi_phi_array
+//                                                      psi_phi_array.cpp:219-372
+// (2*T single-image launches each with malloc + H2D + D2H there; here: one
+// batched launch over all epochs, tiles staged through LDS, results written
+// straight into the [t][row][col][psi,phi] array).
+//
+// Numerics follow the reference CPU loop exactly: taps visited row-major
+// (j outer, i inner), separate multiply and add (no FMA), invalid taps skipped,
+// result = (sum * psf_total) / psf_portion, invalid centre passed through.
+#include <cfloat>
+#include <cstring>
+#include <cmath>
+#include <vector>
+
+#include "kb_common.h"
+
+#pragma clang fp contract(off)
+
+namespace kb {
+
+constexpr int CONV_BX = 32;  // output tile: 32 x 8 pixels per 256-thread workgroup
+constexpr int CONV_BY = 8;
+
+struct ConvArgs {
+    const float* in0;  // MODE 0: image ; MODE 1: sci [T][H][W]
+    const float* in1;  // MODE 1: var [T][H][W]
+    float* out_plain;  // MODE 0: convolved image
+    float* out_pairs;  // MODE 1: interleaved [T][H][W][2] float32 (final array or staging)
+    const float* psf;      // all kernels, concatenated (MODE 1: followed by their squares)
+    const int* psf_off;    // [T] offset of kernel t in psf
+    const int* psf_dim;    // [T]
+    const float* psf_tot;  // [T] sum of kernel t ; MODE 1: [T..2T) sums of the squared kernels
+    int sq_base;           // MODE 1: offset of the squared kernels inside psf
+    int W, H, T;
+    int max_radius;
+    int empty_is_nan;
+    unsigned* minmax;  // MODE 1, encoded output: {psi_min, psi_max, phi_min, phi_max} as ordered keys, or null
+};
+
+// Order-preserving map float -> unsigned (finite values only are ever inserted).
+__device__ __forceinline__ unsigned float_key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+static inline float key_float(unsigned k) {
+    unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+
+// One masked correlation at LDS tile position (lx, ly) (tile pitch = pitch).
+__device__ __forceinline__ float masked_correlate(const float* __restrict__ tile, int pitch, int lx, int ly,
+                                                  const float* __restrict__ k, int dim, int rad, int tile_rad,
+                                                  float ktot, int empty_is_nan) {
+    const float centre = tile[(ly + tile_rad) * pitch + lx + tile_rad];
+    if (!__builtin_isfinite(centre)) return centre;  // image_utils_cpp.cpp:41-44
+    float sum = 0.0f, part = 0.0f;
+    for (int j = -rad; j <= rad; ++j) {
+        const float* row = tile + (ly + tile_rad + j) * pitch + lx + tile_rad;
+        const float* krow = k + (j + rad) * dim + rad;
+        for (int i = -rad; i <= rad; ++i) {
+            const float v = row[i];
+            if (__builtin_isfinite(v)) {  // out-of-image taps were staged as NaN
+                const float kk = krow[i];
+                part += kk;
+                sum += v * kk;
+            }
+        }
+    }
+    if (part == 0.0f) return empty_is_nan ? NAN : 0.0f;
+    return (sum * ktot) / part;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void kb_conv_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = blockIdx.z;
+    const int dim = a.psf_dim[t];
+    const int rad = (dim - 1) / 2;
+    const int R = a.max_radius;
+    const int pitch = CONV_BX + 2 * R;
+    const int rows = CONV_BY + 2 * R;
+    float* tile0 = smem;                                  // psi0 (or the image)
+    float* tile1 = smem + pitch * rows;                   // phi0
+    float* k0 = smem + (MODE == 1 ? 2 : 1) * pitch * rows;  // kernel
+    float* k1 = k0 + (2 * R + 1) * (2 * R + 1);           // squared kernel
+
+    const int x0 = blockIdx.x * CONV_BX, y0 = blockIdx.y * CONV_BY;
+    const size_t img = (size_t)t * a.W * a.H;
+
+    for (int e = threadIdx.x; e < dim * dim; e += 256) {
+        k0[e] = a.psf[a.psf_off[t] + e];
+        if (MODE == 1) k1[e] = a.psf[a.sq_base + a.psf_off[t] + e];
+    }
+    for (int e = threadIdx.x; e < pitch * rows; e += 256) {
+        const int ly = e / pitch, lx = e - ly * pitch;
+        const int gx = x0 + lx - R, gy = y0 + ly - R;
+        float v0 = NAN, v1 = NAN;
+        if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) {
+            const size_t p = img + (size_t)gy * a.W + gx;
+            if (MODE == 0) {
+                v0 = a.in0[p];
+            } else {
+                const float sci = a.in0[p];
+                const float var = a.in1[p];
+                // image_utils_cpp.cpp:142-149 and :165-172
+                const bool var_ok = __builtin_isfinite(var) && var != 0.0f;
+                v0 = (var_ok && __builtin_isfinite(sci)) ? (sci / var) : NAN;
+                v1 = var_ok ? (float)__ddiv_rn(1.0, (double)var) : NAN;
+            }
+        }
+        tile0[e] = v0;
+        if (MODE == 1) tile1[e] = v1;
+    }
+    __syncthreads();
+
+    const int lx = threadIdx.x % CONV_BX, ly = threadIdx.x / CONV_BX;
+    const int gx = x0 + lx, gy = y0 + ly;
+    const bool inside = gx < a.W && gy < a.H;
+    float psi = NAN, phi = NAN;
+    if (inside) {
+        psi = masked_correlate(tile0, pitch, lx, ly, k0, dim, rad, R, a.psf_tot[t], a.empty_is_nan);
+        if (MODE == 1) phi = masked_correlate(tile1, pitch, lx, ly, k1, dim, rad, R, a.psf_tot[a.T + t], a.empty_is_nan);
+        const size_t p = img + (size_t)gy * a.W + gx;
+        if (MODE == 0) {
+            a.out_plain[p] = psi;
+        } else {
+            reinterpret_cast<float2*>(a.out_pairs)[p] = make_float2(psi, phi);
+        }
+    }
+
+    if (MODE == 1 && a.minmax != nullptr) {
+        // psi_phi_array.cpp:223-232: min/max over finite values of every image.
+        unsigned kmin0 = 0xffffffffu, kmax0 = 0u, kmin1 = 0xffffffffu, kmax1 = 0u;
+        if (inside && __builtin_isfinite(psi)) kmin0 = kmax0 = float_key(psi);
+        if (inside && __builtin_isfinite(phi)) kmin1 = kmax1 = float_key(phi);
+        for (int o = 32; o > 0; o >>= 1) {
+            kmin0 = min(kmin0, (unsigned)__shfl_xor((int)kmin0, o));
+            kmax0 = max(kmax0, (unsigned)__shfl_xor((int)kmax0, o));
+            kmin1 = min(kmin1, (unsigned)__shfl_xor((int)kmin1, o));
+            kmax1 = max(kmax1, (unsigned)__shfl_xor((int)kmax1, o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (kmin0 != 0xffffffffu) {
+                atomicMin(&a.minmax[0], kmin0);
+                atomicMax(&a.minmax[1], kmax0);
+            }
+            if (kmin1 != 0xffffffffu) {
+                atomicMin(&a.minmax[2], kmin1);
+                atomicMax(&a.minmax[3], kmax1);
+            }
+        }
+    }
+}
+
+// psi_phi_array_ds.h:40-43 + psi_phi_array.cpp:284-285 (truncating cast).
+__device__ __forceinline__ unsigned encode_value(float v, float mn, float safe_max, float scale) {
+    if (!__builtin_isfinite(v)) return 0u;
+    const float lo = (safe_max < v) ? safe_max : v;
+    const float cl = (lo < mn) ? mn : lo;
+    const float q = (cl - mn) / scale;
+    const float e = (float)__dadd_rn((double)q, 1.0);
+    return (unsigned)e;
+}
+
+template <typename OUT>
+__global__ __launch_bounds__(256) void kb_encode_kernel(const float2* __restrict__ pairs, OUT* __restrict__ out,
+                                                        size_t n, float psi_min, float psi_safe_max,
+                                                        float psi_scale, float phi_min, float phi_safe_max,
+                                                        float phi_scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float2 v = pairs[i];
+        OUT o;
+        o.x = encode_value(v.x, psi_min, psi_safe_max, psi_scale);
+        o.y = encode_value(v.y, phi_min, phi_safe_max, phi_scale);
+        out[i] = o;
+    }
+}
+
+struct DeviceBuffer {  // frees on scope exit
+    void* p = nullptr;
+    ~DeviceBuffer() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+// psi_phi_array.cpp:234-242
+static float scale_from_range(float min_val, float max_val, int num_bytes) {
+    float width = (max_val - min_val);
+    if (width < 1e-6) width = 1e-6;
+    const uint64_t num_values = (1 << (8 * num_bytes)) - 1;
+    return (float)(width / (double)num_values);
+}
+
+static void fill_meta(kb_psi_phi_meta* m, int num_bytes, uint64_t T, uint64_t H, uint64_t W) {
+    // psi_phi_array.cpp:113-148
+    m->num_bytes = (num_bytes == 1 || num_bytes == 2) ? num_bytes : 4;
+    m->block_size = (uint64_t)m->num_bytes;
+    m->num_times = T;
+    m->width = W;
+    m->height = H;
+    m->pixels_per_image = W * H;
+    m->num_entries = 2 * m->pixels_per_image * T;
+    m->total_array_size = m->block_size * m->num_entries;
+    m->psi_min_val = FLT_MAX;
+    m->psi_max_val = -FLT_MAX;
+    m->psi_scale = 1.0f;
+    m->phi_min_val = FLT_MAX;
+    m->phi_max_val = -FLT_MAX;
+    m->phi_scale = 1.0f;
+}
+
+// Packs kernels (+ squares when with_squares) and their float sums.
+static int pack_psfs(const float* psf_host, const int32_t* psf_dims, int T, bool with_squares,
+                     std::vector<float>* packed, std::vector<int>* offs, std::vector<float>* totals,
+                     int* max_radius, int* sq_base) {
+    int total = 0;
+    *max_radius = 0;
+    offs->resize(T);
+    for (int t = 0; t < T; ++t) {
+        if (psf_dims[t] <= 0 || (psf_dims[t] % 2) == 0) return fail("PSF kernels must be square with an odd width.");
+        (*offs)[t] = total;
+        total += psf_dims[t] * psf_dims[t];
+        *max_radius = std::max(*max_radius, (psf_dims[t] - 1) / 2);
+    }
+    *sq_base = total;
+    packed->assign(psf_host, psf_host + total);
+    totals->assign(with_squares ? 2 * T : T, 0.0f);
+    if (with_squares) packed->resize(2 * (size_t)total);
+    for (int t = 0; t < T; ++t) {
+        const int n = psf_dims[t] * psf_dims[t];
+        float tot = 0.0f, tot_sq = 0.0f;
+        for (int e = 0; e < n; ++e) {  // image_utils_cpp.cpp:30-35 row-major float sum
+            const float k = psf_host[(*offs)[t] + e];
+            tot += k;
+            if (with_squares) {
+                const float k2 = k * k;  // image_utils_cpp.cpp:110-120
+                (*packed)[(size_t)total + (*offs)[t] + e] = k2;
+                tot_sq += k2;
+            }
+        }
+        (*totals)[t] = tot;
+        if (with_squares) (*totals)[T + t] = tot_sq;
+    }
+    return 0;
+}
+
+static size_t conv_lds_bytes(int max_radius, bool two_tiles) {
+    const int pitch = CONV_BX + 2 * max_radius, rows = CONV_BY + 2 * max_radius;
+    const int kd = 2 * max_radius + 1;
+    return sizeof(float) * ((size_t)(two_tiles ? 2 : 1) * pitch * rows + (size_t)(two_tiles ? 2 : 1) * kd * kd);
+}
+
+}  // namespace kb
+
+extern "C" {
+
+int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, const float* psf_host,
+                                 const int32_t* psf_dims, int32_t num_times, int32_t height, int32_t width,
+                                 int32_t num_bytes, kb_psi_phi_meta* meta_out, void** psi_phi_dev_out,
+                                 void* stream_v) {
+    using namespace kb;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (meta_out == nullptr || psi_phi_dev_out == nullptr) return fail("build_psi_phi: null output pointer");
+    *psi_phi_dev_out = nullptr;
+    if (num_times <= 0) return fail("Trying to fill PsiPhi from empty vectors.");
+    if (width <= 0 || height <= 0) return fail("Invalid image dimensions for PsiPhi build.");
+    if (num_bytes != -1 && num_bytes != 1 && num_bytes != 2 && num_bytes != 4) {
+        return fail("Invalid setting of num_bytes. Must be (-1 [use default], 1, 2, or 4). Got " +
+                    std::to_string(num_bytes));
+    }
+    if (sci_dev == nullptr || var_dev == nullptr || psf_host == nullptr || psf_dims == nullptr) {
+        return fail("build_psi_phi: null input pointer");
+    }
+    if (kb_device_count() == 0) return fail("GPU is not available for the psi/phi build.");
+
+    fill_meta(meta_out, num_bytes, (uint64_t)num_times, (uint64_t)height, (uint64_t)width);
+    const bool encoded = meta_out->num_bytes != 4;
+    const size_t n_pix = (size_t)num_times * height * width;
+
+    std::vector<float> packed, totals;
+    std::vector<int> offs;
+    int max_radius = 0, sq_base = 0;
+    if (pack_psfs(psf_host, psf_dims, num_times, true, &packed, &offs, &totals, &max_radius, &sq_base)) return 1;
+    const size_t lds = conv_lds_bytes(max_radius, true);
+    if (lds > 160 * 1024) return fail("PSF radius too large for the LDS-tiled convolution.");
+
+    DeviceBuffer d_psf, d_off, d_dim, d_tot, d_stage, d_minmax;
+    KB_HIP_TRY(hipMalloc(&d_psf.p, packed.size() * sizeof(float)));
+    KB_HIP_TRY(hipMalloc(&d_off.p, offs.size() * sizeof(int)));
+    KB_HIP_TRY(hipMalloc(&d_dim.p, (size_t)num_times * sizeof(int)));
+    KB_HIP_TRY(hipMalloc(&d_tot.p, totals.size() * sizeof(float)));
+    KB_HIP_TRY(hipMemcpyAsync(d_psf.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    KB_HIP_TRY(hipMemcpyAsync(d_off.p, offs.data(), offs.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    KB_HIP_TRY(hipMemcpyAsync(d_dim.p, psf_dims, (size_t)num_times * sizeof(int), hipMemcpyHostToDevice, stream));
+    KB_HIP_TRY(hipMemcpyAsync(d_tot.p, totals.data(), totals.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+
+    void* final_arr = nullptr;
+    KB_HIP_TRY(hipMalloc(&final_arr, meta_out->total_array_size));
+    DeviceBuffer final_guard;
+    final_guard.p = final_arr;  // released on any early return
+
+    float* pairs = reinterpret_cast<float*>(final_arr);
+    if (encoded) {
+        KB_HIP_TRY(hipMalloc(&d_stage.p, n_pix * 2 * sizeof(float)));
+        pairs = reinterpret_cast<float*>(d_stage.p);
+        KB_HIP_TRY(hipMalloc(&d_minmax.p, 4 * sizeof(unsigned)));
+        const unsigned init[4] = {0xffffffffu, 0u, 0xffffffffu, 0u};
+        KB_HIP_TRY(hipMemcpyAsync(d_minmax.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    }
+
+    ConvArgs a;
+    a.in0 = sci_dev;
+    a.in1 = var_dev;
+    a.out_plain = nullptr;
+    a.out_pairs = pairs;
+    a.psf = reinterpret_cast<const float*>(d_psf.p);
+    a.psf_off = reinterpret_cast<const int*>(d_off.p);
+    a.psf_dim = reinterpret_cast<const int*>(d_dim.p);
+    a.psf_tot = reinterpret_cast<const float*>(d_tot.p);
+    a.sq_base = sq_base;
+    a.W = width;
+    a.H = height;
+    a.T = num_times;
+    a.max_radius = max_radius;
+    a.empty_is_nan = 1;  // the array is the CPU StackSearch's array (image_utils_cpp.cpp:60-61)
+    a.minmax = reinterpret_cast<unsigned*>(d_minmax.p);
+
+    if (lds > 64 * 1024) {
+        KB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_conv_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    const dim3 grid((width + CONV_BX - 1) / CONV_BX, (height + CONV_BY - 1) / CONV_BY, num_times);
+    hipLaunchKernelGGL((kb_conv_kernel<1>), grid, dim3(256), lds, stream, a);
+    KB_HIP_TRY(hipGetLastError());
+
+    if (encoded) {
+        unsigned keys[4];
+        KB_HIP_TRY(hipMemcpyAsync(keys, d_minmax.p, sizeof(keys), hipMemcpyDeviceToHost, stream));
+        KB_HIP_TRY(hipStreamSynchronize(stream));
+        const bool psi_any = keys[0] != 0xffffffffu, phi_any = keys[2] != 0xffffffffu;
+        meta_out->psi_min_val = psi_any ? key_float(keys[0]) : FLT_MAX;
+        meta_out->psi_max_val = psi_any ? key_float(keys[1]) : -FLT_MAX;
+        meta_out->phi_min_val = phi_any ? key_float(keys[2]) : FLT_MAX;
+        meta_out->phi_max_val = phi_any ? key_float(keys[3]) : -FLT_MAX;
+        meta_out->psi_scale = scale_from_range(meta_out->psi_min_val, meta_out->psi_max_val, meta_out->num_bytes);
+        meta_out->phi_scale = scale_from_range(meta_out->phi_min_val, meta_out->phi_max_val, meta_out->num_bytes);
+        // psi_phi_array.cpp:150-168 set_psi_scaling / set_phi_scaling validation
+        if (meta_out->psi_min_val > meta_out->psi_max_val) {
+            return fail("Min value needs to be < max value. Got " + std::to_string(meta_out->psi_min_val) + " and " +
+                        std::to_string(meta_out->psi_max_val));
+        }
+        if (meta_out->phi_min_val > meta_out->phi_max_val) {
+            return fail("Min value needs to be < max value. Got " + std::to_string(meta_out->phi_min_val) + " and " +
+                        std::to_string(meta_out->phi_max_val));
+        }
+        if (meta_out->psi_scale <= 0 || meta_out->phi_scale <= 0) {
+            return fail("Scale value must be greater than zero.");
+        }
+        // psi_phi_array.cpp:264-265
+        const float psi_safe = (float)((double)meta_out->psi_max_val - (double)meta_out->psi_scale / 100.0);
+        const float phi_safe = (float)((double)meta_out->phi_max_val - (double)meta_out->phi_scale / 100.0);
+        const int blocks = (int)std::min<size_t>((n_pix + 255) / 256, 256 * 32);
+        if (meta_out->num_bytes == 1) {
+            hipLaunchKernelGGL((kb_encode_kernel<uchar2>), dim3(blocks), dim3(256), 0, stream,
+                               reinterpret_cast<const float2*>(pairs), reinterpret_cast<uchar2*>(final_arr), n_pix,
+                               meta_out->psi_min_val, psi_safe, meta_out->psi_scale, meta_out->phi_min_val, phi_safe,
+                               meta_out->phi_scale);
+        } else {
+            hipLaunchKernelGGL((kb_encode_kernel<ushort2>), dim3(blocks), dim3(256), 0, stream,
+                               reinterpret_cast<const float2*>(pairs), reinterpret_cast<ushort2*>(final_arr), n_pix,
+                               meta_out->psi_min_val, psi_safe, meta_out->psi_scale, meta_out->phi_min_val, phi_safe,
+                               meta_out->phi_scale);
+        }
+        KB_HIP_TRY(hipGetLastError());
+    }
+    KB_HIP_TRY(hipStreamSynchronize(stream));
+    final_guard.p = nullptr;  // ownership passes to the caller
+    *psi_phi_dev_out = final_arr;
+    return 0;
+}
+
+int kb_build_psi_phi_from_host(const float* const* sci_host, const float* const* var_host,
+                               const float* psf_host, const int32_t* psf_dims, int32_t num_times,
+                               int32_t height, int32_t width, int32_t num_bytes, kb_psi_phi_meta* meta_out,
+                               void** psi_phi_dev_out) {
+    using namespace kb;
+    if (num_times <= 0) return fail("Trying to fill PsiPhi from empty vectors.");
+    if (sci_host == nullptr || var_host == nullptr) return fail("build_psi_phi: null input pointer");
+    if (kb_device_count() == 0) return fail("GPU is not available for the psi/phi build.");
+    const size_t img = (size_t)height * width;
+    DeviceBuffer d_sci, d_var;
+    KB_HIP_TRY(hipMalloc(&d_sci.p, img * num_times * sizeof(float)));
+    KB_HIP_TRY(hipMalloc(&d_var.p, img * num_times * sizeof(float)));
+    for (int t = 0; t < num_times; ++t) {
+        KB_HIP_TRY(hipMemcpy(reinterpret_cast<float*>(d_sci.p) + img * t, sci_host[t], img * sizeof(float),
+                             hipMemcpyHostToDevice));
+        KB_HIP_TRY(hipMemcpy(reinterpret_cast<float*>(d_var.p) + img * t, var_host[t], img * sizeof(float),
+                             hipMemcpyHostToDevice));
+    }
+    return kb_build_psi_phi_from_device(reinterpret_cast<const float*>(d_sci.p),
+                                        reinterpret_cast<const float*>(d_var.p), psf_host, psf_dims, num_times,
+                                        height, width, num_bytes, meta_out, psi_phi_dev_out, nullptr);
+}
+
+int kb_device_convolve(const float* src_host, float* dst_host, int width, int height, const float* psf_host,
+                       int psf_radius, int empty_is_nan) {
+    using namespace kb;
+    // image_kernels.cu:70-72
+    if (width <= 0) return fail("Invalid width = " + std::to_string(width));
+    if (height <= 0) return fail("Invalid height = " + std::to_string(height));
+    if (psf_radius < 0) return fail("Invalid PSF radius = " + std::to_string(psf_radius));
+    if (src_host == nullptr || dst_host == nullptr || psf_host == nullptr) return fail("deviceConvolve: null pointer");
+    if (kb_device_count() == 0) return fail("Unable to perform convolve_image_gpu() without GPU.");
+
+    const int32_t dim = 2 * psf_radius + 1;
+    std::vector<float> packed, totals;
+    std::vector<int> offs;
+    int max_radius = 0, sq_base = 0;
+    if (pack_psfs(psf_host, &dim, 1, false, &packed, &offs, &totals, &max_radius, &sq_base)) return 1;
+    const size_t lds = conv_lds_bytes(max_radius, false);
+    if (lds > 160 * 1024) return fail("PSF radius too large for the LDS-tiled convolution.");
+
+    const size_t n = (size_t)width * height;
+    DeviceBuffer d_src, d_dst, d_psf, d_meta;
+    KB_HIP_TRY(hipMalloc(&d_src.p, n * sizeof(float)));
+    KB_HIP_TRY(hipMalloc(&d_dst.p, n * sizeof(float)));
+    KB_HIP_TRY(hipMalloc(&d_psf.p, packed.size() * sizeof(float)));
+    KB_HIP_TRY(hipMalloc(&d_meta.p, 16));
+    KB_HIP_TRY(hipMemcpy(d_src.p, src_host, n * sizeof(float), hipMemcpyHostToDevice));
+    KB_HIP_TRY(hipMemcpy(d_psf.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    const int meta_i[2] = {0, dim};
+    KB_HIP_TRY(hipMemcpy(d_meta.p, meta_i, sizeof(meta_i), hipMemcpyHostToDevice));
+    KB_HIP_TRY(hipMemcpy(reinterpret_cast<char*>(d_meta.p) + 8, totals.data(), sizeof(float), hipMemcpyHostToDevice));
+
+    ConvArgs a;
+    a.in0 = reinterpret_cast<const float*>(d_src.p);
+    a.in1 = nullptr;
+    a.out_plain = reinterpret_cast<float*>(d_dst.p);
+    a.out_pairs = nullptr;
+    a.psf = reinterpret_cast<const float*>(d_psf.p);
+    a.psf_off = reinterpret_cast<const int*>(d_meta.p);
+    a.psf_dim = reinterpret_cast<const int*>(d_meta.p) + 1;
+    a.psf_tot = reinterpret_cast<const float*>(reinterpret_cast<char*>(d_meta.p) + 8);
+    a.sq_base = 0;
+    a.W = width;
+    a.H = height;
+    a.T = 1;
+    a.max_radius = max_radius;
+    a.empty_is_nan = empty_is_nan;
+    a.minmax = nullptr;
+    if (lds > 64 * 1024) {
+        KB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_conv_kernel<0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    const dim3 grid((width + CONV_BX - 1) / CONV_BX, (height + CONV_BY - 1) / CONV_BY, 1);
+    hipLaunchKernelGGL((kb_conv_kernel<0>), grid, dim3(256), lds, nullptr, a);
+    KB_HIP_TRY(hipGetLastError());
+    KB_HIP_TRY(hipMemcpy(dst_host, d_dst.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int kb_generate_psi_phi_host(const float* sci_host, const float* var_host, int width, int height,
+                             const float* psf_host, int psf_dim, float* psi_out_host, float* phi_out_host) {
+    using namespace kb;
+    if (sci_host == nullptr || var_host == nullptr || psf_host == nullptr) return fail("generate_psi_phi: null input");
+    kb_psi_phi_meta meta;
+    void* arr = nullptr;
+    const float* sci_list[1] = {sci_host};
+    const float* var_list[1] = {var_host};
+    const int32_t dims[1] = {psf_dim};
+    if (kb_build_psi_phi_from_host(sci_list, var_list, psf_host, dims, 1, height, width, 4, &meta, &arr)) return 1;
+    const size_t n = (size_t)width * height;
+    std::vector<float> pairs(2 * n);
+    const int rc = kb_copy_block_to_cpu(pairs.data(), arr, 2 * n * sizeof(float));
+    (void)hipFree(arr);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) {
+        if (psi_out_host) psi_out_host[i] = pairs[2 * i];
+        if (phi_out_host) phi_out_host[i] = pairs[2 * i + 1];
+    }
+    return 0;
+}
+
+}  // extern "C"

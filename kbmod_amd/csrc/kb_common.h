@@ -1,0 +1,56 @@
+// Internal helpers shared by the translation units of libkbmod_hip.so.
+#ifndef KB_COMMON_H_
+#define KB_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <string>
+
+#include "kbmod_hip.h"
+
+namespace kb {
+
+// Thread-local message behind kb_last_error().
+void set_error(const std::string& msg);
+int fail(const std::string& msg);  // set_error + return 1
+
+#define KB_HIP_TRY(expr)                                                                          \
+    do {                                                                                          \
+        hipError_t kb_err_ = (expr);                                                              \
+        if (kb_err_ != hipSuccess) {                                                              \
+            return kb::fail(std::string(#expr) + " failed: " + hipGetErrorString(kb_err_));       \
+        }                                                                                         \
+    } while (0)
+
+constexpr int WAVE = 64;  // gfx950 wavefront
+
+// RAII pair of HIP events recorded on the launch stream (bench/roofline timing).
+struct EventTimer {
+    hipEvent_t start = nullptr, stop = nullptr;
+    hipStream_t stream;
+    bool active;
+    EventTimer(hipStream_t s, bool enable) : stream(s), active(enable) {
+        if (active) {
+            if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) active = false;
+        }
+    }
+    void begin() {
+        if (active) (void)hipEventRecord(start, stream);
+    }
+    float end() {  // synchronises on the stop event
+        if (!active) return 0.0f;
+        float ms = 0.0f;
+        (void)hipEventRecord(stop, stream);
+        (void)hipEventSynchronize(stop);
+        (void)hipEventElapsedTime(&ms, start, stop);
+        return ms;
+    }
+    ~EventTimer() {
+        if (start) (void)hipEventDestroy(start);
+        if (stop) (void)hipEventDestroy(stop);
+    }
+};
+
+}  // namespace kb
+#endif

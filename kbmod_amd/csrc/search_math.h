@@ -1,0 +1,222 @@
+// Arithmetic shared by the device search kernel and its host instantiation.
+// Everything here must reproduce the reference's IEEE operation sequence bit
+// for bit; the library is built with
+// -ffp-contract=off and the position formula additionally uses the explicit
+// round-to-nearest intrinsics on the device so that no FMA can appear.
+//
+// References (relative to /root/reference/src/kbmod/search/):
+//   predict_index             kernels/kernels.cu:33-35, cpu_search_algorithms.cpp:35-36
+//   read_encoded_psi_phi      kernels/kernels.cu:37-71, psi_phi_array.cpp:172-205
+//   SigmaGFilteredIndicesCU   kernels/kernels.cu:77-147
+//   evaluateTrajectory        kernels/kernels.cu:154-242
+#ifndef KB_SEARCH_MATH_H_
+#define KB_SEARCH_MATH_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+
+#include "kbmod_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace kb {
+
+#define KB_HD __host__ __device__ __forceinline__
+
+// (int)floor((double)pos0 + (double)vel0 * time + 0.5) with every operation
+// rounded separately.  Returns false when the value does not fit an int (the
+// reference then indexes out of bounds and reads NO_DATA either way).
+KB_HD bool predict_index(int pos0, float vel0, double time, int* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double prod = __dmul_rn((double)vel0, time);
+    const double s = __dadd_rn((double)pos0, prod);
+    const double v = floor(__dadd_rn(s, 0.5));
+#else
+    volatile double prod = (double)vel0 * time;  // volatile: keep the separate roundings on the host too
+    volatile double s = (double)pos0 + prod;
+    const double v = std::floor(s + 0.5);
+#endif
+    if (!(v >= -2147483648.0 && v <= 2147483647.0)) {
+        *out = -1;
+        return false;
+    }
+    *out = (int)v;
+    return true;
+}
+
+// decode_uint_scalar (psi_phi_array_ds.h:45-47): double arithmetic, one
+// rounding to float at the end.  code != 0.
+KB_HD float decode_code(float code, float scale, float min_val) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (float)__dadd_rn(__dmul_rn(__dadd_rn((double)code, -1.0), (double)scale), (double)min_val);
+#else
+    volatile double p = ((double)code - 1.0) * (double)scale;
+    return (float)(p + (double)min_val);
+#endif
+}
+
+// One (psi, phi) sample with the reference's bounds rule; NaN = NO_DATA.
+KB_HD void read_psi_phi(const kb_psi_phi_meta& m, const void* arr, uint64_t t, int row, int col, float* psi,
+                        float* phi) {
+    *psi = NAN;
+    *phi = NAN;
+    if (row < 0 || col < 0 || (uint64_t)row >= m.height || (uint64_t)col >= m.width || t >= m.num_times ||
+        arr == nullptr)
+        return;
+    const uint64_t start = 2 * (m.pixels_per_image * t + (uint64_t)row * m.width + (uint64_t)col);
+    if (m.num_bytes == 4) {
+        *psi = reinterpret_cast<const float*>(arr)[start];
+        *phi = reinterpret_cast<const float*>(arr)[start + 1];
+        return;
+    }
+    float pv, fv;
+    if (m.num_bytes == 1) {
+        pv = (float)reinterpret_cast<const uint8_t*>(arr)[start];
+        fv = (float)reinterpret_cast<const uint8_t*>(arr)[start + 1];
+    } else {
+        pv = (float)reinterpret_cast<const uint16_t*>(arr)[start];
+        fv = (float)reinterpret_cast<const uint16_t*>(arr)[start + 1];
+    }
+    *psi = (pv == 0.0f) ? NAN : decode_code(pv, m.psi_scale, m.psi_min_val);
+    *phi = (fv == 0.0f) ? NAN : decode_code(fv, m.phi_scale, m.phi_min_val);
+}
+
+KB_HD float lh_from_sums(float psi_sum, float phi_sum) {
+    return (phi_sum > 0.0f) ? (psi_sum / sqrtf(phi_sum)) : -1.0f;
+}
+KB_HD float flux_from_sums(float psi_sum, float phi_sum) {
+    return (phi_sum > 0.0f) ? (psi_sum / phi_sum) : -1.0f;
+}
+
+// Strided views: the device keeps per-lane scratch interleaved across the 64
+// lanes of a wave (element i of a lane at p[i * 64]); the host uses stride 1.
+template <typename T, int STRIDE>
+struct StridedView {
+    T* p;
+    KB_HD T& operator[](int i) const { return p[(size_t)i * STRIDE]; }
+};
+
+// kernels.cu:77-147.  The exchange sort is reproduced literally (idx[j] is held
+// in a register across the inner loop, which does not change the sequence of
+// comparisons or swaps): the permutation it leaves among equal values decides
+// the summation order of the clipped sums.
+template <typename VAL, typename IDX>
+KB_HD void sigmag_filtered_indices_t(const VAL& values, int num_values, float sgl0, float sgl1, float sigmag_coeff,
+                                     float width, const IDX& idx_array, int* min_keep_idx, int* max_keep_idx) {
+    if (num_values == 0) {
+        *min_keep_idx = 0;
+        *max_keep_idx = -1;
+        return;
+    }
+    if ((double)sgl0 < 0.0001) sgl0 = (float)0.0001;
+    if ((double)sgl1 > 0.9999) sgl1 = (float)0.9999;
+
+    for (int j = 0; j < num_values; j++) idx_array[j] = j;
+    for (int j = 0; j < num_values; j++) {
+        int ij = idx_array[j];
+        float vj = values[ij];
+        for (int k = j + 1; k < num_values; k++) {
+            const int ik = idx_array[k];
+            const float vk = values[ik];
+            if (vj > vk) {
+                idx_array[k] = ij;
+                ij = ik;
+                vj = vk;
+            }
+        }
+        idx_array[j] = ij;
+    }
+    int pct_L = (int)((double)ceilf((float)num_values * sgl0) + 0.001) - 1;
+    pct_L = (pct_L < 0) ? 0 : pct_L;
+    pct_L = (pct_L >= num_values) ? (num_values - 1) : pct_L;
+    int pct_H = (int)((double)ceilf((float)num_values * sgl1) + 0.001) - 1;
+    pct_H = (pct_H < 0) ? 0 : pct_H;
+    pct_H = (pct_H >= num_values) ? (num_values - 1) : pct_H;
+    int median_ind = (int)(ceil((double)num_values * 0.5) + 0.001) - 1;
+    median_ind = (median_ind < 0) ? 0 : median_ind;
+    median_ind = (median_ind >= num_values) ? (num_values - 1) : median_ind;
+
+    const float sigma_g = sigmag_coeff * (values[idx_array[pct_H]] - values[idx_array[pct_L]]);
+    const float wsg = width * sigma_g;
+    const float vmed = values[idx_array[median_ind]];
+    const float min_value = vmed - wsg;
+    const float max_value = vmed + wsg;
+
+    int start = 0;
+    while ((start < median_ind) && (values[idx_array[start]] < min_value)) ++start;
+    *min_keep_idx = start;
+    int end = median_ind + 1;
+    while ((end < num_values) && (values[idx_array[end]] <= max_value)) ++end;
+    *max_keep_idx = end - 1;
+}
+
+// Scratch for one clipped evaluation: 3 floats + 1 index per epoch.
+template <int STRIDE>
+struct SigmaGScratch {
+    StridedView<float, STRIDE> psi, phi, lc;
+    StridedView<int, STRIDE> idx;
+};
+
+// Full evaluateTrajectory (kernels.cu:154-242) for one trajectory with exact
+// per-sample positions.  scratch may be null when !do_sigmag_filter.
+template <int STRIDE>
+KB_HD void evaluate_trajectory_full(const kb_psi_phi_meta& m, const void* arr, const double* times,
+                                    const kb_search_params& p, kb_trajectory* c,
+                                    const SigmaGScratch<STRIDE>* scratch) {
+    float psi_sum = 0.0f, phi_sum = 0.0f;
+    c->obs_count = 0;
+    c->lh = -1.0f;
+    c->flux = -1.0f;
+    const bool keep = p.do_sigmag_filter && scratch != nullptr;
+    int num_seen = 0;
+    const int T = (int)m.num_times;
+    for (int i = 0; i < T; ++i) {
+        const double t = times[i];
+        int cx, cy;
+        const bool okx = predict_index(c->x, c->vx, t, &cx);
+        const bool oky = predict_index(c->y, c->vy, t, &cy);
+        float psi = NAN, phi = NAN;
+        if (okx && oky) read_psi_phi(m, arr, (uint64_t)i, cy, cx, &psi, &phi);
+        if (__builtin_isfinite(psi) && __builtin_isfinite(phi)) {
+            psi_sum += psi;
+            phi_sum += phi;
+            if (keep) {
+                scratch->psi[num_seen] = psi;
+                scratch->phi[num_seen] = phi;
+            }
+            num_seen += 1;
+        }
+    }
+    c->obs_count = num_seen;
+    c->lh = lh_from_sums(psi_sum, phi_sum);
+    c->flux = flux_from_sums(psi_sum, phi_sum);
+
+    if ((c->obs_count < p.min_observations) || (c->obs_count == 0) ||
+        (p.do_sigmag_filter && c->lh < p.min_lh))
+        return;
+    if (!keep) return;
+
+    for (int i = 0; i < num_seen; ++i) {
+        const float f = scratch->phi[i];
+        scratch->lc[i] = (f != 0.0f) ? (scratch->psi[i] / f) : 0.0f;
+    }
+    int min_keep = 0, max_keep = num_seen - 1;
+    sigmag_filtered_indices_t(scratch->lc, num_seen, p.sgl_L, p.sgl_H, p.sigmag_coeff, 2.0f, scratch->idx,
+                              &min_keep, &max_keep);
+    if (min_keep < 0) min_keep = 0;
+    if (max_keep >= num_seen) max_keep = num_seen - 1;
+    float new_psi = 0.0f, new_phi = 0.0f;
+    for (int i = min_keep; i <= max_keep; i++) {  // sorted-value order
+        const int id = scratch->idx[i];
+        new_psi += scratch->psi[id];
+        new_phi += scratch->phi[id];
+    }
+    c->lh = lh_from_sums(new_psi, new_phi);
+    c->flux = flux_from_sums(new_psi, new_phi);
+}
+
+}  // namespace kb
+#endif

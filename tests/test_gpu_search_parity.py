@@ -1,0 +1,130 @@
+"""GPU parity: the HIP search (through the C ABI behind StackSearch.search_all(..., True))
+against the oracle's kernel-semantics search on the same seeded inputs.
+
+Bar: bit-exact on every field (x, y, obs_count are integers; vx, vy, lh, flux are
+compared bit for bit as well, which is stricter than the 1e-4 the north star asks).
+"""
+
+import numpy as np
+import pytest
+
+from kbmod_amd import fake_data as fd
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+OBJ = [(17, 12, 21.0, 16.0, 250.0), (60, 40, -8.0, 11.0, 180.0)]
+
+
+def _check(got, exp):
+    assert got.shape == exp.shape, (got.shape, exp.shape)
+    bad = np.nonzero(np.any(got != exp, axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} rows differ, first {bad[:3]}: {got[bad[:3]]} vs {exp[bad[:3]]}"
+
+
+@pytest.fixture(scope="module")
+def stack():
+    return util.make_stack(20, 80, 100, seed=100, noise=4.0, psf=1.0, objects=OBJ, mask_fraction=0.01)
+
+
+@pytest.fixture(scope="module")
+def cands():
+    return fd.kbmod_v1_candidates(12, 5.0, 40.0, 11, 0.0, 1.5)  # 132: not a multiple of the chunk
+
+
+def test_requires_gpu(kb):
+    assert kb.kb_has_gpu(), "-m gpu tests need a device; the product has no CPU fallback"
+
+
+def test_float_default(kb, orc, stack, cands):
+    got, exp, s = util.run_both(kb, orc, stack, *cands, {})
+    _check(got, exp)
+    assert s.last_search_stats()["num_evals"] == 20 * 80 * 100 * 132
+
+
+def test_table_path_equals_exact_path(kb, orc, stack, cands):
+    a, _, _ = util.run_both(kb, orc, stack, *cands, {}, flags=0)
+    b, _, _ = util.run_both(kb, orc, stack, *cands, {}, flags=1)
+    _check(a, b)
+
+
+@pytest.mark.parametrize("K", [1, 5, 8, 10, 16, 20, 32])
+def test_results_per_pixel(kb, orc, stack, cands, K):
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, {"K": K, "min_lh": -1e30})
+    _check(got, exp)
+    assert len(got) == K * 80 * 100  # every slot survives min_lh = -1e30, placeholders are -FLT_MAX
+
+
+def test_min_obs_and_min_lh(kb, orc, stack, cands):
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, {"min_obs": 12, "min_lh": 2.5})
+    _check(got, exp)
+
+
+def test_extended_bounds(kb, orc, stack, cands):
+    cfg = {"xb": (-10, 110), "yb": (-10, 90), "K": 5}
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, cfg)
+    _check(got, exp)
+
+
+def test_reduced_bounds(kb, orc, stack, cands):
+    cfg = {"xb": (5, 95), "yb": (5, 75), "K": 10, "min_lh": -1e30}
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, cfg)
+    _check(got, exp)
+    assert len(got) == 10 * 90 * 70
+
+
+def test_fewer_candidates_than_slots(kb, orc, stack):
+    vx, vy = fd.velocity_grid_candidates(2, -5.0, 5.0, 2, -3.0, 3.0)
+    got, exp, _ = util.run_both(kb, orc, stack, vx, vy, {"min_lh": -1e30})
+    _check(got, exp)
+
+
+@pytest.mark.parametrize("num_bytes", [1, 2])
+def test_encoded(kb, orc, stack, cands, num_bytes):
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, {"min_obs": 10}, num_bytes=num_bytes)
+    _check(got, exp)
+
+
+@pytest.mark.parametrize("num_bytes", [-1, 1])
+def test_sigma_g(kb, orc, stack, cands, num_bytes):
+    cfg = {"sigmag": (0.25, 0.75, 0.7413, 5.0), "min_obs": 8}
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, cfg, num_bytes=num_bytes)
+    _check(got, exp)
+    assert len(got) > 0
+
+
+def test_sigma_g_low_threshold(kb, orc):
+    # min_lh below every likelihood: every trajectory with data is clipped.
+    st = util.make_stack(9, 24, 40, seed=5, objects=[(8, 8, 10.0, 4.0, 120.0)], mask_fraction=0.05)
+    vx, vy = fd.kbmod_v1_candidates(4, 2.0, 20.0, 5, 0.0, 1.2)
+    cfg = {"sigmag": (0.15, 0.85, 0.4824, -50.0), "K": 4}
+    got, exp, _ = util.run_both(kb, orc, st, vx, vy, cfg)
+    _check(got, exp)
+
+
+def test_half_integer_shifts_take_exact_path(kb, orc):
+    # vx * t + 0.5 lands exactly on integers: the shift table must refuse these.
+    times = np.array([0.0, 0.25, 0.5, 0.75, 1.0, 1.5])
+    st = util.make_stack(6, 32, 70, seed=11, times=times)
+    vx = np.array([2.0, 6.0, -2.0, 1.0], dtype=np.float32)
+    vy = np.array([2.0, -6.0, 1.0, 0.0], dtype=np.float32)
+    got, exp, _ = util.run_both(kb, orc, st, vx, vy, {"min_lh": -1e30, "xb": (-3, 73), "yb": (-3, 35)})
+    _check(got, exp)
+
+
+def test_too_many_images(kb):
+    st = util.make_stack(1000, 10, 12, seed=1, noise=0.5)
+    s = kb.StackSearch(st.sci, st.var, st.psfs, st.zeroed_times)
+    t = kb.Trajectory(x=0, y=0, vx=0.0, vy=0.0)
+    with pytest.raises(RuntimeError):
+        s.search_all([t], True)
+    with pytest.raises(RuntimeError):
+        s.evaluate_single_trajectory(t, True)
+
+
+def test_deep_stack_512(kb, orc):
+    # beyond the reference's 200-epoch device limit
+    st = util.make_stack(512, 16, 70, seed=3, objects=[(5, 5, 30.0, 6.0, 80.0)])
+    vx, vy = fd.kbmod_v1_candidates(4, 10.0, 40.0, 3, 0.0, 0.6)
+    got, exp, _ = util.run_both(kb, orc, st, vx, vy, {"min_obs": 100}, num_bytes=2)
+    _check(got, exp)
