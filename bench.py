@@ -65,7 +65,6 @@ def load_lib():
                                                  C.c_int32, C.c_int32, C.POINTER(Meta), C.POINTER(C.c_void_p), C.c_void_p]
     lib.kb_device_search_filter.argtypes = [C.POINTER(Meta), C.c_void_p, C.c_void_p, Params, C.c_void_p, C.c_uint64,
                                             C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
-    lib.kb_merge_topk.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]
     lib.kb_free_gpu_block.argtypes = [C.c_void_p]
     lib.kb_copy_block_to_cpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     return lib
@@ -93,6 +92,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    from kbmod_amd import distributed as kdist
     from kbmod_amd import fake_data as fd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,8 +166,7 @@ def main():
         check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), n_local,
                                                results.data_ptr(), S * K, 0, stream, C.byref(st)))
         if world > 1:
-            dist.all_gather_into_tensor(gathered.view(-1), results.view(-1))
-            check(lib, lib.kb_merge_topk(gathered.data_ptr(), world, S, K, merged.data_ptr(), stream))
+            kdist.gather_and_merge(results, S, K, gathered=gathered, out=merged)
         if record:
             kernel_ms.append(st.search_kernel_ms)
         return st

@@ -297,6 +297,17 @@ PYBIND11_MODULE(search, m) {
     m.def("extract_all_trajectory_flux", &extract_all_trajectory_flux);
     m.def("extract_all_trajectory_obs_count", &extract_all_trajectory_obs_count);
 
+    m.def("merge_topk_host", [](py::array_t<uint8_t, py::array::c_style> raw, int n_lists, uint64_t n_pixels, int K) {
+        if ((uint64_t)raw.size() != (uint64_t)n_lists * n_pixels * K * sizeof(Trajectory)) {
+            throw std::runtime_error("merge_topk_host: buffer size does not match n_lists * n_pixels * K * 28");
+        }
+        std::vector<Trajectory> out =
+                merge_topk_host(reinterpret_cast<const Trajectory*>(raw.data()), n_lists, n_pixels, K);
+        py::array_t<uint8_t> res((py::ssize_t)(out.size() * sizeof(Trajectory)));
+        if (!out.empty()) std::memcpy(res.mutable_data(), out.data(), out.size() * sizeof(Trajectory));
+        return res;
+    });
+
     // ---- cpu_search_algorithms.cpp:128-131 ----
     m.def("evaluate_trajectory_cpu", &evaluate_trajectory_cpu);
     m.def("search_cpu_only", &search_cpu_only);

@@ -158,5 +158,32 @@ KBH_EXTRACT(flux, float, flux)
 KBH_EXTRACT(obs_count, int, obs_count)
 #undef KBH_EXTRACT
 
+// Host twin of the device merge kernel kb_merge_topk (search_kernels.hip): lists
+// = [n_lists][n_pixels][K], each per-pixel list sorted descending by lh; ties go
+// to the lower list, then the lower slot.
+inline std::vector<Trajectory> merge_topk_host(const Trajectory* lists, int n_lists, uint64_t n_pixels, int K) {
+    std::vector<Trajectory> out(n_pixels * (uint64_t)K);
+    const uint64_t stride = n_pixels * (uint64_t)K;
+    std::vector<int> head(n_lists);
+    for (uint64_t pix = 0; pix < n_pixels; ++pix) {
+        std::fill(head.begin(), head.end(), 0);
+        for (int s = 0; s < K; ++s) {
+            int best = -1;
+            float best_lh = 0.0f;
+            for (int r = 0; r < n_lists; ++r) {
+                if (head[r] >= K) continue;
+                const float lh = lists[(uint64_t)r * stride + pix * K + head[r]].lh;
+                if (best < 0 || lh > best_lh) {
+                    best = r;
+                    best_lh = lh;
+                }
+            }
+            out[pix * K + s] = lists[(uint64_t)best * stride + pix * K + head[best]];
+            head[best] += 1;
+        }
+    }
+    return out;
+}
+
 }  // namespace search
 #endif
