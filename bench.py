@@ -56,7 +56,7 @@ class Stats(C.Structure):
 
 
 def load_lib():
-    path = os.path.join(ROOT, "kbmod_amd", "lib", "libkbmod_hip.so")
+    path = os.environ.get("KBMOD_HIP_LIB", os.path.join(ROOT, "kbmod_amd", "lib", "libkbmod_hip.so"))
     if not os.path.exists(path):
         raise RuntimeError("libkbmod_hip.so is not built (run __graft_entry__.build()); there is no fallback path")
     lib = C.CDLL(path)
@@ -85,6 +85,11 @@ def main():
     ap.add_argument("--vel-steps", type=int, default=32)
     ap.add_argument("--ang-steps", type=int, default=32)
     ap.add_argument("--num-bytes", type=int, default=-1, choices=[-1, 1, 2, 4])
+    ap.add_argument("--min-vel", type=float, default=5.0)
+    ap.add_argument("--max-vel", type=float, default=40.0)
+    ap.add_argument("--min-ang", type=float, default=0.0)
+    ap.add_argument("--max-ang", type=float, default=1.5)
+    ap.add_argument("--flags", type=int, default=0, help="kb_device_search_filter flags (1 exact positions, 4 LDS-staged kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
     args = ap.parse_args()
@@ -146,7 +151,8 @@ def main():
 
     # ---- candidates: KBMODV1Search(32, 5, 40, 32, 0, 1.5) = 1024 per GPU; rank r
     # takes the r-th contiguous slice of an N*1024 candidate (v, theta) grid ----
-    vx, vy = fd.kbmod_v1_candidates(args.vel_steps, 5.0, 40.0, args.ang_steps * world, 0.0, 1.5)
+    vx, vy = fd.kbmod_v1_candidates(args.vel_steps, args.min_vel, args.max_vel, args.ang_steps * world, args.min_ang,
+                                    args.max_ang)
     n_local = args.vel_steps * args.ang_steps
     sl = slice(rank * n_local, (rank + 1) * n_local)
     cands_np = np.zeros((n_local, 7), dtype=np.float32)
@@ -164,7 +170,7 @@ def main():
     def step(record):
         st = Stats()
         check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), n_local,
-                                               results.data_ptr(), S * K, 0, stream, C.byref(st)))
+                                               results.data_ptr(), S * K, args.flags, stream, C.byref(st)))
         if world > 1:
             kdist.gather_and_merge(results, S, K, gathered=gathered, out=merged)
         if record:

@@ -111,7 +111,10 @@ int kb_generate_psi_phi_host(const float* sci_host, const float* var_host, int w
  * bytes); times_dev: double[T]; cands_dev: n_cands trajectories (vx, vy read);
  * results_dev: at least K*search_w*search_h trajectories, fully overwritten
  * (slot layout kernels.cu:286: ((y-y_min)*search_w + (x-x_min))*K + s).
- * flags: bit 0 = force the per-lane exact-position path (debug / self-check). */
+ * flags: bit 0 = force the per-lane exact-position path (debug / self-check);
+ *        bit 3 (value 8) = always decode uint8/uint16 samples in double (skip the verified fp32-FMA form);
+ *        bit 2 (value 4) = use the LDS-staged kernel kb_search_lds instead of the default
+ *        kb_search_direct (falls back to direct when a chunk's footprint does not fit the stage). */
 int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
                             kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
                             kb_trajectory* results_dev, uint64_t n_results, uint32_t flags, void* stream,

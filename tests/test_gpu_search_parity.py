@@ -32,6 +32,16 @@ def cands():
     return fd.kbmod_v1_candidates(12, 5.0, 40.0, 11, 0.0, 1.5)  # 132: not a multiple of the chunk
 
 
+@pytest.fixture(scope="module")
+def lds_cands():
+    # No candidate lands on an exact half-pixel, so every chunk is LDS-stageable.
+    return fd.kbmod_v1_candidates(16, 5.0, 20.0, 9, 0.05, 1.45)  # 16 = 2 chunks per angle row, <= 8 px spread
+
+
+def _used_lds(search):
+    return search.last_search_stats()["kernel_variant"] >= 10000
+
+
 def test_requires_gpu(kb):
     assert kb.kb_has_gpu(), "-m gpu tests need a device; the product has no CPU fallback"
 
@@ -40,6 +50,27 @@ def test_float_default(kb, orc, stack, cands):
     got, exp, s = util.run_both(kb, orc, stack, *cands, {})
     _check(got, exp)
     assert s.last_search_stats()["num_evals"] == 20 * 80 * 100 * 132
+
+
+@pytest.mark.parametrize("num_bytes", [-1, 1, 2])
+@pytest.mark.parametrize("cfg", [{}, {"K": 10, "min_obs": 5}, {"xb": (-10, 110), "yb": (-10, 90), "min_lh": -1e30},
+                                 {"sigmag": (0.25, 0.75, 0.7413, 5.0), "min_obs": 8}])
+def test_lds_kernel(kb, orc, stack, lds_cands, cfg, num_bytes):
+    """The LDS-staged kernel (masked pixels -> validity plane; off-image starts -> edge staging)."""
+    got, exp, s = util.run_both(kb, orc, stack, *lds_cands, cfg, num_bytes=num_bytes, flags=4)
+    assert _used_lds(s)
+    _check(got, exp)
+
+
+def test_lds_kernel_clean_stack(kb, orc, lds_cands):
+    """No masked pixel anywhere: interior tiles take the raw (validity-free) staging path."""
+    st = util.make_stack(21, 96, 200, seed=77, objects=OBJ)
+    got, exp, s = util.run_both(kb, orc, st, *lds_cands, {"min_obs": 3}, flags=4)
+    assert _used_lds(s)
+    _check(got, exp)
+    a, _, s2 = util.run_both(kb, orc, st, *lds_cands, {"min_obs": 3}, flags=0)
+    assert not _used_lds(s2)
+    _check(a, exp)
 
 
 def test_table_path_equals_exact_path(kb, orc, stack, cands):
@@ -79,9 +110,10 @@ def test_fewer_candidates_than_slots(kb, orc, stack):
     _check(got, exp)
 
 
+@pytest.mark.parametrize("flags", [0, 8])  # 0: verified fp32-FMA decode, 8: double decode
 @pytest.mark.parametrize("num_bytes", [1, 2])
-def test_encoded(kb, orc, stack, cands, num_bytes):
-    got, exp, _ = util.run_both(kb, orc, stack, *cands, {"min_obs": 10}, num_bytes=num_bytes)
+def test_encoded(kb, orc, stack, cands, num_bytes, flags):
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, {"min_obs": 10}, num_bytes=num_bytes, flags=flags)
     _check(got, exp)
 
 
