@@ -751,6 +751,52 @@ __global__ __launch_bounds__(256, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_se
 }
 
 // ---------------------------------------------------------------------------
+// large-K kernel (results_per_pixel > 32, e.g. TrajectoryExplorer's K up to 10 000)
+// ---------------------------------------------------------------------------
+// One lane per start pixel, candidates evaluated one at a time with exact
+// per-lane positions, the K-slot list kept in the result array itself and
+// updated with the reference's swap-down (kernels.cu:304-331).  This is the
+// reference kernel's own structure; it is only used where the register top-K
+// cannot hold the list (few start pixels x many results in practice).
+template <bool SIGMAG>
+__global__ __launch_bounds__(256) void kb_search_large_k(const SearchArgs a) {
+    const TileCoords tc = tile_coords(a);
+    if (!tc.row_active || tc.x_i >= a.sw) return;
+    SigmaGScratch<WAVE> scratch = {};
+    if constexpr (SIGMAG) scratch = make_scratch(a, tc);
+    kb_trajectory* slots = a.results + ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
+    for (int s = 0; s < a.K; ++s) {  // kernels.cu:293-301
+        kb_trajectory p;
+        p.x = tc.x;
+        p.y = tc.y;
+        p.vx = 0.0f;
+        p.vy = 0.0f;
+        p.lh = -FLT_MAX;
+        p.flux = 0.0f;
+        p.obs_count = 0;
+        slots[s] = p;
+    }
+    for (int cand = 0; cand < a.n_cands; ++cand) {
+        kb_trajectory cur;
+        cur.x = tc.x;
+        cur.y = tc.y;
+        cur.vx = a.cands[cand].vx;
+        cur.vy = a.cands[cand].vy;
+        evaluate_trajectory_full<WAVE>(a.meta, a.psi_phi, a.times, a.params, &cur, SIGMAG ? &scratch : nullptr);
+        if ((cur.obs_count < a.params.min_observations) || (a.params.do_sigmag_filter && cur.lh < a.params.min_lh))
+            continue;  // kernels.cu:318-320
+        if (!(cur.lh > slots[a.K - 1].lh)) continue;  // cannot displace anything
+        for (int s = 0; s < a.K; ++s) {  // kernels.cu:323-330
+            const kb_trajectory t = slots[s];
+            if (cur.lh > t.lh) {
+                slots[s] = cur;
+                cur = t;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // multi-GPU: per-pixel merge of the per-rank top-K lists after the RCCL gather
 // ---------------------------------------------------------------------------
 // lists[r][pixel][K] (each sorted descending by lh, placeholders lh = -FLT_MAX
@@ -922,9 +968,6 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
         std::abs((long)params.y_start_max) > (1 << 21)) {
         flags |= 1u;  // start coordinates outside the proven range of the shift table
     }
-    if (params.results_per_pixel > 32) {
-        return fail("results_per_pixel > 32 is not supported by the register top-K path yet.");
-    }
 
     SearchArgs a;
     a.psi_phi = psi_phi_dev;
@@ -1026,7 +1069,14 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
 
     search_timer.begin();
     int variant;
-    if (a.K <= 8) {
+    if (a.K > 32) {
+        use_lds = false;
+        if (sigmag)
+            hipLaunchKernelGGL((kb_search_large_k<true>), dim3(a.n_tiles), dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((kb_search_large_k<false>), dim3(a.n_tiles), dim3(256), 0, stream, a);
+        variant = 99;
+    } else if (a.K <= 8) {
         launch_search<8>(a, sigmag, use_lds, stream);
         variant = 8;
     } else if (a.K <= 16) {

@@ -86,6 +86,20 @@ def test_results_per_pixel(kb, orc, stack, cands, K):
     assert len(got) == K * 80 * 100  # every slot survives min_lh = -1e30, placeholders are -FLT_MAX
 
 
+def test_large_k_keeps_every_candidate(kb, orc):
+    # TrajectoryExplorer-style: K >= number of candidates, all of them come back per pixel
+    # (reference: tests/test_trajectory_explorer.py:106-124).
+    st = util.make_stack(12, 20, 24, seed=8, objects=[(6, 5, 9.0, 4.0, 150.0)], mask_fraction=0.02)
+    vx, vy = fd.velocity_grid_candidates(9, -10.0, 10.0, 7, -6.0, 6.0)  # 63 candidates
+    cfg = {"K": 100, "min_lh": -1e30, "xb": (2, 10), "yb": (1, 9)}
+    got, exp, _ = util.run_both(kb, orc, st, vx, vy, cfg)
+    _check(got, exp)
+    assert len(got) == 63 * 8 * 8  # the 37 placeholder slots per pixel carry lh = -FLT_MAX and are filtered
+    cfg = {"K": 40, "sigmag": (0.25, 0.75, 0.7413, -5.0), "xb": (2, 10), "yb": (1, 9)}
+    got, exp, _ = util.run_both(kb, orc, st, vx, vy, cfg)
+    _check(got, exp)
+
+
 def test_min_obs_and_min_lh(kb, orc, stack, cands):
     got, exp, _ = util.run_both(kb, orc, stack, *cands, {"min_obs": 12, "min_lh": 2.5})
     _check(got, exp)
