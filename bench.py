@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--max-ang", type=float, default=1.5)
     ap.add_argument("--flags", type=int, default=0, help="kb_device_search_filter flags (1 exact positions, 4 LDS-staged kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the CPU baseline sample")
     args = ap.parse_args()
 
     import torch
@@ -232,12 +232,24 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": None,
-            "kernel": "kb_search_tiles",
+            "kernel": "kb_search_direct" if args.flags & 4 == 0 else "kb_search_lds",
             "kernel_ms": k_ms,
             "algorithmic_bytes_per_launch": int(last.algorithmic_bytes),
             "kernel_evals_per_s": evals_per_step_rank / (k_ms * 1e-3),
         },
     }
+
+    # HBM-side traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (it cannot be
+    # read from inside this process); attached when the workload matches a profiled configuration.
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            traffic = json.load(fh)
+        key = f"{out['dtype']}:{T}x{H}x{W}:{n_local}"
+        if key in traffic and args.flags == 0:
+            out["roofline"]["traffic"] = traffic[key]["bytes"]
+            out["roofline"]["traffic_source"] = traffic[key]["source"]
+    except (OSError, ValueError):
+        pass
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lib, meta, arr, tcpu, vx[sl], vy[sl], args.cpu_seconds)
@@ -272,7 +284,7 @@ def cpu_baseline(lib, meta, arr, times, vx, vy, target_s):
         pp.search_cpu(cands, p)
         return time.perf_counter() - t0, rows * W * len(cands) * T
 
-    dt, ev = run(4)  # calibration
+    dt, ev = run(16)  # calibration
     rate = ev / dt
     rows = int(max(4, min(H, target_s * rate / (W * len(cands) * T))))
     dt, ev = run(rows)

@@ -148,14 +148,18 @@ __global__ __launch_bounds__(256) void kb_conv_kernel(const ConvArgs a) {
             kmin1 = min(kmin1, (unsigned)__shfl_xor((int)kmin1, o));
             kmax1 = max(kmax1, (unsigned)__shfl_xor((int)kmax1, o));
         }
+        // One lane per wave, and only when the wave's extremum can still move the
+        // global value (plain pre-read: the atomic itself stays the arbiter).  Without
+        // the pre-read ~10^6 same-address atomics serialise into milliseconds.
         if ((threadIdx.x & 63) == 0) {
+            volatile unsigned* mm = a.minmax;
             if (kmin0 != 0xffffffffu) {
-                atomicMin(&a.minmax[0], kmin0);
-                atomicMax(&a.minmax[1], kmax0);
+                if (kmin0 < mm[0]) atomicMin(&a.minmax[0], kmin0);
+                if (kmax0 > mm[1]) atomicMax(&a.minmax[1], kmax0);
             }
             if (kmin1 != 0xffffffffu) {
-                atomicMin(&a.minmax[2], kmin1);
-                atomicMax(&a.minmax[3], kmax1);
+                if (kmin1 < mm[2]) atomicMin(&a.minmax[2], kmin1);
+                if (kmax1 > mm[3]) atomicMax(&a.minmax[3], kmax1);
             }
         }
     }
