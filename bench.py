@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--max-vel", type=float, default=40.0)
     ap.add_argument("--min-ang", type=float, default=0.0)
     ap.add_argument("--max-ang", type=float, default=1.5)
+    ap.add_argument("--inset", type=int, default=0, help="shrink the start-pixel grid by this many pixels per side")
     ap.add_argument("--flags", type=int, default=0, help="kb_device_search_filter flags (1 exact positions, 4 LDS-staged kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the CPU baseline sample")
@@ -159,9 +160,11 @@ def main():
     cands_np[:, 0], cands_np[:, 1] = vx[sl], vy[sl]
     cands = torch.from_numpy(cands_np).to(dev)
 
-    S = H * W
+    ins = args.inset
+    S = (H - 2 * ins) * (W - 2 * ins)
     results = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
-    params = Params(0, 0.0, 0, 0.25, 0.75, -1.0, -1 if args.num_bytes in (-1, 4) else args.num_bytes, 0, W, 0, H, K, 0)
+    params = Params(0, 0.0, 0, 0.25, 0.75, -1.0, -1 if args.num_bytes in (-1, 4) else args.num_bytes, ins, W - ins, ins,
+                    H - ins, K, 0)
     gathered = torch.empty((world, S * K, 7), dtype=torch.float32, device=dev) if world > 1 else None
     merged = torch.empty((S * K, 7), dtype=torch.float32, device=dev) if world > 1 else None
 

@@ -48,11 +48,12 @@ constexpr int CHUNK = 8;                 // candidates accumulated together per 
 // LDS stage buffer: at most LDS_ROWS x LDS_COLS pixels per (chunk, epoch).
 // Plane A: (psi, phi) float2 with NO_DATA replaced by (+0, +0); plane B: validity
 // (1 / 0) for obs_count.
-constexpr int LDS_COLS = 96;  // pitch in pixels: 64 start columns + up to 32 of dx spread
-constexpr int LDS_ROWS = 16;  // 4 start rows + up to 12 of dy spread
+constexpr int LDS_COLS = 84;  // pitch in pixels: 64 start columns + up to 20 of dx spread
+constexpr int LDS_ROWS = 13;  // 4 start rows + up to 9 of dy spread
 constexpr int LDS_PLANE_A = LDS_ROWS * LDS_COLS * 8;  // bytes
 constexpr int LDS_PLANE_B = LDS_ROWS * LDS_COLS * 4;
-constexpr int LDS_BUF = LDS_PLANE_A + LDS_PLANE_B;  // 18 KiB; two buffers per workgroup
+constexpr int LDS_BUF = LDS_PLANE_A + LDS_PLANE_B;  // 12.8 KiB
+constexpr int LDS_NBUF = 3;                         // ring of three: 38.4 KiB per workgroup, 4 workgroups per CU
 
 struct ChunkInfo {
     int dx_min, dx_max, dy_min, dy_max;  // bounding box of the chunk's shifts over all epochs
@@ -79,7 +80,8 @@ struct SearchArgs {
     const ChunkInfo* chunks;   // [n_chunks]
     const EpochBox* boxes;     // [n_chunks][T]
     const int* lds_off;        // [n_chunks][T][C] byte offset of the shifted tile inside plane A
-    const int* epoch_invalid;  // [T] number of NO_DATA pixels in image t
+    const int* epoch_invalid;  // [T] number of NO_DATA pixels in image t, then [T] = their total
+    const int* global_box;     // {dx_min, dx_max, dy_min, dy_max} over every (candidate, epoch)
     kb_psi_phi_meta meta;
     kb_search_params params;
     int T, W, H;
@@ -128,7 +130,8 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
                                                              ChunkInfo* __restrict__ chunks,
                                                              EpochBox* __restrict__ boxes,
                                                              int* __restrict__ lds_off,
-                                                             int* __restrict__ n_not_lds) {
+                                                             int* __restrict__ n_not_lds,
+                                                             int* __restrict__ global_box) {
     // One workgroup per chunk, one thread per epoch (strided): the thread owns the
     // C shifts of its epoch, their bounding box and the LDS offsets derived from it.
     const int chunk = blockIdx.x;
@@ -213,6 +216,12 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
         ci.pad[0] = ci.pad[1] = 0;
         chunks[chunk] = ci;
         if (!ci.lds_ok) atomicAdd(n_not_lds, 1);
+        if (ci.dx_min <= ci.dx_max) {
+            atomicMin(&global_box[0], ci.dx_min);
+            atomicMax(&global_box[1], ci.dx_max);
+            atomicMin(&global_box[2], ci.dy_min);
+            atomicMax(&global_box[3], ci.dy_max);
+        }
     }
 }
 
@@ -237,7 +246,10 @@ __global__ __launch_bounds__(256) void kb_count_invalid_kernel(const void* __res
         }
     }
     for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
-    if ((threadIdx.x & 63) == 0 && bad != 0) atomicAdd(&counts[t], bad);
+    if ((threadIdx.x & 63) == 0 && bad != 0) {
+        atomicAdd(&counts[t], bad);
+        atomicAdd(&counts[gridDim.y], bad);  // total over all epochs
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -551,20 +563,18 @@ __global__ __launch_bounds__(256, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_se
 }
 
 // ---------------------------------------------------------------------------
-// LDS-staged kernel (fast path)
+// LDS-staged kernel
 // ---------------------------------------------------------------------------
-constexpr int STAGE_RR = LDS_ROWS / TILE_ROWS;  // staged rows per wave (stride TILE_ROWS)
-constexpr int STAGE_G = 2;                      // column groups of 64 lanes (LDS_COLS <= 128)
+constexpr int STAGE_RR = (LDS_ROWS + TILE_ROWS - 1) / TILE_ROWS;  // staged rows per wave (stride TILE_ROWS)
+constexpr int STAGE_G = 2;                                        // column groups of 64 lanes
 
-// What one (tile, chunk, epoch) footprint needs, all wave-uniform:
-//   clean  : every staged pixel is inside the image and the image has no NO_DATA
-//            pixel at all -> stage raw pairs, no validity plane, no counting;
-//   x0, y0 : image coordinates of the staged region's origin.
+// What one (tile, chunk, epoch) footprint needs, all wave-uniform.
 struct Footprint {
-    int x0, y0, rows, cols;
-    bool clean;
+    int x0, y0, rows, cols;  // image coordinates of the staged region's origin, its size
+    bool clean;              // every staged pixel is inside the image and the image has no NO_DATA pixel
 };
 
+template <bool FAST>
 __device__ __forceinline__ Footprint make_footprint(const SearchArgs& a, const TileCoords& tc, const EpochBox box,
                                                     int invalid_in_epoch) {
     Footprint f;
@@ -572,21 +582,23 @@ __device__ __forceinline__ Footprint make_footprint(const SearchArgs& a, const T
     f.y0 = tc.tile_y0 + box_dy(box);
     f.rows = box_rows(box);
     f.cols = box_cols(box);
-    f.clean = invalid_in_epoch == 0 && f.x0 >= 0 && f.y0 >= 0 && (f.x0 + f.cols) <= a.W && (f.y0 + f.rows) <= a.H;
+    f.clean = FAST ? true
+                   : (invalid_in_epoch == 0 && f.x0 >= 0 && f.y0 >= 0 && (f.x0 + f.cols) <= a.W &&
+                      (f.y0 + f.rows) <= a.H);
     return f;
 }
 
 // Issue the global loads of one footprint into registers.  g_lane = this lane's
-// byte offset (wv * W + lane) * BYTES inside the footprint; the row / column-group
-// strides are added on the scalar side or as immediates.
-template <int NB>
+// byte offset (wv * W + lane) * BYTES inside the footprint; row and column-group
+// strides are added on the scalar side / as immediates.
+template <int NB, bool FAST>
 __device__ __forceinline__ void stage_load(const SearchArgs& a, const Footprint& f, int t, const TileCoords& tc,
                                            uint32_t g_lane, typename RawPair<NB>::type (&raw)[STAGE_RR][STAGE_G]) {
     using R = RawPair<NB>;
     using RT = typename R::type;
     constexpr int BYTES = 2 * fmt_bytes(NB);
     const char* image = reinterpret_cast<const char*>(a.psi_phi) + (uint64_t)t * a.meta.pixels_per_image * (uint64_t)BYTES;
-    if (f.clean) {
+    if (FAST || f.clean) {
         // Whole footprint inside the image: scalar base + one per-lane offset, no bounds tests.
         const char* base = image + ((int64_t)f.y0 * a.W + f.x0) * BYTES;
 #pragma unroll
@@ -617,9 +629,9 @@ __device__ __forceinline__ void stage_load(const SearchArgs& a, const Footprint&
     }
 }
 
-// Publish one staged footprint into the LDS buffer at compile-time offset BUF.
+// Publish one staged footprint into LDS ring slot BUF.
 // l_lane = this lane's byte offset (wv * LDS_COLS + lane) * 8 in plane A.
-template <int NB, int BUF>
+template <int NB, bool FAST, int BUF>
 __device__ __forceinline__ void stage_write(const SearchArgs& a, const Footprint& f, const TileCoords& tc, char* smem,
                                             int l_lane, const typename RawPair<NB>::type (&raw)[STAGE_RR][STAGE_G]) {
     using R = RawPair<NB>;
@@ -634,7 +646,7 @@ __device__ __forceinline__ void stage_write(const SearchArgs& a, const Footprint
                     constexpr int ROW_A = TILE_ROWS * LDS_COLS * 8, ROW_B = TILE_ROWS * LDS_COLS * 4;
                     float psi, phi;
                     R::decode(raw[rr][g], a, &psi, &phi);
-                    if (f.clean) {
+                    if (FAST || f.clean) {
                         *reinterpret_cast<float2*>(pa + rr * ROW_A + g * WAVE * 8) = make_float2(psi, phi);
                     } else {
                         const bool valid = __builtin_isfinite(psi) && __builtin_isfinite(phi);
@@ -648,23 +660,43 @@ __device__ __forceinline__ void stage_write(const SearchArgs& a, const Footprint
     }
 }
 
-// One epoch of one chunk: (1) issue the global loads of the NEXT footprint,
-// (2) read this epoch's C shifted rows from LDS buffer BUF, (3) accumulate in
-// epoch order, (4) publish the next footprint into the other buffer, barrier.
-template <int C, int NB, int BUF>
-__device__ __forceinline__ void lds_epoch(const SearchArgs& a, const TileCoords& tc, char* smem, int t, bool more,
-                                          const Footprint& f_cur, const Footprint& f_next, const int (&off)[C],
-                                          uint32_t g_lane, int l_lane, int& clean_epochs, float (&ps)[C],
-                                          float (&ph)[C], int (&cnt)[C]) {
-    typename RawPair<NB>::type raw[STAGE_RR][STAGE_G];
-    if (more) stage_load<NB>(a, f_next, t + 1, tc, g_lane, raw);
+// Ring-of-three pipeline state of one chunk.
+template <int NB>
+struct LdsPipe {
+    typename RawPair<NB>::type raw[STAGE_RR][STAGE_G];  // footprint of epoch t+1, loads in flight
+    Footprint f_cur;                                     // epoch t   (resident in ring slot t % 3)
+    Footprint f_pending;                                 // epoch t+1 (in `raw`)
+};
 
-    const char* cur = smem + BUF * LDS_BUF + l_lane;  // compile-time buffer offset
+// One epoch t (ring slot BUF):
+//   1. publish the footprint of epoch t+1 (its loads were issued one iteration ago) into slot BUF+1,
+//   2. issue the loads of epoch t+2,
+//   3. read this epoch's C shifted rows from slot BUF and accumulate in epoch order,
+//   4. barrier.
+template <int C, int NB, bool FAST, int BUF>
+__device__ __forceinline__ void lds_epoch(const SearchArgs& a, const TileCoords& tc, char* smem, int t, int T,
+                                          const EpochBox* __restrict__ boxes, const int* __restrict__ invalid,
+                                          const int* __restrict__ offs, uint32_t g_lane, int l_lane,
+                                          LdsPipe<NB>& p, int& clean_epochs, float (&ps)[C], float (&ph)[C],
+                                          int (&cnt)[C]) {
+    int off[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) off[c] = offs[t * C + c];  // scalar loads, consumed in step 3
+
+    if (t + 1 < T) stage_write<NB, FAST, (BUF + 1) % LDS_NBUF>(a, p.f_pending, tc, smem, l_lane, p.raw);
+    const Footprint f_now = p.f_cur;
+    p.f_cur = p.f_pending;
+    if (t + 2 < T) {
+        p.f_pending = make_footprint<FAST>(a, tc, boxes[t + 2], FAST ? 0 : invalid[t + 2]);
+        stage_load<NB, FAST>(a, p.f_pending, t + 2, tc, g_lane, p.raw);
+    }
+
+    const char* cur = smem + BUF * LDS_BUF + l_lane;  // compile-time ring slot
     float2 v[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) v[c] = *reinterpret_cast<const float2*>(cur + off[c]);
-    if (f_cur.clean) {
-        clean_epochs += 1;
+    if (FAST || f_now.clean) {
+        if (!FAST) clean_epochs += 1;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             ps[c] += v[c].x;
@@ -682,22 +714,63 @@ __device__ __forceinline__ void lds_epoch(const SearchArgs& a, const TileCoords&
             cnt[c] += ok[c];
         }
     }
-    if (more) stage_write<NB, 1 - BUF>(a, f_next, tc, smem, l_lane, raw);
     __syncthreads();
+}
+
+// All T epochs of one chunk.  FAST: the workgroup's tile never leaves the image
+// under any candidate shift and the stack has no NO_DATA pixel at all, so every
+// footprint is clean, nothing is bounds-tested and obs_count is T.
+template <int C, int NB, bool FAST>
+__device__ __forceinline__ void lds_chunk(const SearchArgs& a, const TileCoords& tc, char* smem, int chunk,
+                                          uint32_t g_lane, int l_lane, float (&ps)[C], float (&ph)[C], int (&cnt)[C]) {
+    const int T = a.T;
+    const EpochBox* __restrict__ boxes = a.boxes + (size_t)chunk * T;
+    const int* __restrict__ offs = a.lds_off + (size_t)chunk * T * C;
+    const int* __restrict__ invalid = a.epoch_invalid;
+    int clean_epochs = 0;
+
+    LdsPipe<NB> p;
+    p.f_cur = make_footprint<FAST>(a, tc, boxes[0], FAST ? 0 : invalid[0]);
+    stage_load<NB, FAST>(a, p.f_cur, 0, tc, g_lane, p.raw);
+    stage_write<NB, FAST, 0>(a, p.f_cur, tc, smem, l_lane, p.raw);
+    p.f_pending = p.f_cur;
+    if (T > 1) {
+        p.f_pending = make_footprint<FAST>(a, tc, boxes[1], FAST ? 0 : invalid[1]);
+        stage_load<NB, FAST>(a, p.f_pending, 1, tc, g_lane, p.raw);
+    }
+    __syncthreads();
+
+    int t = 0;
+    for (; t + 2 < T; t += 3) {
+        lds_epoch<C, NB, FAST, 0>(a, tc, smem, t, T, boxes, invalid, offs, g_lane, l_lane, p, clean_epochs, ps, ph, cnt);
+        lds_epoch<C, NB, FAST, 1>(a, tc, smem, t + 1, T, boxes, invalid, offs, g_lane, l_lane, p, clean_epochs, ps, ph, cnt);
+        lds_epoch<C, NB, FAST, 2>(a, tc, smem, t + 2, T, boxes, invalid, offs, g_lane, l_lane, p, clean_epochs, ps, ph, cnt);
+    }
+    if (t < T) {
+        lds_epoch<C, NB, FAST, 0>(a, tc, smem, t, T, boxes, invalid, offs, g_lane, l_lane, p, clean_epochs, ps, ph, cnt);
+        if (t + 1 < T)
+            lds_epoch<C, NB, FAST, 1>(a, tc, smem, t + 1, T, boxes, invalid, offs, g_lane, l_lane, p, clean_epochs, ps,
+                                      ph, cnt);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) cnt[c] += FAST ? T : clean_epochs;
 }
 
 template <int KS, int C, int NB, bool SIGMAG>
 __global__ __launch_bounds__(256, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_search_lds(const SearchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // two stage buffers
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // ring of LDS_NBUF stage buffers
     const TileCoords tc = tile_coords(a);  // rows past the search area stay alive (barriers)
     TopK<KS> top;
     top.init();
     SigmaGScratch<WAVE> scratch = {};
     if constexpr (SIGMAG) scratch = make_scratch(a, tc);
-    const int l_lane = (tc.wv * LDS_COLS + tc.lane) * 8;                          // plane A offset of this lane
-    const uint32_t g_lane = (uint32_t)(tc.wv * a.W + tc.lane) * (uint32_t)(2 * fmt_bytes(NB));  // footprint offset of this lane
-    const int* __restrict__ invalid = a.epoch_invalid;
-    const int T = a.T;
+    const int l_lane = (tc.wv * LDS_COLS + tc.lane) * 8;  // plane A offset of this lane
+    const uint32_t g_lane = (uint32_t)(tc.wv * a.W + tc.lane) * (uint32_t)(2 * fmt_bytes(NB));  // footprint offset
+
+    // Workgroup-uniform: can this tile take the validity-free pipeline for the whole search?
+    const int* __restrict__ gb = a.global_box;
+    const bool fast = a.epoch_invalid[a.T] == 0 && (tc.tile_x0 + gb[0] >= 0) && (tc.tile_x0 + WAVE + gb[1] <= a.W) &&
+                      (tc.tile_y0 + gb[2] >= 0) && (tc.tile_y0 + TILE_ROWS + gb[3] <= a.H);
 
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
         float ps[C], ph[C];
@@ -708,43 +781,11 @@ __global__ __launch_bounds__(256, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_se
             ph[c] = 0.0f;
             cnt[c] = 0;
         }
-        const EpochBox* __restrict__ boxes = a.boxes + (size_t)chunk * T;
-        const int* __restrict__ offs = a.lds_off + (size_t)chunk * T * C;
-        int clean_epochs = 0;  // epochs whose whole footprint was valid (uniform)
-
-        Footprint f0 = make_footprint(a, tc, boxes[0], invalid[0]);
-        {
-            typename RawPair<NB>::type raw[STAGE_RR][STAGE_G];
-            stage_load<NB>(a, f0, 0, tc, g_lane, raw);
-            stage_write<NB, 0>(a, f0, tc, smem, l_lane, raw);
+        if (fast) {
+            lds_chunk<C, NB, true>(a, tc, smem, chunk, g_lane, l_lane, ps, ph, cnt);
+        } else {
+            lds_chunk<C, NB, false>(a, tc, smem, chunk, g_lane, l_lane, ps, ph, cnt);
         }
-        int off0[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) off0[c] = offs[c];
-        __syncthreads();
-
-        int t = 0;
-        for (; t + 1 < T; t += 2) {
-            // scalar prefetch: boxes / offsets / invalid counts of the next two epochs
-            const Footprint f1 = make_footprint(a, tc, boxes[t + 1], invalid[t + 1]);
-            int off1[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) off1[c] = offs[(t + 1) * C + c];
-            lds_epoch<C, NB, 0>(a, tc, smem, t, true, f0, f1, off0, g_lane, l_lane, clean_epochs, ps, ph, cnt);
-
-            const bool more = (t + 2) < T;
-            const int tn = more ? t + 2 : t + 1;
-            const Footprint f2 = make_footprint(a, tc, boxes[tn], invalid[tn]);
-#pragma unroll
-            for (int c = 0; c < C; ++c) off0[c] = offs[tn * C + c];
-            lds_epoch<C, NB, 1>(a, tc, smem, t + 1, more, f1, f2, off1, g_lane, l_lane, clean_epochs, ps, ph, cnt);
-            f0 = f2;
-        }
-        if (t < T) {  // odd T: the last epoch sits in buffer 0 with its offsets in off0
-            lds_epoch<C, NB, 0>(a, tc, smem, t, false, f0, f0, off0, g_lane, l_lane, clean_epochs, ps, ph, cnt);
-        }
-#pragma unroll
-        for (int c = 0; c < C; ++c) cnt[c] += clean_epochs;
         if (tc.row_active) finish_chunk<KS, C, SIGMAG>(a, tc, chunk, ps, ph, cnt, top, scratch);
     }
     write_results<KS, SIGMAG>(a, tc, top, scratch);
@@ -883,10 +924,10 @@ static void debug_occupancy(const char* name, KernelT kernel, size_t lds) {
 
 template <int KS, int NB, bool SIGMAG>
 static void launch_variant(const SearchArgs& a, bool lds, hipStream_t stream) {
-    debug_occupancy("kb_search_lds", kb_search_lds<KS, CHUNK, NB, SIGMAG>, 2 * LDS_BUF);
+    debug_occupancy("kb_search_lds", kb_search_lds<KS, CHUNK, NB, SIGMAG>, LDS_NBUF * LDS_BUF);
     debug_occupancy("kb_search_direct", kb_search_direct<KS, CHUNK, NB, SIGMAG>, 0);
     if (lds) {
-        hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, NB, SIGMAG>), dim3(a.n_tiles), dim3(256), 2 * LDS_BUF, stream, a);
+        hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, NB, SIGMAG>), dim3(a.n_tiles), dim3(256), LDS_NBUF * LDS_BUF, stream, a);
     } else {
         hipLaunchKernelGGL((kb_search_direct<KS, CHUNK, NB, SIGMAG>), dim3(a.n_tiles), dim3(256), 0, stream, a);
     }
@@ -1001,6 +1042,7 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
     a.boxes = nullptr;
     a.lds_off = nullptr;
     a.epoch_invalid = nullptr;
+    a.global_box = nullptr;
 
     EventTimer table_timer(stream, stats_out != nullptr);
     EventTimer search_timer(stream, stats_out != nullptr);
@@ -1016,7 +1058,8 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
         const size_t off_bytes = (size_t)a.n_chunks * a.T * CHUNK * sizeof(int);
         const size_t box_bytes = (size_t)a.n_chunks * a.T * sizeof(EpochBox);
         const size_t chunk_bytes = (size_t)a.n_chunks * sizeof(ChunkInfo);
-        const size_t inv_bytes = ((size_t)a.T + 1) * sizeof(int);  // per-epoch counts + the not-LDS chunk counter
+        // per-epoch NO_DATA counts [T], their total [1], the not-LDS chunk counter [1], the global shift box [4]
+        const size_t inv_bytes = ((size_t)a.T + 6) * sizeof(int);
         void* ws = nullptr;
         if (ensure_workspace(0, table_bytes + off_bytes + box_bytes + chunk_bytes + inv_bytes, &ws)) return 1;
         char* wsc = reinterpret_cast<char*>(ws);
@@ -1026,14 +1069,18 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
         a.chunks = reinterpret_cast<const ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes);
         int* inv = reinterpret_cast<int*>(wsc + table_bytes + off_bytes + box_bytes + chunk_bytes);
         a.epoch_invalid = inv;
-        int* n_not_lds = inv + a.T;
+        int* n_not_lds = inv + a.T + 1;
+        int* gbox = inv + a.T + 2;
+        a.global_box = gbox;
         table_timer.begin();
         KB_HIP_TRY(hipMemsetAsync(inv, 0, inv_bytes, stream));
+        static const int gbox_init[4] = {INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN};
+        KB_HIP_TRY(hipMemcpyAsync(gbox, gbox_init, sizeof(gbox_init), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL((kb_shift_table_kernel<CHUNK>), dim3(a.n_chunks), dim3(256), 0, stream, cands_dev,
                            times_dev, a.n_cands, a.T, reinterpret_cast<int2*>(wsc),
                            reinterpret_cast<ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes),
                            reinterpret_cast<EpochBox*>(wsc + table_bytes + off_bytes),
-                           reinterpret_cast<int*>(wsc + table_bytes), n_not_lds);
+                           reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox);
         KB_HIP_TRY(hipGetLastError());
         if (use_lds) {
             const dim3 grid((unsigned)std::min<uint64_t>((meta->pixels_per_image + 255) / 256, 1024), (unsigned)a.T);
