@@ -120,6 +120,14 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
                             kb_trajectory* results_dev, uint64_t n_results, uint32_t flags, void* stream,
                             kb_search_stats* stats_out);
 
+/* ---- result post-processing in HBM: the filter_by_likelihood / filter_by_obs_count /
+ * sort_by_likelihood sequence of stack_search.cpp:266-281 (trajectory_list.cpp:96-126).
+ * results_dev: n trajectories (the slots written by kb_device_search_filter); out_dev: room for n.
+ * Keeps entries with !(lh < min_lh) && !(obs_count < min_obs) in slot order, then sorts them by lh
+ * descending (stable).  *n_out_host receives the number kept.  Synchronises the stream. */
+int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs,
+                           kb_trajectory* out_dev, uint64_t* n_out_host, void* stream);
+
 /* ---- multi-GPU: merge of per-rank top-K lists (new; the reference is single-GPU).
  * lists_dev: [n_lists][n_pixels][K] as gathered by one RCCL all_gather of each
  * rank's kb_device_search_filter output over its candidate slice; out_dev:

@@ -19,7 +19,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 _INC = os.path.join(_ROOT, "include")
 _LIBDIR = os.path.join(_PKG, "lib")
 
-HIP_SOURCES = ["device_memory.hip", "image_kernels.hip", "search_kernels.hip"]
+HIP_SOURCES = ["device_memory.hip", "image_kernels.hip", "search_kernels.hip", "result_kernels.hip"]
 HIP_HEADERS = ["kb_common.h", "search_math.h"]
 HOST_SOURCES = ["host/bindings.cpp"]
 HOST_HEADERS = ["host/common.h", "host/image_utils.h", "host/psi_phi_array.h", "host/trajectory_list.h",
@@ -49,21 +49,40 @@ def _hipcc():
 
 
 def build_hip(force=False, verbose=False):
+    """Compile every .hip translation unit to an object (in parallel) and link the C-ABI library."""
+    from concurrent.futures import ThreadPoolExecutor
+
     os.makedirs(_LIBDIR, exist_ok=True)
-    srcs = [os.path.join(_CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(_CSRC, h) for h in HIP_HEADERS] + [os.path.join(_INC, "kbmod_hip.h")]
-    out = hip_lib_path()
-    if not force and not _stale(out, deps):
-        return out
-    cmd = [
-        _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    objdir = os.path.join(_PKG, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(_CSRC, h) for h in HIP_HEADERS] + [os.path.join(_INC, "kbmod_hip.h")]
+    flags = [
+        "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
         # the reference CPU build has no FMA; keep every multiply and add separately rounded
         "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
         "-I" + _INC, "-I" + _CSRC,
-    ] + srcs + ["-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    ]
+
+    def compile_one(name):
+        src = os.path.join(_CSRC, name)
+        obj = os.path.join(objdir, name.replace(".hip", ".o"))
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            return obj, True
+        return obj, False
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        results = list(pool.map(compile_one, HIP_SOURCES))
+    objs = [o for o, _ in results]
+    out = hip_lib_path()
+    if force or any(changed for _, changed in results) or not os.path.exists(out):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return out
 
 

@@ -292,28 +292,48 @@ public:
             // The result slots are initialised by the kernel itself; nothing is
             // uploaded (the reference uploads S*K*28 bytes of zeros here).
             void* results_dev = nullptr;
-            check_status(kb_allocate_gpu_block(std::max<uint64_t>(max_results, 1) * sizeof(Trajectory), &results_dev));
+            void* sorted_dev = nullptr;
+            const uint64_t n_alloc = std::max<uint64_t>(max_results, 1) * sizeof(Trajectory);
+            check_status(kb_allocate_gpu_block(n_alloc, &results_dev));
             try {
+                check_status(kb_allocate_gpu_block(n_alloc, &sorted_dev));
                 check_status(kb_device_search_filter(
                         &psi_phi_array.get_meta_data(), psi_phi_array.get_gpu_array_ptr(),
                         psi_phi_array.get_gpu_time_array_ptr(), params,
                         reinterpret_cast<const kb_trajectory*>(candidate_list.get_gpu_list_ptr()),
                         candidate_list.get_size(), reinterpret_cast<kb_trajectory*>(results_dev), max_results,
                         search_flags, nullptr, &last_stats));
+                search_timer.stop();
+                // stack_search.cpp:266-277 (filter by lh, filter by obs_count, sort by lh) done in HBM:
+                // only the survivors cross PCIe.
+                DebugTimer filter_timer = DebugTimer("Filtering results by LH and min_obs", rs_logger);
+                uint64_t kept = 0;
+                check_status(kb_filter_sort_results(reinterpret_cast<const kb_trajectory*>(results_dev), max_results,
+                                                    params.min_lh, params.min_observations,
+                                                    reinterpret_cast<kb_trajectory*>(sorted_dev), &kept, nullptr));
+                rs_logger->debug("Core search returned " + std::to_string(max_results) + " results.\n");
+                rs_logger->debug("After filtering by LH and min_obs " + std::to_string(kept) + " results (" +
+                                 std::to_string(max_results - kept) + " removed).\n");
+                filter_timer.stop();
                 rs_logger->info("Clearing all data from GPU.");
                 results.resize(0);
-                results.resize(max_results);
-                check_status(kb_copy_block_to_cpu(results.get_list().data(), results_dev,
-                                                  max_results * sizeof(Trajectory)));
+                results.resize(kept);
+                if (kept > 0) {
+                    check_status(kb_copy_block_to_cpu(results.get_list().data(), sorted_dev, kept * sizeof(Trajectory)));
+                }
             } catch (...) {
                 (void)kb_free_gpu_block(results_dev);
+                if (sorted_dev != nullptr) (void)kb_free_gpu_block(sorted_dev);
                 if (!psi_phi_preloaded) psi_phi_array.end_device_use();
                 throw;
             }
             (void)kb_free_gpu_block(results_dev);
-            results.assert_valid();  // trajectory_list.cpp:152
+            (void)kb_free_gpu_block(sorted_dev);
             candidate_list.move_to_cpu();
             if (!psi_phi_preloaded) psi_phi_array.end_device_use();
+            results.assert_valid();  // trajectory_list.cpp:152 / stack_search.cpp:280
+            core_timer.stop();
+            return;
         } else {
             rs_logger->info("Running search on CPU.");
             results.resize(0);
