@@ -128,6 +128,12 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
 int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs,
                            kb_trajectory* out_dev, uint64_t* n_out_host, void* stream);
 
+/* ---- psi/phi curves of result trajectories (StackSearch::get_all_psi_phi_curves,
+ * stack_search.cpp:302-318): out_dev is [n][2*T] float32, psi in [0,T), phi in [T,2T), non-finite -> 0.
+ * Synchronises the stream. */
+int kb_psi_phi_curves(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
+                      const kb_trajectory* trjs_dev, uint64_t n, float* out_dev, void* stream);
+
 /* ---- multi-GPU: merge of per-rank top-K lists (new; the reference is single-GPU).
  * lists_dev: [n_lists][n_pixels][K] as gathered by one RCCL all_gather of each
  * rank's kb_device_search_filter output over its candidate slice; out_dev:

@@ -372,11 +372,34 @@ public:
         return search_width * search_height * params.results_per_pixel;
     }
 
-    // stack_search.cpp:302-318: (num_trj, 2*num_times) row-major.
+    // stack_search.cpp:302-318: (num_trj, 2*num_times) row-major.  With the array resident in HBM the
+    // gather runs on the device (kb_psi_phi_curves); otherwise the reference's host loop.
     Image get_all_psi_phi_curves(const std::vector<Trajectory>& trajectories) {
         const int64_t num_trj = trajectories.size();
         Image out(num_trj, 2 * (int64_t)num_imgs);
         if (num_trj == 0) return out;
+        if (has_gpu() && psi_phi_array.device_resident()) {
+            psi_phi_array.ensure_device();  // times too
+            void* trj_dev = nullptr;
+            void* out_dev = nullptr;
+            check_status(kb_allocate_gpu_block((uint64_t)num_trj * sizeof(Trajectory), &trj_dev));
+            try {
+                check_status(kb_allocate_gpu_block(out.data.size() * sizeof(float), &out_dev));
+                check_status(kb_copy_block_to_gpu(trajectories.data(), trj_dev, (uint64_t)num_trj * sizeof(Trajectory)));
+                check_status(kb_psi_phi_curves(&psi_phi_array.get_meta_data(), psi_phi_array.get_gpu_array_ptr(),
+                                               psi_phi_array.get_gpu_time_array_ptr(),
+                                               reinterpret_cast<const kb_trajectory*>(trj_dev), (uint64_t)num_trj,
+                                               reinterpret_cast<float*>(out_dev), nullptr));
+                check_status(kb_copy_block_to_cpu(out.data.data(), out_dev, out.data.size() * sizeof(float)));
+            } catch (...) {
+                (void)kb_free_gpu_block(trj_dev);
+                if (out_dev != nullptr) (void)kb_free_gpu_block(out_dev);
+                throw;
+            }
+            (void)kb_free_gpu_block(trj_dev);
+            (void)kb_free_gpu_block(out_dev);
+            return out;
+        }
         psi_phi_array.ensure_host();
 #pragma omp parallel for schedule(dynamic, 64)
         for (int64_t i = 0; i < num_trj; ++i) {

@@ -188,3 +188,20 @@ def test_off_chip_start(kb):
     best = s.get_results(0, 10)[0]
     assert abs(best.x + 3) <= 1 and abs(best.y - 12) <= 1
     assert best.vx / 25.0 == pytest.approx(1, abs=0.1) and best.vy / 10.0 == pytest.approx(1, abs=0.1)
+
+
+@pytest.mark.parametrize("num_bytes", [-1, 1, 2])
+def test_psi_phi_curves_on_device_equal_oracle(kb, orc, stack, num_bytes):
+    s = kb.StackSearch(stack.sci, stack.var, stack.psfs, stack.zeroed_times, num_bytes)
+    assert s.get_psi_phi_array().device_resident
+    pp = orc.PsiPhi.from_images(stack.sci, stack.var, stack.psfs, stack.zeroed_times, num_bytes)
+    rng = np.random.default_rng(4)
+    trjs, exp = [], []
+    for _ in range(300):
+        x, y = int(rng.integers(-4, 105)), int(rng.integers(-4, 74))
+        vx, vy = float(np.float32(rng.normal(0, 25))), float(np.float32(rng.normal(0, 25)))
+        trjs.append(kb.Trajectory(x=x, y=y, vx=vx, vy=vy))
+        exp.append(pp.curve(x, y, vx, vy))
+    got = s.get_all_psi_phi_curves(trjs)
+    assert got.shape == (300, 18) and np.array_equal(got, np.stack(exp))
+    assert s.get_all_psi_phi_curves([]).shape == (0, 18)

@@ -158,6 +158,17 @@ def test_half_integer_shifts_take_exact_path(kb, orc):
     _check(got, exp)
 
 
+def test_empty_candidate_list(kb, stack):
+    s = kb.StackSearch(stack.sci, stack.var, stack.psfs, stack.zeroed_times)
+    s.search_all([], True)
+    assert s.get_number_total_results() == 0  # only -FLT_MAX placeholders, all below min_lh = 0
+    s.set_min_lh(-3.5e38)
+    s.set_results_per_pixel(2)
+    s.search_all([], True)
+    res = s.results_to_numpy()
+    assert len(res) == 2 * 80 * 100 and np.all(res[:, 4] == np.float32(-3.4028234663852886e38)) and np.all(res[:, 6] == 0)
+
+
 def test_too_many_images(kb):
     st = util.make_stack(1000, 10, 12, seed=1, noise=0.5)
     s = kb.StackSearch(st.sci, st.var, st.psfs, st.zeroed_times)
