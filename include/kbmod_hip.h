@@ -111,14 +111,24 @@ int kb_generate_psi_phi_host(const float* sci_host, const float* var_host, int w
  * bytes); times_dev: double[T]; cands_dev: n_cands trajectories (vx, vy read);
  * results_dev: at least K*search_w*search_h trajectories, fully overwritten
  * (slot layout kernels.cu:286: ((y-y_min)*search_w + (x-x_min))*K + s).
- * flags: bit 0 = force the per-lane exact-position path (debug / self-check);
- *        bit 3 (value 8) = always decode uint8/uint16 samples in double (skip the verified fp32-FMA form);
- *        bit 2 (value 4) = use the LDS-staged kernel kb_search_lds instead of the default
- *        kb_search_direct (falls back to direct when a chunk's footprint does not fit the stage). */
+ * flags (0 = let the library choose; results are identical for every combination):
+ *   1  force the per-lane exact-position path of kb_search_direct (debug / self-check);
+ *   2  use kb_search_direct (every sample a wave-wide load from the array);
+ *   4  use kb_search_lds (slabs staged once per workgroup into LDS from a padded copy of the
+ *      array) even for fewer than 32 candidates; the default from 32 candidates on.  Falls back
+ *      to kb_search_direct when more than 10 % of the (chunk, epoch) footprints cannot be staged,
+ *      when K > 32, or when the apron of the padded copy would outweigh the image;
+ *   8  always decode uint8/uint16 samples in double (skip the verified fp32-FMA form);
+ *  16  keep an encoded array encoded in the padded copy (default: canonical floats when HBM
+ *      has room, which makes the search as fast as on a float array).
+ * The library keeps its workspaces (shift tables, sigma-G scratch, padded copy) between
+ * calls; kb_release_workspaces() returns them. */
 int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
                             kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
                             kb_trajectory* results_dev, uint64_t n_results, uint32_t flags, void* stream,
                             kb_search_stats* stats_out);
+
+int kb_release_workspaces(void);
 
 /* ---- result post-processing in HBM: the filter_by_likelihood / filter_by_obs_count /
  * sort_by_likelihood sequence of stack_search.cpp:266-281 (trajectory_list.cpp:96-126).

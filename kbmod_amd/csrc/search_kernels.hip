@@ -45,27 +45,30 @@ constexpr int SHIFT_UNSAFE = INT32_MIN;  // dx marker: no uniform shift proven f
 constexpr int TILE_ROWS = 4;             // waves (rows) per 256-thread workgroup
 constexpr int CHUNK = 8;                 // candidates accumulated together per wave
 
-// LDS stage buffer: at most LDS_ROWS x LDS_COLS pixels per (chunk, epoch).
-// Plane A: (psi, phi) float2 with NO_DATA replaced by (+0, +0); plane B: validity
-// (1 / 0) for obs_count.
-constexpr int LDS_COLS = 84;  // pitch in pixels: 64 start columns + up to 20 of dx spread
-constexpr int LDS_ROWS = 13;  // 4 start rows + up to 9 of dy spread
-constexpr int LDS_PLANE_A = LDS_ROWS * LDS_COLS * 8;  // bytes
-constexpr int LDS_PLANE_B = LDS_ROWS * LDS_COLS * 4;
-constexpr int LDS_BUF = LDS_PLANE_A + LDS_PLANE_B;  // 12.8 KiB
-constexpr int LDS_NBUF = 3;                         // ring of three: 38.4 KiB per workgroup, 4 workgroups per CU
+// LDS staging (kb_search_lds): per (chunk, epoch) the workgroup stages a slab of
+// rows_max(chunk) x LDS_COLS raw pairs -- the union footprint of its 64 x 4 tile
+// under the chunk's shifts -- straight from a padded HBM copy of the array into
+// LDS with LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), several epochs
+// per barrier, double-buffered.
+constexpr int LDS_COLS = 88;          // slab pitch in pixels: 64 start columns + up to 24 of dx spread
+                                      // (88 * {8,4,2} bytes are multiples of the 16-byte DMA granule)
+constexpr int LDS_GROUP_BYTES = 20480;  // one group buffer; two per workgroup = 40 KiB -> 4 workgroups per CU
 
 struct ChunkInfo {
     int dx_min, dx_max, dy_min, dy_max;  // bounding box of the chunk's shifts over all epochs
     int unsafe;                          // any entry flagged SHIFT_UNSAFE
-    int lds_ok;                          // every epoch's footprint fits the LDS stage buffer
-    int pad[2];
+    int lds_ok;                          // every epoch's footprint fits one LDS slab
+    int rows_max;                        // TILE_ROWS + largest dy spread of any epoch (slab height)
+    int pad;
 };
 
 // Per (chunk, epoch) footprint, packed for one 8-byte scalar load:
 //   x = (dy_min << 16) | (dx_min & 0xffff)   origin of the staged region relative to the tile
 //   y = (rows   << 16) | cols                64 + dx spread, TILE_ROWS + dy spread
 using EpochBox = int2;
+constexpr int BOX_NOT_STAGED = (int)0x80008000u;  // word 0 of an epoch that kb_search_lds does not stage
+constexpr int LDS_OFF_UNSTAGED = -1;
+constexpr int LDS_OFF_PER_LANE = -2;
 __host__ __device__ __forceinline__ int box_dx(EpochBox b) { return (int)(short)(b.x & 0xffff); }
 __host__ __device__ __forceinline__ int box_dy(EpochBox b) { return b.x >> 16; }
 __host__ __device__ __forceinline__ int box_cols(EpochBox b) { return b.y & 0xffff; }
@@ -80,8 +83,11 @@ struct SearchArgs {
     const ChunkInfo* chunks;   // [n_chunks]
     const EpochBox* boxes;     // [n_chunks][T]
     const int* lds_off;        // [n_chunks][T][C] byte offset of the shifted tile inside plane A
-    const int* epoch_invalid;  // [T] number of NO_DATA pixels in image t, then [T] = their total
-    const int* global_box;     // {dx_min, dx_max, dy_min, dy_max} over every (candidate, epoch)
+    const int* global_box;     // {dx_min, dx_max, dy_min, dy_max, rows_max} over every (candidate, epoch)
+    const void* padded;        // [T][Hp][Wp] raw pairs, apron = NO_DATA (kb_search_lds only)
+    int Wp, Hp, px0, py0;      // padded pitch / height, position of image pixel (0,0) inside the padded frame
+    const int* n_invalid;      // device counter: NO_DATA pixels inside the image (written by kb_pad_kernel)
+    int all_staged;            // every (chunk, epoch) is staged through LDS
     kb_psi_phi_meta meta;
     kb_search_params params;
     int T, W, H;
@@ -108,7 +114,9 @@ __device__ __forceinline__ float decode_fast_or_exact(unsigned code, float scale
 // ---------------------------------------------------------------------------
 // shift table
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int uniform_shift(float v, double t, bool* unsafe) {
+// kind: 0 = the shift is uniform over all start pixels; 1 = v*t + 0.5 sits inside the guard band
+// of a rounding boundary, each pixel lands on fl - 1, fl or fl + 1; 2 = out of the proven range.
+__device__ __forceinline__ int uniform_shift(float v, double t, int* kind) {
     const double a = __dmul_rn((double)v, t);
     const double g = __dadd_rn(a, 0.5);
     const double fl = floor(g);
@@ -116,10 +124,11 @@ __device__ __forceinline__ int uniform_shift(float v, double t, bool* unsafe) {
     // Guard band 2^-20 around the rounding boundary and |a| < 2^22: with start
     // coordinates |x| < 2^22 the two extra roundings of (x + a) + 0.5 move the
     // value by < 2^-28, so floor() cannot change ("shift table").
-    if (!(fabs(a) < 4194304.0) || !(frac >= 9.5367431640625e-07 && frac <= 1.0 - 9.5367431640625e-07)) {
-        *unsafe = true;
+    if (!(fabs(a) < 4194304.0)) {
+        *kind = 2;
         return 0;
     }
+    if (!(frac >= 9.5367431640625e-07 && frac <= 1.0 - 9.5367431640625e-07)) *kind = max(*kind, 1);
     return (int)fl;
 }
 
@@ -136,39 +145,54 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
     // C shifts of its epoch, their bounding box and the LDS offsets derived from it.
     const int chunk = blockIdx.x;
     int dx_min = INT32_MAX, dx_max = INT32_MIN, dy_min = INT32_MAX, dy_max = INT32_MIN, any_unsafe = 0, lds_bad = 0;
+    int rows_max = TILE_ROWS;
+    int sx_min = INT32_MAX, sx_max = INT32_MIN, sy_min = INT32_MAX, sy_max = INT32_MIN;  // staged epochs only
+    int n_per_lane = 0;
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
         const double tm = times[t];
         int2 sh[C];
         int ex0 = INT32_MAX, ex1 = INT32_MIN, ey0 = INT32_MAX, ey1 = INT32_MIN;
-        bool epoch_unsafe = false;
+        bool epoch_unsafe = false;  // some candidate has no uniform shift here
+        bool epoch_wild = false;    // ... and not even a bounded one
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int ci = chunk * C + c;
             sh[c] = make_int2(0, 0);
             if (ci < n_cands) {
-                bool unsafe = false;
-                sh[c].x = uniform_shift(cands[ci].vx, tm, &unsafe);
-                sh[c].y = uniform_shift(cands[ci].vy, tm, &unsafe);
-                if (unsafe) {
+                int kx = 0, ky = 0;
+                sh[c].x = uniform_shift(cands[ci].vx, tm, &kx);
+                sh[c].y = uniform_shift(cands[ci].vy, tm, &ky);
+                if (kx == 2 || ky == 2) {
+                    epoch_wild = true;
+                } else {
+                    // footprint: one pixel of slack on an axis whose shift is only known to +-1
+                    ex0 = min(ex0, sh[c].x - (kx ? 1 : 0));
+                    ex1 = max(ex1, sh[c].x + (kx ? 1 : 0));
+                    ey0 = min(ey0, sh[c].y - (ky ? 1 : 0));
+                    ey1 = max(ey1, sh[c].y + (ky ? 1 : 0));
+                }
+                if (kx != 0 || ky != 0) {
                     sh[c].x = SHIFT_UNSAFE;
                     epoch_unsafe = true;
-                } else {
-                    ex0 = min(ex0, sh[c].x);
-                    ex1 = max(ex1, sh[c].x);
-                    ey0 = min(ey0, sh[c].y);
-                    ey1 = max(ey1, sh[c].y);
                 }
             }
         }
-        const bool fits = !epoch_unsafe && ex0 <= ex1 && (ex1 - ex0) <= (LDS_COLS - WAVE) &&
-                          (ey1 - ey0) <= (LDS_ROWS - TILE_ROWS) && ex0 > -30000 && ex1 < 30000 && ey0 > -30000 &&
-                          ey1 < 30000;
+        // A slab of (TILE_ROWS + dy spread) x LDS_COLS 8-byte pairs must fit one group buffer.
+        const bool fits = !epoch_wild && ex0 <= ex1 && (ex1 - ex0) <= (LDS_COLS - WAVE) &&
+                          (TILE_ROWS + ey1 - ey0) * LDS_COLS * 8 <= LDS_GROUP_BYTES && ex0 > -30000 && ex1 < 30000 &&
+                          ey0 > -30000 && ey1 < 30000;
         EpochBox box = make_int2(0, (TILE_ROWS << 16) | WAVE);
         if (fits) {
             box.x = (ey0 << 16) | (ex0 & 0xffff);
             box.y = ((TILE_ROWS + ey1 - ey0) << 16) | (WAVE + ex1 - ex0);
+            rows_max = max(rows_max, TILE_ROWS + ey1 - ey0);
+            sx_min = min(sx_min, ex0);
+            sx_max = max(sx_max, ex1);
+            sy_min = min(sy_min, ey0);
+            sy_max = max(sy_max, ey1);
         } else {
-            lds_bad = 1;
+            box.x = BOX_NOT_STAGED;  // kb_search_lds evaluates this epoch per lane from the array itself
+            lds_bad += 1;
         }
         boxes[(size_t)chunk * T + t] = box;
 #pragma unroll
@@ -176,9 +200,14 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
             const size_t e = ((size_t)chunk * T + t) * C + c;
             table[e] = sh[c];
             const bool real = (chunk * C + c) < n_cands;
-            lds_off[e] = (fits && real) ? ((sh[c].y - ey0) * LDS_COLS + (sh[c].x - ex0)) * 8 : 0;
+            // >= 0: slab offset of the uniformly shifted tile; LDS_OFF_PER_LANE: staged, but the lanes
+            // find their own pixel inside the slab; LDS_OFF_UNSTAGED: not staged at all
+            lds_off[e] = !fits ? LDS_OFF_UNSTAGED
+                               : (epoch_unsafe ? LDS_OFF_PER_LANE
+                                               : (real ? ((sh[c].y - ey0) * LDS_COLS + (sh[c].x - ex0)) * 8 : 0));
         }
         if (epoch_unsafe) any_unsafe = 1;
+        if (epoch_unsafe && fits) n_per_lane += 1;
         if (ex0 <= ex1) {
             dx_min = min(dx_min, ex0);
             dx_max = max(dx_max, ex1);
@@ -186,13 +215,19 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
             dy_max = max(dy_max, ey1);
         }
     }
-    __shared__ int red[6][256];
+    __shared__ int red[12][256];
     red[0][threadIdx.x] = dx_min;
     red[1][threadIdx.x] = dx_max;
     red[2][threadIdx.x] = dy_min;
     red[3][threadIdx.x] = dy_max;
     red[4][threadIdx.x] = any_unsafe;
     red[5][threadIdx.x] = lds_bad;
+    red[6][threadIdx.x] = rows_max;
+    red[7][threadIdx.x] = sx_min;
+    red[8][threadIdx.x] = sx_max;
+    red[9][threadIdx.x] = sy_min;
+    red[10][threadIdx.x] = sy_max;
+    red[11][threadIdx.x] = n_per_lane;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
@@ -201,7 +236,13 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
             red[2][threadIdx.x] = min(red[2][threadIdx.x], red[2][threadIdx.x + s]);
             red[3][threadIdx.x] = max(red[3][threadIdx.x], red[3][threadIdx.x + s]);
             red[4][threadIdx.x] |= red[4][threadIdx.x + s];
-            red[5][threadIdx.x] |= red[5][threadIdx.x + s];
+            red[5][threadIdx.x] += red[5][threadIdx.x + s];
+            red[6][threadIdx.x] = max(red[6][threadIdx.x], red[6][threadIdx.x + s]);
+            red[7][threadIdx.x] = min(red[7][threadIdx.x], red[7][threadIdx.x + s]);
+            red[8][threadIdx.x] = max(red[8][threadIdx.x], red[8][threadIdx.x + s]);
+            red[9][threadIdx.x] = min(red[9][threadIdx.x], red[9][threadIdx.x + s]);
+            red[10][threadIdx.x] = max(red[10][threadIdx.x], red[10][threadIdx.x + s]);
+            red[11][threadIdx.x] += red[11][threadIdx.x + s];
         }
         __syncthreads();
     }
@@ -212,43 +253,19 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
         ci.dy_min = red[2][0];
         ci.dy_max = red[3][0];
         ci.unsafe = red[4][0];
-        ci.lds_ok = (red[5][0] == 0 && red[4][0] == 0) ? 1 : 0;
-        ci.pad[0] = ci.pad[1] = 0;
+        ci.lds_ok = (red[5][0] == 0) ? 1 : 0;
+        ci.rows_max = red[6][0];
+        ci.pad = 0;
         chunks[chunk] = ci;
-        if (!ci.lds_ok) atomicAdd(n_not_lds, 1);
-        if (ci.dx_min <= ci.dx_max) {
-            atomicMin(&global_box[0], ci.dx_min);
-            atomicMax(&global_box[1], ci.dx_max);
-            atomicMin(&global_box[2], ci.dy_min);
-            atomicMax(&global_box[3], ci.dy_max);
+        if (red[5][0] != 0) atomicAdd(n_not_lds, red[5][0]);  // (chunk, epoch) pairs that are not staged
+        if (red[11][0] != 0) atomicAdd(&global_box[5], red[11][0]);  // ... staged, but summed per lane
+        atomicMax(&global_box[4], ci.rows_max);
+        if (red[7][0] <= red[8][0]) {  // shift box of the staged epochs: sizes the apron of the padded copy
+            atomicMin(&global_box[0], red[7][0]);
+            atomicMax(&global_box[1], red[8][0]);
+            atomicMin(&global_box[2], red[9][0]);
+            atomicMax(&global_box[3], red[10][0]);
         }
-    }
-}
-
-// Number of NO_DATA pixels per image: an epoch without any lets the LDS path skip
-// the validity plane whenever the staged footprint lies inside the image.
-template <int NB>
-__global__ __launch_bounds__(256) void kb_count_invalid_kernel(const void* __restrict__ psi_phi, uint64_t ppi,
-                                                               int* __restrict__ counts) {
-    const int t = blockIdx.y;
-    int bad = 0;
-    for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < ppi; p += (uint64_t)gridDim.x * 256) {
-        const uint64_t e = (uint64_t)t * ppi + p;
-        if (NB == 4) {
-            const float2 v = reinterpret_cast<const float2*>(psi_phi)[e];
-            bad += !(__builtin_isfinite(v.x) && __builtin_isfinite(v.y));
-        } else if (NB == 2) {
-            const ushort2 v = reinterpret_cast<const ushort2*>(psi_phi)[e];
-            bad += (v.x == 0 || v.y == 0);
-        } else {
-            const uchar2 v = reinterpret_cast<const uchar2*>(psi_phi)[e];
-            bad += (v.x == 0 || v.y == 0);
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
-    if ((threadIdx.x & 63) == 0 && bad != 0) {
-        atomicAdd(&counts[t], bad);
-        atomicAdd(&counts[gridDim.y], bad);  // total over all epochs
     }
 }
 
@@ -563,230 +580,355 @@ __global__ __launch_bounds__(256, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_se
 }
 
 // ---------------------------------------------------------------------------
-// LDS-staged kernel
+// LDS-staged kernel (LDS-DMA from a padded copy, several epochs per barrier)
 // ---------------------------------------------------------------------------
-constexpr int STAGE_RR = (LDS_ROWS + TILE_ROWS - 1) / TILE_ROWS;  // staged rows per wave (stride TILE_ROWS)
-constexpr int STAGE_G = 2;                                        // column groups of 64 lanes
-
-// What one (tile, chunk, epoch) footprint needs, all wave-uniform.
-struct Footprint {
-    int x0, y0, rows, cols;  // image coordinates of the staged region's origin, its size
-    bool clean;              // every staged pixel is inside the image and the image has no NO_DATA pixel
-};
-
-template <bool FAST>
-__device__ __forceinline__ Footprint make_footprint(const SearchArgs& a, const TileCoords& tc, const EpochBox box,
-                                                    int invalid_in_epoch) {
-    Footprint f;
-    f.x0 = tc.tile_x0 + box_dx(box);
-    f.y0 = tc.tile_y0 + box_dy(box);
-    f.rows = box_rows(box);
-    f.cols = box_cols(box);
-    f.clean = FAST ? true
-                   : (invalid_in_epoch == 0 && f.x0 >= 0 && f.y0 >= 0 && (f.x0 + f.cols) <= a.W &&
-                      (f.y0 + f.rows) <= a.H);
-    return f;
+// The padded copy [T][Hp][Wp] holds the image at (px0, py0) and NO_DATA everywhere
+// else, so that no staged slab ever needs a bounds test.  Two forms:
+//  * CANON (floats; the default, also for encoded arrays when HBM allows): each
+//    sample is decoded once, here, with the search's own decode, and NO_DATA becomes
+//    the pair (+0, -0).  Adding either zero to a running sum that started at +0
+//    leaves it bit-identical (such a sum is never -0), so the search adds every
+//    sample unconditionally -- one packed add for (psi, phi) -- and tests only the
+//    marker phi == -0 for obs_count.  A valid phi of -0 becomes +0, equally neutral.
+//  * encoded (NB bytes per value, apron = code 0): the search decodes per sample.
+// n_invalid counts the NO_DATA pixels inside the image.
+template <int NB, bool CANON>
+__global__ __launch_bounds__(256) void kb_pad_kernel(const SearchArgs a, void* __restrict__ padded,
+                                                     int* __restrict__ n_invalid) {
+    using R = RawPair<NB>;
+    const int t = blockIdx.z;
+    const int y = blockIdx.y;
+    const int sy = y - a.py0;
+    int bad = 0;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < a.Wp; x += gridDim.x * 256) {
+        const int sx = x - a.px0;
+        const bool in = sx >= 0 && sx < a.W && sy >= 0 && sy < a.H;
+        const size_t d = ((size_t)t * a.Hp + y) * a.Wp + x;
+        const size_t sidx = ((size_t)t * a.H + (in ? sy : 0)) * a.W + (in ? sx : 0);
+        const typename R::type raw = in ? reinterpret_cast<const typename R::type*>(a.psi_phi)[sidx] : R::invalid();
+        float psi, phi;
+        R::decode(raw, a, &psi, &phi);
+        const bool valid = in && __builtin_isfinite(psi) && __builtin_isfinite(phi);
+        bad += (in && !valid) ? 1 : 0;
+        if (CANON) {
+            float2 v = make_float2(0.0f, -0.0f);
+            if (valid) {
+                v = make_float2(psi, phi);
+                if (__float_as_uint(v.y) == 0x80000000u) v.y = 0.0f;
+            }
+            reinterpret_cast<float2*>(padded)[d] = v;
+        } else {
+            reinterpret_cast<typename R::type*>(padded)[d] = raw;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+    if ((threadIdx.x & 63) == 0 && bad != 0) atomicAdd(n_invalid, bad);
 }
 
-// Issue the global loads of one footprint into registers.  g_lane = this lane's
-// byte offset (wv * W + lane) * BYTES inside the footprint; row and column-group
-// strides are added on the scalar side / as immediates.
-template <int NB, bool FAST>
-__device__ __forceinline__ void stage_load(const SearchArgs& a, const Footprint& f, int t, const TileCoords& tc,
-                                           uint32_t g_lane, typename RawPair<NB>::type (&raw)[STAGE_RR][STAGE_G]) {
-    using R = RawPair<NB>;
-    using RT = typename R::type;
-    constexpr int BYTES = 2 * fmt_bytes(NB);
-    const char* image = reinterpret_cast<const char*>(a.psi_phi) + (uint64_t)t * a.meta.pixels_per_image * (uint64_t)BYTES;
-    if (FAST || f.clean) {
-        // Whole footprint inside the image: scalar base + one per-lane offset, no bounds tests.
-        const char* base = image + ((int64_t)f.y0 * a.W + f.x0) * BYTES;
+// Tables are read through the constant address space: the DMA writes and barriers of
+// the main loop would otherwise make the compiler fetch them with vector loads, whose
+// vmcnt wait also waits for the slab DMA in flight.
+typedef const __attribute__((address_space(4))) int* ConstIntPtr;
+template <typename P>
+__device__ __forceinline__ ConstIntPtr as_const_ints(const P* p) {
+    return (ConstIntPtr)(uintptr_t)p;
+}
+
+// Per-thread constants of the DMA map.  A workgroup-wide DMA step j moves 4 KiB:
+// thread tid's 16 bytes land at slab offset o = 16 * (tid + 256 j), i.e. pixel
+// p = o / BYTES = (row, col) = divmod(p, LDS_COLS) of the slab; its source is the
+// padded array at the slab origin plus (row * Wp + col) * BYTES.
+constexpr int LDS_DMA_SLOTS = LDS_GROUP_BYTES / 4096;
+struct DmaLane {
+    uint32_t goff[LDS_DMA_SLOTS];
+};
+
+// Issue the DMA of one epoch's slab (rows x LDS_COLS raw pairs) into LDS at `dst`
+// (wave-uniform).  Slab origin = tile origin + (dx_min, dy_min) of (chunk, epoch).
+template <int BYTES>
+__device__ __forceinline__ void dma_slab(const SearchArgs& a, const TileCoords& tc, const DmaLane& dl, int t,
+                                         int box_word, int slab_bytes, char* dst) {
+    const EpochBox box = make_int2(box_word, 0);
+    const int64_t origin =
+            (((int64_t)t * a.Hp + (tc.tile_y0 + box_dy(box) + a.py0)) * a.Wp + (tc.tile_x0 + box_dx(box) + a.px0)) * BYTES;
+    const char* base = reinterpret_cast<const char*>(a.padded) + origin;
+    const int tid = threadIdx.x;
 #pragma unroll
-        for (int rr = 0; rr < STAGE_RR; ++rr) {
-            if (tc.wv + TILE_ROWS * rr < f.rows) {  // uniform
-                const char* row = base + (int64_t)rr * (TILE_ROWS * BYTES) * a.W;
-                raw[rr][0] = *reinterpret_cast<const RT*>(row + g_lane);
-                if (f.cols > WAVE) {  // uniform
-                    if (tc.lane < f.cols - WAVE) raw[rr][1] = *reinterpret_cast<const RT*>(row + g_lane + WAVE * BYTES);
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int rr = 0; rr < STAGE_RR; ++rr) {
-            const int r = tc.wv + TILE_ROWS * rr;  // wave-uniform
-            const int gy = f.y0 + r;
-            const bool row_ok = (r < f.rows) && ((unsigned)gy < (unsigned)a.H);
-#pragma unroll
-            for (int g = 0; g < STAGE_G; ++g) {
-                const int col = tc.lane + WAVE * g;
-                const int gx = f.x0 + col;
-                const bool ok = row_ok && (col < f.cols) && ((unsigned)gx < (unsigned)a.W);
-                raw[rr][g] = R::invalid();
-                if (ok) raw[rr][g] = *reinterpret_cast<const RT*>(image + (uint32_t)(gy * a.W + gx) * (uint32_t)BYTES);
+    for (int j = 0; j < LDS_DMA_SLOTS; ++j) {
+        if (4096 * j < slab_bytes) {  // uniform
+            if (16 * (tid + 256 * j) < slab_bytes) {
+                // LDS destination: M0 = wave-uniform base, the hardware adds lane * 16.  Issued as inline
+                // assembly on purpose: for the builtin the compiler tracks the DMA as an LDS write in flight
+                // and puts s_waitcnt vmcnt(0) in front of every ds_read of the compute loop, which serialises
+                // the staging of group g+1 with the arithmetic on group g.  The waits are explicit instead
+                // (vmcnt(0) + barrier before a group buffer is read).
+                const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(dst + 4096 * j) +
+                                     1024u * (uint32_t)tc.wv;
+                asm volatile(
+                        "s_mov_b32 m0, %0\n\t"
+                        "s_nop 0\n\t"
+                        "global_load_lds_dwordx4 %1, %2"
+                        :
+                        : "s"(lds), "v"(dl.goff[j]), "s"(base)
+                        : "memory");
             }
         }
     }
 }
 
-// Publish one staged footprint into LDS ring slot BUF.
-// l_lane = this lane's byte offset (wv * LDS_COLS + lane) * 8 in plane A.
-template <int NB, bool FAST, int BUF>
-__device__ __forceinline__ void stage_write(const SearchArgs& a, const Footprint& f, const TileCoords& tc, char* smem,
-                                            int l_lane, const typename RawPair<NB>::type (&raw)[STAGE_RR][STAGE_G]) {
+typedef float PairF __attribute__((ext_vector_type(2)));
+
+// One epoch that is not staged (a shift inside the guard band of a rounding boundary,
+// or a footprint larger than a slab): every lane predicts its own pixel exactly and
+// reads the array itself, like kb_search_direct's exact mode.
+template <int C, int NB>
+__device__ __forceinline__ void unstaged_epoch(const SearchArgs& a, int x, int y, int chunk, int t, PairF (&acc)[C],
+                                            int (&cnt)[C]) {
     using R = RawPair<NB>;
-    char* pa = smem + BUF * LDS_BUF + l_lane;                       // plane A, this lane
-    char* pb = smem + BUF * LDS_BUF + LDS_PLANE_A + (l_lane >> 1);  // plane B, this lane
+    constexpr int BYTES = 2 * fmt_bytes(NB);
+    const double tm = a.times[t];
+    const char* base = reinterpret_cast<const char*>(a.psi_phi) + (uint64_t)t * a.meta.pixels_per_image * BYTES;
 #pragma unroll
-    for (int rr = 0; rr < STAGE_RR; ++rr) {
-        if (tc.wv + TILE_ROWS * rr < f.rows) {  // uniform
+    for (int c = 0; c < C; ++c) {
+        const int ci = min(chunk * C + c, a.n_cands - 1);
+        int cx, cy;
+        bool in = predict_index(x, a.cands[ci].vx, tm, &cx);
+        in = predict_index(y, a.cands[ci].vy, tm, &cy) && in;
+        const bool ok = in && ((unsigned)cx < (unsigned)a.W) && ((unsigned)cy < (unsigned)a.H);
+        const uint32_t voff = ok ? (uint32_t)(cy * a.W + cx) * (uint32_t)BYTES : 0u;
+        const typename R::type raw = *reinterpret_cast<const typename R::type*>(base + voff);
+        float psi, phi;
+        R::decode(raw, a, &psi, &phi);
+        float s0 = acc[c].x, s1 = acc[c].y;
+        accumulate(psi, phi, ok, s0, s1, cnt[c]);
+        acc[c] = PairF{s0, s1};
+    }
+}
+
+// One staged epoch in which some candidate's shift is known only to +-1 pixel (v*t + 0.5 on a
+// rounding boundary): every lane predicts its own pixel with the reference's arithmetic and reads
+// it from the slab, which was sized with that slack.  No global memory traffic.
+template <int C, int SF, bool CANON>
+__device__ __forceinline__ void per_lane_epoch(const SearchArgs& a, const TileCoords& tc, int chunk, int t, int box_word,
+                                               int slab_bytes, const char* slab, PairF (&acc)[C], int (&cnt)[C]) {
+    using R = RawPair<SF>;
+    constexpr int BYTES = 2 * fmt_bytes(SF);
+    typedef const __attribute__((address_space(4))) double* ConstDoublePtr;
+    const double tm = ((ConstDoublePtr)(uintptr_t)a.times)[t];
+    const EpochBox box = make_int2(box_word, 0);
+    const int ox = tc.tile_x0 + box_dx(box), oy = tc.tile_y0 + box_dy(box);  // image coordinates of slab pixel (0, 0)
+    const int rows = slab_bytes / (LDS_COLS * BYTES);
 #pragma unroll
-            for (int g = 0; g < STAGE_G; ++g) {
-                if (g == 0 || (f.cols > WAVE && tc.lane < f.cols - WAVE)) {
-                    constexpr int ROW_A = TILE_ROWS * LDS_COLS * 8, ROW_B = TILE_ROWS * LDS_COLS * 4;
+    for (int c = 0; c < C; ++c) {
+        const int ci = min(chunk * C + c, a.n_cands - 1);
+        const ConstIntPtr cw = as_const_ints(a.cands + ci);  // {vx, vy, ...}
+        int cx, cy;
+        bool in = predict_index(tc.x, __int_as_float(cw[0]), tm, &cx);
+        in = predict_index(tc.y, __int_as_float(cw[1]), tm, &cy) && in;
+        const int rx = cx - ox, ry = cy - oy;
+        const bool ok = in && ((unsigned)rx < (unsigned)LDS_COLS) && ((unsigned)ry < (unsigned)rows);
+        const int off = ok ? (ry * LDS_COLS + rx) * BYTES : 0;
+        const typename R::type raw = *reinterpret_cast<const typename R::type*>(slab + off);
+        float psi, phi;
+        R::decode(raw, a, &psi, &phi);
+        if (CANON) {
+            acc[c] += ok ? PairF{psi, phi} : PairF{0.0f, 0.0f};
+            cnt[c] += (ok && __float_as_uint(phi) != 0x80000000u) ? 1 : 0;
+        } else {
+            float s0 = acc[c].x, s1 = acc[c].y;
+            accumulate(psi, phi, ok, s0, s1, cnt[c]);
+            acc[c] = PairF{s0, s1};
+        }
+    }
+}
+
+// Staging schedule of one chunk.
+struct ChunkPlan {
+    int slab_bytes;  // rows_max * LDS_COLS * BYTES
+    int E;           // epochs per group
+    int clean;       // every epoch is staged with uniform shifts: the summing loop needs no per-epoch test
+};
+template <int BYTES>
+__device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) {
+    ChunkPlan p;
+    const ConstIntPtr ci = as_const_ints(&a.chunks[chunk]);  // {dx_min, dx_max, dy_min, dy_max, unsafe, lds_ok, rows_max}
+    p.slab_bytes = ci[6] * LDS_COLS * BYTES;
+    p.E = max(1, min(a.T, LDS_GROUP_BYTES / p.slab_bytes));
+    p.clean = (ci[4] == 0 && ci[5] != 0) ? 1 : 0;
+    return p;
+}
+
+template <int BYTES>
+__device__ __forceinline__ void stage_group(const SearchArgs& a, const TileCoords& tc, const DmaLane& dl, int chunk,
+                                            int t0, const ChunkPlan& plan, char* buf) {
+    const ConstIntPtr boxes = as_const_ints(a.boxes + (size_t)chunk * a.T);  // word 0 of each box = (dy, dx)
+    const int n = min(plan.E, a.T - t0);
+    for (int e = 0; e < n; ++e) {
+        const int bw = boxes[2 * (t0 + e)];
+#ifndef KB_ABL_NO_DMA
+        if (bw != BOX_NOT_STAGED) dma_slab<BYTES>(a, tc, dl, t0 + e, bw, plan.slab_bytes, buf + e * plan.slab_bytes);
+#endif
+    }
+}
+
+// The whole search of one tile.  One flat software pipeline over (chunk, group): while
+// group g is summed out of one LDS buffer, the DMA of group g+1 -- possibly the first
+// group of the next chunk -- fills the other.
+// FAST: no sample of this tile can be NO_DATA (the tile stays inside the image under
+// every shift, the array has no NO_DATA pixel, every epoch is staged): obs_count is T.
+template <int KS, int C, int NB, bool CANON, bool SIGMAG, bool FAST>
+__device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileCoords& tc, char* smem, const DmaLane& dl,
+                                                TopK<KS>& top, SigmaGScratch<WAVE>& scratch) {
+    constexpr int SF = CANON ? 4 : NB;  // staged format
+    using R = RawPair<SF>;
+    constexpr int BYTES = 2 * fmt_bytes(SF);
+    const int T = a.T;
+    const int lane_b = (tc.wv * LDS_COLS + tc.lane) * BYTES;  // this lane's start pixel inside a slab
+
+    PairF acc[C];  // (psi_sum, phi_sum) as pairs: one v_pk_add_f32 per sample
+    int cnt[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        acc[c] = PairF{0.0f, 0.0f};
+        cnt[c] = 0;
+    }
+
+    int chunk = 0, t0 = 0, buf = 0;
+    ChunkPlan plan = chunk_plan<BYTES>(a, 0);
+    stage_group<BYTES>(a, tc, dl, 0, 0, plan, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    while (chunk < a.n_chunks) {
+        // next group in flight during this group's arithmetic
+        int n_chunk = chunk, n_t0 = t0 + plan.E;
+        ChunkPlan n_plan = plan;
+        if (n_t0 >= T) {
+            n_chunk = chunk + 1;
+            n_t0 = 0;
+            if (n_chunk < a.n_chunks) n_plan = chunk_plan<BYTES>(a, n_chunk);
+        }
+        if (n_chunk < a.n_chunks) {
+            stage_group<BYTES>(a, tc, dl, n_chunk, n_t0, n_plan, smem + (1 - buf) * LDS_GROUP_BYTES);
+        }
+
+        const ConstIntPtr offs = as_const_ints(a.lds_off + ((size_t)chunk * T + t0) * C);  // offsets for 8-byte pairs
+        const char* cb = smem + buf * LDS_GROUP_BYTES + lane_b;
+        const int n_cur = min(plan.E, T - t0);
+        // C samples of one staged epoch with uniform shifts: slab offsets o[] (scalars) -> LDS reads -> sums
+        auto sum_epoch = [&](const int (&o)[C], int e) {
+            typename R::type raw[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int off = (BYTES == 8) ? o[c] : (o[c] >> 3) * BYTES;
+                raw[c] = *reinterpret_cast<const typename R::type*>(cb + e * plan.slab_bytes + off);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if constexpr (CANON) {
+                    acc[c] += PairF{raw[c].x, raw[c].y};
+                    if (!FAST) cnt[c] += (__float_as_uint(raw[c].y) != 0x80000000u) ? 1 : 0;
+                } else {
                     float psi, phi;
-                    R::decode(raw[rr][g], a, &psi, &phi);
-                    if (FAST || f.clean) {
-                        *reinterpret_cast<float2*>(pa + rr * ROW_A + g * WAVE * 8) = make_float2(psi, phi);
+                    R::decode(raw[c], a, &psi, &phi);
+                    if (FAST) {
+                        acc[c] += PairF{psi, phi};
                     } else {
-                        const bool valid = __builtin_isfinite(psi) && __builtin_isfinite(phi);
-                        *reinterpret_cast<float2*>(pa + rr * ROW_A + g * WAVE * 8) =
-                                valid ? make_float2(psi, phi) : make_float2(0.0f, 0.0f);
-                        *reinterpret_cast<int*>(pb + rr * ROW_B + g * WAVE * 4) = valid ? 1 : 0;
+                        float s0 = acc[c].x, s1 = acc[c].y;
+                        accumulate(psi, phi, true, s0, s1, cnt[c]);
+                        acc[c] = PairF{s0, s1};
                     }
                 }
             }
+        };
+#ifdef KB_ABL_NO_SUM
+        if (false) {
+#else
+        if (FAST || plan.clean) {
+#endif
+            for (int e = 0; e < n_cur; ++e) {
+                int o[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) o[c] = offs[e * C + c];
+                sum_epoch(o, e);
+            }
+        } else {
+#ifdef KB_ABL_NO_SUM
+            for (int e = 0; e < 0; ++e) {
+#else
+            for (int e = 0; e < n_cur; ++e) {
+#endif
+                int o[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) o[c] = offs[e * C + c];
+                if (o[0] >= 0) {
+                    sum_epoch(o, e);
+                } else if (o[0] == LDS_OFF_UNSTAGED) {
+                    unstaged_epoch<C, NB>(a, tc.x, tc.y, chunk, t0 + e, acc, cnt);
+                } else {
+                    const int bw = as_const_ints(a.boxes + (size_t)chunk * T + t0 + e)[0];
+                    per_lane_epoch<C, SF, CANON>(a, tc, chunk, t0 + e, bw, plan.slab_bytes,
+                                                 smem + buf * LDS_GROUP_BYTES + e * plan.slab_bytes, acc, cnt);
+                }
+            }
         }
+
+        if (n_chunk != chunk) {  // chunk complete: likelihoods + top-K, while the next chunk's first group lands
+            if (tc.row_active) {
+                float ps[C], ph[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    ps[c] = acc[c].x;
+                    ph[c] = acc[c].y;
+                    if (FAST) cnt[c] = T;
+                }
+                finish_chunk<KS, C, SIGMAG>(a, tc, chunk, ps, ph, cnt, top, scratch);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                acc[c] = PairF{0.0f, 0.0f};
+                cnt[c] = 0;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next group's DMA has landed
+        __syncthreads();
+        buf = 1 - buf;
+        chunk = n_chunk;
+        t0 = n_t0;
+        plan = n_plan;
     }
 }
 
-// Ring-of-three pipeline state of one chunk.
-template <int NB>
-struct LdsPipe {
-    typename RawPair<NB>::type raw[STAGE_RR][STAGE_G];  // footprint of epoch t+1, loads in flight
-    Footprint f_cur;                                     // epoch t   (resident in ring slot t % 3)
-    Footprint f_pending;                                 // epoch t+1 (in `raw`)
-};
+constexpr int LDS_BLOCK = TILE_ROWS * WAVE;
 
-// One epoch t (ring slot BUF):
-//   1. publish the footprint of epoch t+1 (its loads were issued one iteration ago) into slot BUF+1,
-//   2. issue the loads of epoch t+2,
-//   3. read this epoch's C shifted rows from slot BUF and accumulate in epoch order,
-//   4. barrier.
-template <int C, int NB, bool FAST, int BUF>
-__device__ __forceinline__ void lds_epoch(const SearchArgs& a, const TileCoords& tc, char* smem, int t, int T,
-                                          const EpochBox* __restrict__ boxes, const int* __restrict__ invalid,
-                                          const int* __restrict__ offs, uint32_t g_lane, int l_lane,
-                                          LdsPipe<NB>& p, int& clean_epochs, float (&ps)[C], float (&ph)[C],
-                                          int (&cnt)[C]) {
-    int off[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) off[c] = offs[t * C + c];  // scalar loads, consumed in step 3
-
-    if (t + 1 < T) stage_write<NB, FAST, (BUF + 1) % LDS_NBUF>(a, p.f_pending, tc, smem, l_lane, p.raw);
-    const Footprint f_now = p.f_cur;
-    p.f_cur = p.f_pending;
-    if (t + 2 < T) {
-        p.f_pending = make_footprint<FAST>(a, tc, boxes[t + 2], FAST ? 0 : invalid[t + 2]);
-        stage_load<NB, FAST>(a, p.f_pending, t + 2, tc, g_lane, p.raw);
-    }
-
-    const char* cur = smem + BUF * LDS_BUF + l_lane;  // compile-time ring slot
-    float2 v[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) v[c] = *reinterpret_cast<const float2*>(cur + off[c]);
-    if (FAST || f_now.clean) {
-        if (!FAST) clean_epochs += 1;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            ps[c] += v[c].x;
-            ph[c] += v[c].y;
-        }
-    } else {
-        const char* curb = smem + BUF * LDS_BUF + LDS_PLANE_A + (l_lane >> 1);
-        int ok[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) ok[c] = *reinterpret_cast<const int*>(curb + (off[c] >> 1));
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            ps[c] += v[c].x;
-            ph[c] += v[c].y;
-            cnt[c] += ok[c];
-        }
-    }
-    __syncthreads();
-}
-
-// All T epochs of one chunk.  FAST: the workgroup's tile never leaves the image
-// under any candidate shift and the stack has no NO_DATA pixel at all, so every
-// footprint is clean, nothing is bounds-tested and obs_count is T.
-template <int C, int NB, bool FAST>
-__device__ __forceinline__ void lds_chunk(const SearchArgs& a, const TileCoords& tc, char* smem, int chunk,
-                                          uint32_t g_lane, int l_lane, float (&ps)[C], float (&ph)[C], int (&cnt)[C]) {
-    const int T = a.T;
-    const EpochBox* __restrict__ boxes = a.boxes + (size_t)chunk * T;
-    const int* __restrict__ offs = a.lds_off + (size_t)chunk * T * C;
-    const int* __restrict__ invalid = a.epoch_invalid;
-    int clean_epochs = 0;
-
-    LdsPipe<NB> p;
-    p.f_cur = make_footprint<FAST>(a, tc, boxes[0], FAST ? 0 : invalid[0]);
-    stage_load<NB, FAST>(a, p.f_cur, 0, tc, g_lane, p.raw);
-    stage_write<NB, FAST, 0>(a, p.f_cur, tc, smem, l_lane, p.raw);
-    p.f_pending = p.f_cur;
-    if (T > 1) {
-        p.f_pending = make_footprint<FAST>(a, tc, boxes[1], FAST ? 0 : invalid[1]);
-        stage_load<NB, FAST>(a, p.f_pending, 1, tc, g_lane, p.raw);
-    }
-    __syncthreads();
-
-    int t = 0;
-    for (; t + 2 < T; t += 3) {
-        lds_epoch<C, NB, FAST, 0>(a, tc, smem, t, T, boxes, invalid, offs, g_lane, l_lane, p, clean_epochs, ps, ph, cnt);
-        lds_epoch<C, NB, FAST, 1>(a, tc, smem, t + 1, T, boxes, invalid, offs, g_lane, l_lane, p, clean_epochs, ps, ph, cnt);
-        lds_epoch<C, NB, FAST, 2>(a, tc, smem, t + 2, T, boxes, invalid, offs, g_lane, l_lane, p, clean_epochs, ps, ph, cnt);
-    }
-    if (t < T) {
-        lds_epoch<C, NB, FAST, 0>(a, tc, smem, t, T, boxes, invalid, offs, g_lane, l_lane, p, clean_epochs, ps, ph, cnt);
-        if (t + 1 < T)
-            lds_epoch<C, NB, FAST, 1>(a, tc, smem, t + 1, T, boxes, invalid, offs, g_lane, l_lane, p, clean_epochs, ps,
-                                      ph, cnt);
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) cnt[c] += FAST ? T : clean_epochs;
-}
-
-template <int KS, int C, int NB, bool SIGMAG>
-__global__ __launch_bounds__(256, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_search_lds(const SearchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // ring of LDS_NBUF stage buffers
+template <int KS, int C, int NB, bool CANON, bool SIGMAG>
+// second launch bound = waves per SIMD: 4 / 3 / 2 four-wave workgroups per CU for K <= 8 / 16 / 32
+__global__ __launch_bounds__(LDS_BLOCK, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_search_lds(const SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // two group buffers
+    constexpr int BYTES = 2 * fmt_bytes(CANON ? 4 : NB);
     const TileCoords tc = tile_coords(a);  // rows past the search area stay alive (barriers)
     TopK<KS> top;
     top.init();
     SigmaGScratch<WAVE> scratch = {};
     if constexpr (SIGMAG) scratch = make_scratch(a, tc);
-    const int l_lane = (tc.wv * LDS_COLS + tc.lane) * 8;  // plane A offset of this lane
-    const uint32_t g_lane = (uint32_t)(tc.wv * a.W + tc.lane) * (uint32_t)(2 * fmt_bytes(NB));  // footprint offset
 
-    // Workgroup-uniform: can this tile take the validity-free pipeline for the whole search?
-    const int* __restrict__ gb = a.global_box;
-    const bool fast = a.epoch_invalid[a.T] == 0 && (tc.tile_x0 + gb[0] >= 0) && (tc.tile_x0 + WAVE + gb[1] <= a.W) &&
-                      (tc.tile_y0 + gb[2] >= 0) && (tc.tile_y0 + TILE_ROWS + gb[3] <= a.H);
-
-    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
-        float ps[C], ph[C];
-        int cnt[C];
+    DmaLane dl;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            ps[c] = 0.0f;
-            ph[c] = 0.0f;
-            cnt[c] = 0;
-        }
-        if (fast) {
-            lds_chunk<C, NB, true>(a, tc, smem, chunk, g_lane, l_lane, ps, ph, cnt);
-        } else {
-            lds_chunk<C, NB, false>(a, tc, smem, chunk, g_lane, l_lane, ps, ph, cnt);
-        }
-        if (tc.row_active) finish_chunk<KS, C, SIGMAG>(a, tc, chunk, ps, ph, cnt, top, scratch);
+    for (int j = 0; j < LDS_DMA_SLOTS; ++j) {
+        const int p = 16 * ((int)threadIdx.x + 256 * j) / BYTES;  // first pixel of this thread's 16 bytes
+        const int r = p / LDS_COLS, c = p - r * LDS_COLS;
+        dl.goff[j] = (uint32_t)(r * a.Wp + c) * (uint32_t)BYTES;
+    }
+
+    // Workgroup-uniform: can any sample of this tile be NO_DATA?
+    const ConstIntPtr gb = as_const_ints(a.global_box);
+    const bool fast = a.all_staged && as_const_ints(a.n_invalid)[0] == 0 && (tc.tile_x0 + gb[0] >= 0) &&
+                      (tc.tile_x0 + WAVE + gb[1] <= a.W) && (tc.tile_y0 + gb[2] >= 0) &&
+                      (tc.tile_y0 + TILE_ROWS + gb[3] <= a.H);
+    if (fast) {
+        lds_search_tile<KS, C, NB, CANON, SIGMAG, true>(a, tc, smem, dl, top, scratch);
+    } else {
+        lds_search_tile<KS, C, NB, CANON, SIGMAG, false>(a, tc, smem, dl, top, scratch);
     }
     write_results<KS, SIGMAG>(a, tc, top, scratch);
 }
@@ -879,7 +1021,7 @@ struct Workspace {
     int device = -1;
 };
 static std::mutex g_ws_mutex;
-static Workspace g_ws[2];  // 0: shift table + chunk info, 1: sigma-G scratch
+static Workspace g_ws[3];  // 0: shift table + chunk info, 1: sigma-G scratch, 2: padded array copy (LDS kernel)
 
 static int ensure_workspace(int which, size_t bytes, void** out) {
     int dev = 0;
@@ -912,52 +1054,97 @@ static bool verify_fast_decode(float scale, float min_val, int num_bytes) {
 }
 
 template <typename KernelT>
-static void debug_occupancy(const char* name, KernelT kernel, size_t lds) {
+static void debug_occupancy(const char* name, KernelT kernel, size_t lds, int block = 256) {
     if (std::getenv("KBMOD_DEBUG") == nullptr) return;
     int blocks = -1;
     hipFuncAttributes attr;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, 256, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, block, lds);
     (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel));
     std::fprintf(stderr, "[kbmod_hip] %s: %d blocks/CU, %d VGPRs, %zu B static LDS, %zu B scratch, dyn LDS %zu\n", name,
                  blocks, attr.numRegs, attr.sharedSizeBytes, attr.localSizeBytes, lds);
 }
 
+// which: 0 = kb_search_direct, 1 = kb_search_lds on an encoded padded copy, 2 = kb_search_lds on canonical floats
 template <int KS, int NB, bool SIGMAG>
-static void launch_variant(const SearchArgs& a, bool lds, hipStream_t stream) {
-    debug_occupancy("kb_search_lds", kb_search_lds<KS, CHUNK, NB, SIGMAG>, LDS_NBUF * LDS_BUF);
+static void launch_variant(const SearchArgs& a, int which, hipStream_t stream) {
+    debug_occupancy("kb_search_lds", kb_search_lds<KS, CHUNK, NB, true, SIGMAG>, 2 * LDS_GROUP_BYTES, LDS_BLOCK);
     debug_occupancy("kb_search_direct", kb_search_direct<KS, CHUNK, NB, SIGMAG>, 0);
-    if (lds) {
-        hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, NB, SIGMAG>), dim3(a.n_tiles), dim3(256), LDS_NBUF * LDS_BUF, stream, a);
+    const dim3 grid(a.n_tiles), block(256), lds_block(LDS_BLOCK);
+    if (which == 2) {
+        hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, NB, true, SIGMAG>), grid, lds_block, 2 * LDS_GROUP_BYTES, stream,
+                           a);
+    } else if (which == 1) {
+        if constexpr (NB != 4) {
+            hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, NB, false, SIGMAG>), grid, lds_block, 2 * LDS_GROUP_BYTES,
+                               stream, a);
+        }
     } else {
-        hipLaunchKernelGGL((kb_search_direct<KS, CHUNK, NB, SIGMAG>), dim3(a.n_tiles), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((kb_search_direct<KS, CHUNK, NB, SIGMAG>), grid, block, 0, stream, a);
     }
 }
 
 template <int KS, int NB>
-static void launch_sigmag(const SearchArgs& a, bool sigmag, bool lds, hipStream_t stream) {
+static void launch_sigmag(const SearchArgs& a, bool sigmag, int which, hipStream_t stream) {
     if (sigmag)
-        launch_variant<KS, NB, true>(a, lds, stream);
+        launch_variant<KS, NB, true>(a, which, stream);
     else
-        launch_variant<KS, NB, false>(a, lds, stream);
+        launch_variant<KS, NB, false>(a, which, stream);
+}
+
+// Format code of the array for the templates: 4 = float, 2 / 1 = encoded with the reference's
+// double-precision decode, 20 / 10 = encoded with the verified single-FMA decode.
+static int format_code(const SearchArgs& a) {
+    if (a.meta.num_bytes == 1) return a.fast_decode ? 10 : 1;
+    if (a.meta.num_bytes == 2) return a.fast_decode ? 20 : 2;
+    return 4;
 }
 
 template <int KS>
-static void launch_search(const SearchArgs& a, bool sigmag, bool lds, hipStream_t stream) {
-    switch (a.meta.num_bytes) {
+static void launch_search(const SearchArgs& a, bool sigmag, int which, hipStream_t stream) {
+    switch (format_code(a)) {
         case 1:
-            if (a.fast_decode)
-                launch_sigmag<KS, 10>(a, sigmag, lds, stream);
-            else
-                launch_sigmag<KS, 1>(a, sigmag, lds, stream);
+            launch_sigmag<KS, 1>(a, sigmag, which, stream);
+            break;
+        case 10:
+            launch_sigmag<KS, 10>(a, sigmag, which, stream);
             break;
         case 2:
-            if (a.fast_decode)
-                launch_sigmag<KS, 20>(a, sigmag, lds, stream);
-            else
-                launch_sigmag<KS, 2>(a, sigmag, lds, stream);
+            launch_sigmag<KS, 2>(a, sigmag, which, stream);
+            break;
+        case 20:
+            launch_sigmag<KS, 20>(a, sigmag, which, stream);
             break;
         default:
-            launch_sigmag<KS, 4>(a, sigmag, lds, stream);
+            launch_sigmag<KS, 4>(a, sigmag, which, stream);
+            break;
+    }
+}
+
+template <int NB>
+static void launch_pad_fmt(const SearchArgs& a, bool canon, void* padded, int* n_invalid, hipStream_t stream) {
+    const dim3 grid((unsigned)std::min<int64_t>(((int64_t)a.Wp + 255) / 256, 64), (unsigned)a.Hp, (unsigned)a.T);
+    if (canon)
+        hipLaunchKernelGGL((kb_pad_kernel<NB, true>), grid, dim3(256), 0, stream, a, padded, n_invalid);
+    else
+        hipLaunchKernelGGL((kb_pad_kernel<NB, false>), grid, dim3(256), 0, stream, a, padded, n_invalid);
+}
+
+static void launch_pad(const SearchArgs& a, bool canon, void* padded, int* n_invalid, hipStream_t stream) {
+    switch (format_code(a)) {
+        case 1:
+            launch_pad_fmt<1>(a, canon, padded, n_invalid, stream);
+            break;
+        case 10:
+            launch_pad_fmt<10>(a, canon, padded, n_invalid, stream);
+            break;
+        case 2:
+            launch_pad_fmt<2>(a, canon, padded, n_invalid, stream);
+            break;
+        case 20:
+            launch_pad_fmt<20>(a, canon, padded, n_invalid, stream);
+            break;
+        default:
+            launch_pad_fmt<4>(a, true, padded, n_invalid, stream);
             break;
     }
 }
@@ -1041,25 +1228,33 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
     a.chunks = nullptr;
     a.boxes = nullptr;
     a.lds_off = nullptr;
-    a.epoch_invalid = nullptr;
     a.global_box = nullptr;
+    a.padded = nullptr;
+    a.Wp = a.Hp = a.px0 = a.py0 = 0;
+    a.n_invalid = nullptr;
+    a.all_staged = 0;
 
     EventTimer table_timer(stream, stats_out != nullptr);
     EventTimer search_timer(stream, stats_out != nullptr);
     std::lock_guard<std::mutex> lock(g_ws_mutex);
 
     float table_ms = 0.0f, search_ms = 0.0f;
-    // bit 2 selects the LDS-staged kernel.  Measured on MI355X (profiles/r01_*): at 4 waves/SIMD the
-    // per-epoch stage -> barrier -> read chain of kb_search_lds is latency-bound (12.9 ms on cfg2) while
-    // kb_search_direct is bound by the vector-memory pipe (9.2 ms), so the direct kernel is the default.
-    bool use_lds = (flags & 4u) != 0 && (flags & 1u) == 0;
+    // Kernel choice.  kb_search_lds (LDS-DMA staging from a padded copy) is the default for K <= 32;
+    // flags bit 1 forces kb_search_direct, bit 2 insists on kb_search_lds even for few candidates,
+    // bit 4 keeps an encoded array encoded in the padded copy.  Measured on MI355X (profiles/r01_*):
+    // the direct kernel is bound by the vector-memory pipe (every sample is its own 512-byte wave
+    // load), the staged kernel reads each slab once per workgroup and sums out of LDS.
+    int which = 0;
+    const bool want_lds = (flags & 2u) == 0 && (flags & 1u) == 0 && a.K <= 32 &&
+                          (a.n_chunks >= 4 || (flags & 4u) != 0);
     if (n_cands > 0) {
         const size_t table_bytes = (size_t)a.n_chunks * a.T * CHUNK * sizeof(int2);
-        const size_t off_bytes = (size_t)a.n_chunks * a.T * CHUNK * sizeof(int);
+        const size_t off_bytes = ((size_t)a.n_chunks * a.T * CHUNK + 4 * CHUNK) * sizeof(int);  // + prefetch slack
         const size_t box_bytes = (size_t)a.n_chunks * a.T * sizeof(EpochBox);
         const size_t chunk_bytes = (size_t)a.n_chunks * sizeof(ChunkInfo);
-        // per-epoch NO_DATA counts [T], their total [1], the not-LDS chunk counter [1], the global shift box [4]
-        const size_t inv_bytes = ((size_t)a.T + 6) * sizeof(int);
+        // NO_DATA pixel counter [1], unstaged (chunk, epoch) counter [1], staged shift box + tallest slab [5],
+        // per-lane (chunk, epoch) counter [1]
+        const size_t inv_bytes = 8 * sizeof(int);
         void* ws = nullptr;
         if (ensure_workspace(0, table_bytes + off_bytes + box_bytes + chunk_bytes + inv_bytes, &ws)) return 1;
         char* wsc = reinterpret_cast<char*>(ws);
@@ -1068,41 +1263,72 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
         a.boxes = reinterpret_cast<const EpochBox*>(wsc + table_bytes + off_bytes);
         a.chunks = reinterpret_cast<const ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes);
         int* inv = reinterpret_cast<int*>(wsc + table_bytes + off_bytes + box_bytes + chunk_bytes);
-        a.epoch_invalid = inv;
-        int* n_not_lds = inv + a.T + 1;
-        int* gbox = inv + a.T + 2;
+        int* n_invalid = inv;
+        int* n_not_lds = inv + 1;
+        int* gbox = inv + 2;
+        a.n_invalid = n_invalid;
         a.global_box = gbox;
         table_timer.begin();
-        KB_HIP_TRY(hipMemsetAsync(inv, 0, inv_bytes, stream));
-        static const int gbox_init[4] = {INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN};
-        KB_HIP_TRY(hipMemcpyAsync(gbox, gbox_init, sizeof(gbox_init), hipMemcpyHostToDevice, stream));
+        static const int inv_init[8] = {0, 0, INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN, 0, 0};
+        KB_HIP_TRY(hipMemcpyAsync(inv, inv_init, sizeof(inv_init), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL((kb_shift_table_kernel<CHUNK>), dim3(a.n_chunks), dim3(256), 0, stream, cands_dev,
                            times_dev, a.n_cands, a.T, reinterpret_cast<int2*>(wsc),
                            reinterpret_cast<ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes),
                            reinterpret_cast<EpochBox*>(wsc + table_bytes + off_bytes),
                            reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox);
         KB_HIP_TRY(hipGetLastError());
-        if (use_lds) {
-            const dim3 grid((unsigned)std::min<uint64_t>((meta->pixels_per_image + 255) / 256, 1024), (unsigned)a.T);
-            if (meta->num_bytes == 1)
-                hipLaunchKernelGGL((kb_count_invalid_kernel<1>), grid, dim3(256), 0, stream, psi_phi_dev,
-                                   meta->pixels_per_image, inv);
-            else if (meta->num_bytes == 2)
-                hipLaunchKernelGGL((kb_count_invalid_kernel<2>), grid, dim3(256), 0, stream, psi_phi_dev,
-                                   meta->pixels_per_image, inv);
-            else
-                hipLaunchKernelGGL((kb_count_invalid_kernel<4>), grid, dim3(256), 0, stream, psi_phi_dev,
-                                   meta->pixels_per_image, inv);
-            KB_HIP_TRY(hipGetLastError());
-            // The kernel choice needs one int back: are all chunks LDS-stageable?
-            int not_lds = 0;
-            KB_HIP_TRY(hipMemcpyAsync(&not_lds, n_not_lds, sizeof(int), hipMemcpyDeviceToHost, stream));
+        if (want_lds) {
+            // The choice and the apron of the padded copy need six ints back.
+            int back[7] = {0, 0, 0, 0, 0, 0, 0};  // unstaged epochs, dx_min, dx_max, dy_min, dy_max, rows_max, per-lane epochs
+            KB_HIP_TRY(hipMemcpyAsync(back, n_not_lds, sizeof(back), hipMemcpyDeviceToHost, stream));
             KB_HIP_TRY(hipStreamSynchronize(stream));
-            if (not_lds != 0) use_lds = false;
+            // An unstaged epoch costs several times a staged one: above 10 % the direct kernel wins.
+            const uint64_t n_epochs = (uint64_t)a.n_chunks * (uint64_t)a.T;
+            if (std::getenv("KBMOD_DEBUG") != nullptr) {
+                std::fprintf(stderr,
+                             "[kbmod_hip] (chunk, epoch) pairs: %llu, unstaged %d, per-lane %d; staged shift box x [%d, %d] "
+                             "y [%d, %d], tallest slab %d rows\n",
+                             (unsigned long long)n_epochs, back[0], back[6], back[1], back[2], back[3], back[4], back[5]);
+            }
+            if (back[1] <= back[2] && (uint64_t)back[0] * 10ull <= n_epochs) {
+                // Every slab [origin, origin + rows_max) x [origin, origin + LDS_COLS) lies inside the padded frame.
+                const int64_t x_lo = (int64_t)params.x_start_min + back[1];
+                const int64_t x_hi = (int64_t)params.x_start_min + (int64_t)WAVE * (a.tiles_x - 1) + back[2] + LDS_COLS;
+                const int64_t y_lo = (int64_t)params.y_start_min + back[3];
+                const int64_t y_hi =
+                        (int64_t)params.y_start_min + (int64_t)TILE_ROWS * (a.tiles_y - 1) + back[4] + back[5];
+                const int64_t px0 = std::max<int64_t>(0, -x_lo), py0 = std::max<int64_t>(0, -y_lo);
+                const int64_t Wp = px0 + std::max<int64_t>(a.W, x_hi), Hp = py0 + std::max<int64_t>(a.H, y_hi);
+                const uint64_t frame = (uint64_t)a.T * (uint64_t)Hp * (uint64_t)Wp;
+                const uint64_t image = (uint64_t)a.T * (uint64_t)a.H * (uint64_t)a.W;
+                // Canonical floats unless the caller keeps the array encoded or HBM is short.
+                bool canon = meta->num_bytes == 4 || (flags & 16u) == 0;
+                if (canon && meta->num_bytes != 4) {
+                    size_t free_b = 0, total_b = 0;
+                    KB_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+                    const uint64_t have = g_ws[2].ptr != nullptr ? g_ws[2].bytes : 0;
+                    if (frame * 8ull + 64 > have && frame * 8ull + (2ull << 30) > (uint64_t)free_b + have) canon = false;
+                }
+                const uint64_t pair_bytes = canon ? 8ull : 2ull * (uint64_t)meta->block_size;
+                const uint64_t padded_bytes = frame * pair_bytes + 64;
+                // Per-lane DMA offsets are 32-bit; an apron that outweighs the image 3:1 is not worth staging.
+                if ((uint64_t)back[5] * (uint64_t)Wp * pair_bytes <= 0x7fffffffull && frame <= 4ull * image + (8ull << 20)) {
+                    void* padded = nullptr;
+                    if (ensure_workspace(2, padded_bytes, &padded)) return 1;
+                    a.padded = padded;
+                    a.Wp = (int)Wp;
+                    a.Hp = (int)Hp;
+                    a.px0 = (int)px0;
+                    a.py0 = (int)py0;
+                    // bit 5 (debug): never take the count-free specialisation
+                    a.all_staged = (back[0] == 0 && back[6] == 0 && (flags & 32u) == 0) ? 1 : 0;
+                    launch_pad(a, canon, padded, n_invalid, stream);
+                    KB_HIP_TRY(hipGetLastError());
+                    which = canon ? 2 : 1;
+                }
+            }
         }
         table_ms = table_timer.end();
-    } else {
-        use_lds = false;
     }
 
     const bool sigmag = params.do_sigmag_filter != 0;
@@ -1117,24 +1343,30 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
     search_timer.begin();
     int variant;
     if (a.K > 32) {
-        use_lds = false;
         if (sigmag)
             hipLaunchKernelGGL((kb_search_large_k<true>), dim3(a.n_tiles), dim3(256), 0, stream, a);
         else
             hipLaunchKernelGGL((kb_search_large_k<false>), dim3(a.n_tiles), dim3(256), 0, stream, a);
         variant = 99;
     } else if (a.K <= 8) {
-        launch_search<8>(a, sigmag, use_lds, stream);
+        launch_search<8>(a, sigmag, which, stream);
         variant = 8;
     } else if (a.K <= 16) {
-        launch_search<16>(a, sigmag, use_lds, stream);
+        launch_search<16>(a, sigmag, which, stream);
         variant = 16;
     } else {
-        launch_search<32>(a, sigmag, use_lds, stream);
+        launch_search<32>(a, sigmag, which, stream);
         variant = 32;
     }
     KB_HIP_TRY(hipGetLastError());
     search_ms = search_timer.end();
+    if (which != 0 && std::getenv("KBMOD_DEBUG") != nullptr) {
+        int bad = -1;
+        KB_HIP_TRY(hipMemcpyAsync(&bad, a.n_invalid, sizeof(int), hipMemcpyDeviceToHost, stream));
+        KB_HIP_TRY(hipStreamSynchronize(stream));
+        std::fprintf(stderr, "[kbmod_hip] padded frame %d x %d (image at %d, %d), NO_DATA pixels %d, all_staged %d\n", a.Wp,
+                     a.Hp, a.px0, a.py0, bad, a.all_staged);
+    }
 
     if (stats_out != nullptr) {
         const uint64_t S = (uint64_t)sw * (uint64_t)sh;
@@ -1143,11 +1375,27 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
         stats_out->num_evals = S * n_cands * meta->num_times;
         stats_out->algorithmic_bytes = stats_out->num_evals * 2ull * (uint64_t)meta->block_size +
                                        S * (uint64_t)a.K * 28ull + n_cands * 28ull + meta->num_times * 8ull;
-        stats_out->kernel_variant = (use_lds ? 10000 : 0) + variant * 100 + meta->num_bytes * 10 + (sigmag ? 1 : 0);
+        stats_out->kernel_variant = which * 10000 + variant * 100 + meta->num_bytes * 10 + (sigmag ? 1 : 0);
         stats_out->num_search_launches = 1;
     } else {
         // kernels.cu:396 -- the reference call is synchronous.
         KB_HIP_TRY(hipStreamSynchronize(stream));
+    }
+    return 0;
+}
+
+int kb_release_workspaces(void) {
+    using namespace kb;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    for (Workspace& w : g_ws) {
+        if (w.ptr != nullptr) {
+            int prev = 0;
+            KB_HIP_TRY(hipGetDevice(&prev));
+            KB_HIP_TRY(hipSetDevice(w.device));
+            KB_HIP_TRY(hipFree(w.ptr));
+            KB_HIP_TRY(hipSetDevice(prev));
+        }
+        w = Workspace();
     }
     return 0;
 }

@@ -34,54 +34,127 @@ def cands():
 
 @pytest.fixture(scope="module")
 def lds_cands():
-    # No candidate lands on an exact half-pixel, so every chunk is LDS-stageable.
+    # No candidate lands on an exact half-pixel, so every (chunk, epoch) is staged through LDS.
     return fd.kbmod_v1_candidates(16, 5.0, 20.0, 9, 0.05, 1.45)  # 16 = 2 chunks per angle row, <= 8 px spread
 
 
-def _used_lds(search):
-    return search.last_search_stats()["kernel_variant"] >= 10000
+# kb_device_search_filter flags (include/kbmod_hip.h)
+EXACT, DIRECT, LDS, DOUBLE_DECODE, ENCODED_STAGING = 1, 2, 4, 8, 16
+KERNELS = {"direct": DIRECT, "lds": LDS, "lds_encoded": LDS | ENCODED_STAGING}
+
+
+@pytest.fixture(params=["direct", "lds"])
+def kern(request):
+    return request.param
+
+
+def _variant(search):
+    return search.last_search_stats()["kernel_variant"] // 10000  # 0 direct, 1 LDS/encoded copy, 2 LDS/floats
+
+
+def _check_kernel(search, kern, num_bytes=-1):
+    want = {"direct": 0, "lds": 2, "lds_encoded": 2 if num_bytes in (-1, 4) else 1}[kern]
+    assert _variant(search) == want, search.last_search_stats()
 
 
 def test_requires_gpu(kb):
     assert kb.kb_has_gpu(), "-m gpu tests need a device; the product has no CPU fallback"
 
 
-def test_float_default(kb, orc, stack, cands):
-    got, exp, s = util.run_both(kb, orc, stack, *cands, {})
+def test_float_default(kb, orc, stack, cands, kern):
+    got, exp, s = util.run_both(kb, orc, stack, *cands, {}, flags=KERNELS[kern])
+    _check_kernel(s, kern)
     _check(got, exp)
     assert s.last_search_stats()["num_evals"] == 20 * 80 * 100 * 132
 
 
+def test_default_kernel_choice(kb, orc, stack, cands):
+    # flags = 0: the LDS kernel from 4 chunks of candidates on, the direct kernel for fewer.
+    got, exp, s = util.run_both(kb, orc, stack, *cands, {})
+    assert _variant(s) == 2
+    _check(got, exp)
+    got, exp, s = util.run_both(kb, orc, stack, cands[0][:20], cands[1][:20], {})
+    assert _variant(s) == 0
+    _check(got, exp)
+
+
 @pytest.mark.parametrize("num_bytes", [-1, 1, 2])
+@pytest.mark.parametrize("staging", ["lds", "lds_encoded"])
 @pytest.mark.parametrize("cfg", [{}, {"K": 10, "min_obs": 5}, {"xb": (-10, 110), "yb": (-10, 90), "min_lh": -1e30},
                                  {"sigmag": (0.25, 0.75, 0.7413, 5.0), "min_obs": 8}])
-def test_lds_kernel(kb, orc, stack, lds_cands, cfg, num_bytes):
-    """The LDS-staged kernel (masked pixels -> validity plane; off-image starts -> edge staging)."""
-    got, exp, s = util.run_both(kb, orc, stack, *lds_cands, cfg, num_bytes=num_bytes, flags=4)
-    assert _used_lds(s)
+def test_lds_kernel(kb, orc, stack, lds_cands, cfg, num_bytes, staging):
+    """The LDS-staged kernel: masked pixels and off-image starts come out of the padded copy."""
+    if staging == "lds_encoded" and num_bytes == -1:
+        pytest.skip("float arrays are always staged as canonical floats")
+    got, exp, s = util.run_both(kb, orc, stack, *lds_cands, cfg, num_bytes=num_bytes, flags=KERNELS[staging])
+    _check_kernel(s, staging, num_bytes)
     _check(got, exp)
 
 
 def test_lds_kernel_clean_stack(kb, orc, lds_cands):
-    """No masked pixel anywhere: interior tiles take the raw (validity-free) staging path."""
+    """No masked pixel anywhere: interior tiles take the count-free specialisation."""
     st = util.make_stack(21, 96, 200, seed=77, objects=OBJ)
-    got, exp, s = util.run_both(kb, orc, st, *lds_cands, {"min_obs": 3}, flags=4)
-    assert _used_lds(s)
+    got, exp, s = util.run_both(kb, orc, st, *lds_cands, {"min_obs": 3}, flags=LDS)
+    _check_kernel(s, "lds")
     _check(got, exp)
-    a, _, s2 = util.run_both(kb, orc, st, *lds_cands, {"min_obs": 3}, flags=0)
-    assert not _used_lds(s2)
+    a, _, s2 = util.run_both(kb, orc, st, *lds_cands, {"min_obs": 3}, flags=DIRECT)
+    _check_kernel(s2, "direct")
     _check(a, exp)
 
 
+def test_lds_kernel_unstaged_epochs(kb, orc):
+    """Epochs the LDS kernel cannot stage -- shifts exactly on a rounding boundary, chunks whose
+    candidates spread further than a slab -- are evaluated per lane inside the same kernel."""
+    times = np.arange(24) * 0.25  # vx * t + 0.5 is an integer for odd vx at every other odd epoch
+    st = util.make_stack(24, 40, 150, seed=21, objects=[(30, 10, 9.0, 2.0, 200.0)], mask_fraction=0.02, times=times)
+    vx, vy = fd.kbmod_v1_candidates(16, 2.0, 9.0, 16, 0.02, 0.9)
+    vx, vy = vx.copy(), vy.copy()
+    vx[3], vy[3] = 3.0, 1.0     # half-integer products at odd epochs: per-lane pixels inside the slab
+    vx[40], vy[40] = -5.0, 7.0
+    vx[77], vy[77] = 60.0, -35.0  # one outlier: its chunk no longer fits a slab once it has moved away
+    vx[130], vy[130] = 3.0e7, 1.0  # beyond the proven range of the shift table
+    got, exp, s = util.run_both(kb, orc, st, vx, vy, {"min_lh": -1e30, "xb": (-5, 155), "yb": (-3, 44)}, flags=LDS)
+    _check_kernel(s, "lds")
+    _check(got, exp)
+
+
+def test_lds_request_falls_back_when_little_stages(kb, orc):
+    # half of the candidates move further than the shift table's proven range: every (chunk, epoch)
+    # with t > 0 is unstaged -> more than 10 % -> the direct kernel runs instead
+    st = util.make_stack(6, 32, 70, seed=11)
+    vx = np.tile(np.array([1.0, 3.0e7, -1.0, 5.0], dtype=np.float32), 10)
+    vy = np.tile(np.array([3.0, -1.0, 1.0e8, 7.0], dtype=np.float32), 10)
+    got, exp, s = util.run_both(kb, orc, st, vx, vy, {"min_lh": -1e30}, flags=LDS)
+    assert _variant(s) == 0
+    _check(got, exp)
+
+
+def test_lds_kernel_boundary_shifts_everywhere(kb, orc):
+    # every epoch of every chunk has a shift on a rounding boundary: all of them are staged with one
+    # pixel of slack and summed per lane out of LDS
+    times = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 2.5])
+    st = util.make_stack(6, 32, 70, seed=11, times=times, mask_fraction=0.03)
+    vx = np.tile(np.array([1.0, 3.0, -1.0, 5.0], dtype=np.float32), 10)
+    vy = np.tile(np.array([3.0, -1.0, 1.0, 7.0], dtype=np.float32), 10)
+    for nb in (-1, 1):
+        got, exp, s = util.run_both(kb, orc, st, vx, vy, {"min_lh": -1e30, "xb": (-4, 74), "yb": (-4, 36)},
+                                    num_bytes=nb, flags=LDS)
+        assert _variant(s) == 2
+        _check(got, exp)
+
+
 def test_table_path_equals_exact_path(kb, orc, stack, cands):
-    a, _, _ = util.run_both(kb, orc, stack, *cands, {}, flags=0)
-    b, _, _ = util.run_both(kb, orc, stack, *cands, {}, flags=1)
+    a, _, _ = util.run_both(kb, orc, stack, *cands, {}, flags=DIRECT)
+    b, _, _ = util.run_both(kb, orc, stack, *cands, {}, flags=EXACT)
+    c, _, _ = util.run_both(kb, orc, stack, *cands, {}, flags=LDS)
     _check(a, b)
+    _check(c, b)
 
 
 @pytest.mark.parametrize("K", [1, 5, 8, 10, 16, 20, 32])
-def test_results_per_pixel(kb, orc, stack, cands, K):
-    got, exp, _ = util.run_both(kb, orc, stack, *cands, {"K": K, "min_lh": -1e30})
+def test_results_per_pixel(kb, orc, stack, cands, K, kern):
+    got, exp, s = util.run_both(kb, orc, stack, *cands, {"K": K, "min_lh": -1e30}, flags=KERNELS[kern])
+    _check_kernel(s, kern)
     _check(got, exp)
     assert len(got) == K * 80 * 100  # every slot survives min_lh = -1e30, placeholders are -FLT_MAX
 
@@ -100,73 +173,74 @@ def test_large_k_keeps_every_candidate(kb, orc):
     _check(got, exp)
 
 
-def test_min_obs_and_min_lh(kb, orc, stack, cands):
-    got, exp, _ = util.run_both(kb, orc, stack, *cands, {"min_obs": 12, "min_lh": 2.5})
+def test_min_obs_and_min_lh(kb, orc, stack, cands, kern):
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, {"min_obs": 12, "min_lh": 2.5}, flags=KERNELS[kern])
     _check(got, exp)
 
 
-def test_extended_bounds(kb, orc, stack, cands):
+def test_extended_bounds(kb, orc, stack, cands, kern):
     cfg = {"xb": (-10, 110), "yb": (-10, 90), "K": 5}
-    got, exp, _ = util.run_both(kb, orc, stack, *cands, cfg)
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, cfg, flags=KERNELS[kern])
     _check(got, exp)
 
 
-def test_reduced_bounds(kb, orc, stack, cands):
+def test_reduced_bounds(kb, orc, stack, cands, kern):
     cfg = {"xb": (5, 95), "yb": (5, 75), "K": 10, "min_lh": -1e30}
-    got, exp, _ = util.run_both(kb, orc, stack, *cands, cfg)
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, cfg, flags=KERNELS[kern])
     _check(got, exp)
     assert len(got) == 10 * 90 * 70
 
 
-def test_fewer_candidates_than_slots(kb, orc, stack):
+def test_fewer_candidates_than_slots(kb, orc, stack, kern):
     vx, vy = fd.velocity_grid_candidates(2, -5.0, 5.0, 2, -3.0, 3.0)
-    got, exp, _ = util.run_both(kb, orc, stack, vx, vy, {"min_lh": -1e30})
+    got, exp, _ = util.run_both(kb, orc, stack, vx, vy, {"min_lh": -1e30}, flags=KERNELS[kern])
     _check(got, exp)
 
 
-@pytest.mark.parametrize("flags", [0, 8])  # 0: verified fp32-FMA decode, 8: double decode
+@pytest.mark.parametrize("decode", [0, DOUBLE_DECODE])  # 0: verified fp32-FMA decode
 @pytest.mark.parametrize("num_bytes", [1, 2])
-def test_encoded(kb, orc, stack, cands, num_bytes, flags):
-    got, exp, _ = util.run_both(kb, orc, stack, *cands, {"min_obs": 10}, num_bytes=num_bytes, flags=flags)
+@pytest.mark.parametrize("kernel", ["direct", "lds", "lds_encoded"])
+def test_encoded(kb, orc, stack, cands, num_bytes, decode, kernel):
+    got, exp, s = util.run_both(kb, orc, stack, *cands, {"min_obs": 10}, num_bytes=num_bytes,
+                                flags=KERNELS[kernel] | decode)
+    _check_kernel(s, kernel, num_bytes)
     _check(got, exp)
 
 
 @pytest.mark.parametrize("num_bytes", [-1, 1])
-def test_sigma_g(kb, orc, stack, cands, num_bytes):
+def test_sigma_g(kb, orc, stack, cands, num_bytes, kern):
     cfg = {"sigmag": (0.25, 0.75, 0.7413, 5.0), "min_obs": 8}
-    got, exp, _ = util.run_both(kb, orc, stack, *cands, cfg, num_bytes=num_bytes)
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, cfg, num_bytes=num_bytes, flags=KERNELS[kern])
     _check(got, exp)
     assert len(got) > 0
 
 
-def test_sigma_g_low_threshold(kb, orc):
+def test_sigma_g_low_threshold(kb, orc, kern):
     # min_lh below every likelihood: every trajectory with data is clipped.
     st = util.make_stack(9, 24, 40, seed=5, objects=[(8, 8, 10.0, 4.0, 120.0)], mask_fraction=0.05)
     vx, vy = fd.kbmod_v1_candidates(4, 2.0, 20.0, 5, 0.0, 1.2)
     cfg = {"sigmag": (0.15, 0.85, 0.4824, -50.0), "K": 4}
-    got, exp, _ = util.run_both(kb, orc, st, vx, vy, cfg)
+    got, exp, _ = util.run_both(kb, orc, st, vx, vy, cfg, flags=KERNELS[kern])
     _check(got, exp)
 
 
-def test_half_integer_shifts_take_exact_path(kb, orc):
+def test_half_integer_shifts_take_exact_path(kb, orc, kern):
     # vx * t + 0.5 lands exactly on integers: the shift table must refuse these.
     times = np.array([0.0, 0.25, 0.5, 0.75, 1.0, 1.5])
     st = util.make_stack(6, 32, 70, seed=11, times=times)
     vx = np.array([2.0, 6.0, -2.0, 1.0], dtype=np.float32)
     vy = np.array([2.0, -6.0, 1.0, 0.0], dtype=np.float32)
-    got, exp, _ = util.run_both(kb, orc, st, vx, vy, {"min_lh": -1e30, "xb": (-3, 73), "yb": (-3, 35)})
+    got, exp, _ = util.run_both(kb, orc, st, vx, vy, {"min_lh": -1e30, "xb": (-3, 73), "yb": (-3, 35)},
+                                flags=KERNELS[kern])
     _check(got, exp)
 
 
 def test_empty_candidate_list(kb, stack):
+    # The reference cannot place an empty list on the device: GPUArray::allocate_gpu_memory
+    # (gpu_array.h:113-119) / allocate_gpu_block (kernel_memory.cu:93-103) throw for 0 bytes.
     s = kb.StackSearch(stack.sci, stack.var, stack.psfs, stack.zeroed_times)
-    s.search_all([], True)
-    assert s.get_number_total_results() == 0  # only -FLT_MAX placeholders, all below min_lh = 0
-    s.set_min_lh(-3.5e38)
-    s.set_results_per_pixel(2)
-    s.search_all([], True)
-    res = s.results_to_numpy()
-    assert len(res) == 2 * 80 * 100 and np.all(res[:, 4] == np.float32(-3.4028234663852886e38)) and np.all(res[:, 6] == 0)
+    with pytest.raises(RuntimeError):
+        s.search_all([], True)
 
 
 def test_too_many_images(kb):
@@ -179,9 +253,9 @@ def test_too_many_images(kb):
         s.evaluate_single_trajectory(t, True)
 
 
-def test_deep_stack_512(kb, orc):
+def test_deep_stack_512(kb, orc, kern):
     # beyond the reference's 200-epoch device limit
     st = util.make_stack(512, 16, 70, seed=3, objects=[(5, 5, 30.0, 6.0, 80.0)])
     vx, vy = fd.kbmod_v1_candidates(4, 10.0, 40.0, 3, 0.0, 0.6)
-    got, exp, _ = util.run_both(kb, orc, st, vx, vy, {"min_obs": 100}, num_bytes=2)
+    got, exp, _ = util.run_both(kb, orc, st, vx, vy, {"min_obs": 100}, num_bytes=2, flags=KERNELS[kern])
     _check(got, exp)
