@@ -204,6 +204,8 @@ def main():
     total_evals = evals_per_step_rank * world * args.steps
     value = total_evals / elapsed
     k_ms = float(np.mean(kernel_ms))
+    # kb_search_stats.kernel_variant: 0xxxx = kb_search_direct, 1xxxx / 2xxxx = kb_search_lds (encoded / float copy)
+    kernel_name = "kb_search_direct" if int(last.kernel_variant) // 10000 == 0 else "kb_search_lds"
     achieved = float(last.algorithmic_bytes) / (k_ms * 1e-3) / 1e9
 
     out = {
@@ -235,7 +237,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": None,
-            "kernel": "kb_search_direct" if args.flags & 4 == 0 else "kb_search_lds",
+            "kernel": kernel_name,
             "kernel_ms": k_ms,
             "algorithmic_bytes_per_launch": int(last.algorithmic_bytes),
             "kernel_evals_per_s": evals_per_step_rank / (k_ms * 1e-3),
@@ -247,8 +249,8 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             traffic = json.load(fh)
-        key = f"{out['dtype']}:{T}x{H}x{W}:{n_local}"
-        if key in traffic and args.flags == 0:
+        key = f"{out['dtype']}:{T}x{H}x{W}:{n_local}:{kernel_name}"
+        if key in traffic:
             out["roofline"]["traffic"] = traffic[key]["bytes"]
             out["roofline"]["traffic_source"] = traffic[key]["source"]
     except (OSError, ValueError):

@@ -53,6 +53,9 @@ constexpr int CHUNK = 8;                 // candidates accumulated together per 
 constexpr int LDS_COLS = 88;          // slab pitch in pixels: 64 start columns + up to 24 of dx spread
                                       // (88 * {8,4,2} bytes are multiples of the 16-byte DMA granule)
 constexpr int LDS_GROUP_BYTES = 20480;  // one group buffer; two per workgroup = 40 KiB -> 4 workgroups per CU
+constexpr int LDS_ALIGN_PX = 8;         // slab origins are multiples of 8 columns of the padded frame
+constexpr int LDS_SLOTS = 3;            // 16-byte pieces a thread holds in registers at once; slabs beyond
+                                        // 3 x 4 KiB are copied in further, non-overlapped rounds
 
 struct ChunkInfo {
     int dx_min, dx_max, dy_min, dy_max;  // bounding box of the chunk's shifts over all epochs
@@ -82,6 +85,8 @@ struct SearchArgs {
     const int2* table;         // [n_chunks][T][C] integer shifts (dx, dy)
     const ChunkInfo* chunks;   // [n_chunks]
     const EpochBox* boxes;     // [n_chunks][T]
+    const int64_t* origins;    // [n_chunks][T] byte offset of the slab origin inside the padded copy, relative
+                               // to the tile's own pixel (kb_slab_origin_kernel); -1 = not staged
     const int* lds_off;        // [n_chunks][T][C] byte offset of the shifted tile inside plane A
     const int* global_box;     // {dx_min, dx_max, dy_min, dy_max, rows_max} over every (candidate, epoch)
     const void* padded;        // [T][Hp][Wp] raw pairs, apron = NO_DATA (kb_search_lds only)
@@ -177,6 +182,10 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
                 }
             }
         }
+        // The slab starts on a multiple of LDS_ALIGN_PX columns of the padded frame (the host places the
+        // image so that x_start_min + px0 is one): 16-byte pieces of a slab row are then 16-byte aligned
+        // in HBM, 64-byte aligned for float pairs, which the vector memory pipe needs for its full rate.
+        if (ex0 <= ex1) ex0 -= ((ex0 % LDS_ALIGN_PX) + LDS_ALIGN_PX) % LDS_ALIGN_PX;
         // A slab of (TILE_ROWS + dy spread) x LDS_COLS 8-byte pairs must fit one group buffer.
         const bool fits = !epoch_wild && ex0 <= ex1 && (ex1 - ex0) <= (LDS_COLS - WAVE) &&
                           (TILE_ROWS + ey1 - ey0) * LDS_COLS * 8 <= LDS_GROUP_BYTES && ex0 > -30000 && ex1 < 30000 &&
@@ -634,45 +643,80 @@ __device__ __forceinline__ ConstIntPtr as_const_ints(const P* p) {
     return (ConstIntPtr)(uintptr_t)p;
 }
 
-// Per-thread constants of the DMA map.  A workgroup-wide DMA step j moves 4 KiB:
-// thread tid's 16 bytes land at slab offset o = 16 * (tid + 256 j), i.e. pixel
-// p = o / BYTES = (row, col) = divmod(p, LDS_COLS) of the slab; its source is the
-// padded array at the slab origin plus (row * Wp + col) * BYTES.
-constexpr int LDS_DMA_SLOTS = LDS_GROUP_BYTES / 4096;
-struct DmaLane {
-    uint32_t goff[LDS_DMA_SLOTS];
+// Slab origins as byte offsets, once the host has fixed the padded frame: the search kernel adds
+// the tile's own offset and is spared the 64-bit index arithmetic per (chunk, epoch).
+__global__ __launch_bounds__(256) void kb_slab_origin_kernel(const EpochBox* __restrict__ boxes, int64_t n, int T, int Hp,
+                                                             int Wp, int px0, int py0, int pair_bytes,
+                                                             int64_t* __restrict__ origins) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const EpochBox box = boxes[i];
+    const int t = (int)(i % T);
+    origins[i] = (box.x == BOX_NOT_STAGED)
+                         ? -1
+                         : (((int64_t)t * Hp + box_dy(box) + py0) * Wp + box_dx(box) + px0) * (int64_t)pair_bytes;
+}
+
+// Staging map.  A slab (rows x LDS_COLS raw pairs, dense) is copied in workgroup-wide steps of
+// 4 KiB: in step j thread tid moves the 16 bytes at slab offset o = 16 * (tid + 256 j), i.e.
+// pixel p = o / BYTES = (row, col) = divmod(p, LDS_COLS) of the slab, from the padded array at
+// the slab origin plus (row * Wp + col) * BYTES.  The copy goes through registers
+// (global_load_dwordx4 -> ds_write_b128): measured on MI355X the LDS-DMA form of the same copy
+// (global_load_lds_dwordx4) sustains only ~12 B/clk/CU and stalls the issuing wave.
+struct StageLane {
+    uint32_t goff[LDS_SLOTS];
+};
+typedef uint32_t Piece __attribute__((ext_vector_type(4)));
+template <int ALIGN>
+struct __attribute__((packed, aligned(ALIGN))) PieceMem {
+    uint32_t w[4];
+};
+struct SlabRegs {
+    Piece v[LDS_SLOTS];
 };
 
-// Issue the DMA of one epoch's slab (rows x LDS_COLS raw pairs) into LDS at `dst`
-// (wave-uniform).  Slab origin = tile origin + (dx_min, dy_min) of (chunk, epoch).
+// Issue the loads of one epoch's slab; `base` = its origin in the padded copy (uniform).  All LDS_SLOTS
+// loads are issued whatever the slab size (no branch, no exec mask -- the compiler would serialise
+// masked loads with vmcnt(0)): threads past the end of the slab re-read its first bytes and do not
+// write them to LDS.
 template <int BYTES>
-__device__ __forceinline__ void dma_slab(const SearchArgs& a, const TileCoords& tc, const DmaLane& dl, int t,
-                                         int box_word, int slab_bytes, char* dst) {
-    const EpochBox box = make_int2(box_word, 0);
-    const int64_t origin =
-            (((int64_t)t * a.Hp + (tc.tile_y0 + box_dy(box) + a.py0)) * a.Wp + (tc.tile_x0 + box_dx(box) + a.px0)) * BYTES;
-    const char* base = reinterpret_cast<const char*>(a.padded) + origin;
+__device__ __forceinline__ void load_slab(const SearchArgs& a, const StageLane& sl, const char* base, int slab_bytes,
+                                          SlabRegs& regs, int j0 = 0) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < LDS_DMA_SLOTS; ++j) {
-        if (4096 * j < slab_bytes) {  // uniform
-            if (16 * (tid + 256 * j) < slab_bytes) {
-                // LDS destination: M0 = wave-uniform base, the hardware adds lane * 16.  Issued as inline
-                // assembly on purpose: for the builtin the compiler tracks the DMA as an LDS write in flight
-                // and puts s_waitcnt vmcnt(0) in front of every ds_read of the compute loop, which serialises
-                // the staging of group g+1 with the arithmetic on group g.  The waits are explicit instead
-                // (vmcnt(0) + barrier before a group buffer is read).
-                const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(dst + 4096 * j) +
-                                     1024u * (uint32_t)tc.wv;
-                asm volatile(
-                        "s_mov_b32 m0, %0\n\t"
-                        "s_nop 0\n\t"
-                        "global_load_lds_dwordx4 %1, %2"
-                        :
-                        : "s"(lds), "v"(dl.goff[j]), "s"(base)
-                        : "memory");
-            }
+    for (int j = 0; j < LDS_SLOTS; ++j) {
+        uint32_t goff = sl.goff[j];
+        if (j0 != 0) {  // uniform, rare: rounds after the first compute their map on the fly
+            const int p = 16 * (tid + 256 * (j0 + j)) / BYTES;
+            const int r = p / LDS_COLS, c = p - r * LDS_COLS;
+            goff = (uint32_t)(r * a.Wp + c) * (uint32_t)BYTES;
         }
+        const uint32_t off = (16 * (tid + 256 * (j0 + j)) < slab_bytes) ? goff : 0u;
+        // only BYTES-aligned: the hardware takes unaligned 16-byte global loads
+        const PieceMem<(BYTES < 4 ? BYTES : 4)>* src = reinterpret_cast<const PieceMem<(BYTES < 4 ? BYTES : 4)>*>(base + off);
+        regs.v[j] = Piece{src->w[0], src->w[1], src->w[2], src->w[3]};
+    }
+}
+
+__device__ __forceinline__ void write_slab(char* dst, int slab_bytes, const SlabRegs& regs, int j0 = 0) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < LDS_SLOTS; ++j) {
+        if (4096 * (j0 + j) < slab_bytes) {  // uniform
+            const int o = 16 * (tid + 256 * (j0 + j));
+            if (o < slab_bytes) *reinterpret_cast<Piece*>(dst + o) = regs.v[j];
+        }
+    }
+}
+
+// Rounds after the first of a slab larger than LDS_SLOTS x 4 KiB (load, then write, no overlap).
+template <int BYTES>
+__device__ __forceinline__ void copy_slab_tail(const SearchArgs& a, const StageLane& sl, const char* base, int slab_bytes,
+                                               char* dst, SlabRegs& regs) {
+    for (int j0 = LDS_SLOTS; 4096 * j0 < slab_bytes; j0 += LDS_SLOTS) {
+        load_slab<BYTES>(a, sl, base, slab_bytes, regs, j0);
+        write_slab(dst, slab_bytes, regs, j0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
 }
 
@@ -758,27 +802,15 @@ __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) 
     return p;
 }
 
-template <int BYTES>
-__device__ __forceinline__ void stage_group(const SearchArgs& a, const TileCoords& tc, const DmaLane& dl, int chunk,
-                                            int t0, const ChunkPlan& plan, char* buf) {
-    const ConstIntPtr boxes = as_const_ints(a.boxes + (size_t)chunk * a.T);  // word 0 of each box = (dy, dx)
-    const int n = min(plan.E, a.T - t0);
-    for (int e = 0; e < n; ++e) {
-        const int bw = boxes[2 * (t0 + e)];
-#ifndef KB_ABL_NO_DMA
-        if (bw != BOX_NOT_STAGED) dma_slab<BYTES>(a, tc, dl, t0 + e, bw, plan.slab_bytes, buf + e * plan.slab_bytes);
-#endif
-    }
-}
-
 // The whole search of one tile.  One flat software pipeline over (chunk, group): while
-// group g is summed out of one LDS buffer, the DMA of group g+1 -- possibly the first
-// group of the next chunk -- fills the other.
+// group g is summed out of one LDS buffer, group g+1 -- possibly the first group of the next
+// chunk -- is copied into the other, one slab per summed epoch: its loads are issued before
+// the epoch's sums and written to LDS after them.
 // FAST: no sample of this tile can be NO_DATA (the tile stays inside the image under
 // every shift, the array has no NO_DATA pixel, every epoch is staged): obs_count is T.
 template <int KS, int C, int NB, bool CANON, bool SIGMAG, bool FAST>
-__device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileCoords& tc, char* smem, const DmaLane& dl,
-                                                TopK<KS>& top, SigmaGScratch<WAVE>& scratch) {
+__device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileCoords& tc, char* smem,
+                                                const StageLane& sl, TopK<KS>& top, SigmaGScratch<WAVE>& scratch) {
     constexpr int SF = CANON ? 4 : NB;  // staged format
     using R = RawPair<SF>;
     constexpr int BYTES = 2 * fmt_bytes(SF);
@@ -795,8 +827,23 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 
     int chunk = 0, t0 = 0, buf = 0;
     ChunkPlan plan = chunk_plan<BYTES>(a, 0);
-    stage_group<BYTES>(a, tc, dl, 0, 0, plan, smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SlabRegs regs;
+    typedef const __attribute__((address_space(4))) int64_t* ConstI64Ptr;
+    // this tile's own pixel inside the padded copy
+    const char* tile_base = reinterpret_cast<const char*>(a.padded) + ((int64_t)tc.tile_y0 * a.Wp + tc.tile_x0) * BYTES;
+    {
+        const ConstI64Ptr org = (ConstI64Ptr)(uintptr_t)a.origins;
+        const int n = min(plan.E, T);
+        for (int e = 0; e < n; ++e) {
+            const int64_t o = org[e];
+            if (o >= 0) {
+                load_slab<BYTES>(a, sl, tile_base + o, plan.slab_bytes, regs);
+                write_slab(smem + e * plan.slab_bytes, plan.slab_bytes, regs);
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+                copy_slab_tail<BYTES>(a, sl, tile_base + o, plan.slab_bytes, smem + e * plan.slab_bytes, regs);
+            }
+        }
+    }
     __syncthreads();
 
     while (chunk < a.n_chunks) {
@@ -808,9 +855,33 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             n_t0 = 0;
             if (n_chunk < a.n_chunks) n_plan = chunk_plan<BYTES>(a, n_chunk);
         }
-        if (n_chunk < a.n_chunks) {
-            stage_group<BYTES>(a, tc, dl, n_chunk, n_t0, n_plan, smem + (1 - buf) * LDS_GROUP_BYTES);
-        }
+        const int n_next = (n_chunk < a.n_chunks) ? min(n_plan.E, T - n_t0) : 0;
+        const ConstI64Ptr n_org = (ConstI64Ptr)(uintptr_t)(a.origins + (size_t)min(n_chunk, a.n_chunks - 1) * T + n_t0);
+        char* nb = smem + (1 - buf) * LDS_GROUP_BYTES;
+        // slab e of the next group: loads issued before, LDS writes after the sums of epoch e
+        const char* n_base = tile_base;
+        auto next_load = [&](int e) -> bool {
+#ifdef KB_ABL_NO_DMA
+            return false;
+#endif
+            if (e >= n_next) return false;
+            const int64_t o = n_org[e];
+            if (o < 0) return false;
+            n_base = tile_base + o;
+            load_slab<BYTES>(a, sl, n_base, n_plan.slab_bytes, regs);
+            return true;
+        };
+        auto next_write = [&](int e) {
+#ifdef KB_ABL_NO_WRITE
+            asm volatile("" ::"v"(regs.v[0]), "v"(regs.v[1]), "v"(regs.v[2]));
+            return;
+#endif
+            write_slab(nb + e * n_plan.slab_bytes, n_plan.slab_bytes, regs);
+            if (n_plan.slab_bytes > LDS_SLOTS * 4096) {  // uniform, rare
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+                copy_slab_tail<BYTES>(a, sl, n_base, n_plan.slab_bytes, nb + e * n_plan.slab_bytes, regs);
+            }
+        };
 
         const ConstIntPtr offs = as_const_ints(a.lds_off + ((size_t)chunk * T + t0) * C);  // offsets for 8-byte pairs
         const char* cb = smem + buf * LDS_GROUP_BYTES + lane_b;
@@ -821,12 +892,26 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const int off = (BYTES == 8) ? o[c] : (o[c] >> 3) * BYTES;
+#ifdef KB_ABL_NO_LDSREAD
+                if constexpr (CANON) {
+                    raw[c] = make_float2(__int_as_float(off + tc.lane), 1.0f);
+                    continue;
+                }
+#endif
                 raw[c] = *reinterpret_cast<const typename R::type*>(cb + e * plan.slab_bytes + off);
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 if constexpr (CANON) {
+#ifdef KB_ABL_SCALAR_ADD
+                    float ax = acc[c].x, ay = acc[c].y;
+                    ax += raw[c].x;
+                    asm volatile("" : "+v"(ax));
+                    ay += raw[c].y;
+                    acc[c] = PairF{ax, ay};
+#else
                     acc[c] += PairF{raw[c].x, raw[c].y};
+#endif
                     if (!FAST) cnt[c] += (__float_as_uint(raw[c].y) != 0x80000000u) ? 1 : 0;
                 } else {
                     float psi, phi;
@@ -844,13 +929,32 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #ifdef KB_ABL_NO_SUM
         if (false) {
 #else
+        // Keeps the epoch's sums in front of the LDS writes of the staged slab: left alone the compiler
+        // sinks the adds behind the writes, whose vmcnt(0) then waits out the loads with nothing to overlap.
+        auto pin_sums = [&]() {
+            static_assert(C == 8, "operand list below");
+            asm volatile(""
+                         : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                           "+v"(acc[7]), "+v"(cnt[0]), "+v"(cnt[1]), "+v"(cnt[2]), "+v"(cnt[3]), "+v"(cnt[4]), "+v"(cnt[5]),
+                           "+v"(cnt[6]), "+v"(cnt[7])
+                         :
+                         : "memory");
+        };
         if (FAST || plan.clean) {
 #endif
             for (int e = 0; e < n_cur; ++e) {
-                int o[C];
+                int o[C];  // fetched before the slab origin, so that one wait covers both scalar loads
 #pragma unroll
+#ifdef KB_ABL_ZERO_OFF
+                for (int c = 0; c < C; ++c) o[c] = 8 * c;
+#else
                 for (int c = 0; c < C; ++c) o[c] = offs[e * C + c];
+#endif
+                const bool staging = next_load(e);
                 sum_epoch(o, e);
+                pin_sums();
+                if (staging) next_write(e);
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             }
         } else {
 #ifdef KB_ABL_NO_SUM
@@ -858,6 +962,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #else
             for (int e = 0; e < n_cur; ++e) {
 #endif
+                const bool staging = next_load(e);
                 int o[C];
 #pragma unroll
                 for (int c = 0; c < C; ++c) o[c] = offs[e * C + c];
@@ -870,7 +975,14 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     per_lane_epoch<C, SF, CANON>(a, tc, chunk, t0 + e, bw, plan.slab_bytes,
                                                  smem + buf * LDS_GROUP_BYTES + e * plan.slab_bytes, acc, cnt);
                 }
+                pin_sums();
+                if (staging) next_write(e);
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             }
+        }
+        for (int e = n_cur; e < n_next; ++e) {  // the next group holds more epochs than this one
+            if (next_load(e)) next_write(e);
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         }
 
         if (n_chunk != chunk) {  // chunk complete: likelihoods + top-K, while the next chunk's first group lands
@@ -890,8 +1002,9 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 cnt[c] = 0;
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next group's DMA has landed
+#ifndef KB_ABL_NO_BARRIER
         __syncthreads();
+#endif
         buf = 1 - buf;
         chunk = n_chunk;
         t0 = n_t0;
@@ -912,12 +1025,12 @@ __global__ __launch_bounds__(LDS_BLOCK, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void
     SigmaGScratch<WAVE> scratch = {};
     if constexpr (SIGMAG) scratch = make_scratch(a, tc);
 
-    DmaLane dl;
+    StageLane sl;
 #pragma unroll
-    for (int j = 0; j < LDS_DMA_SLOTS; ++j) {
+    for (int j = 0; j < LDS_SLOTS; ++j) {
         const int p = 16 * ((int)threadIdx.x + 256 * j) / BYTES;  // first pixel of this thread's 16 bytes
         const int r = p / LDS_COLS, c = p - r * LDS_COLS;
-        dl.goff[j] = (uint32_t)(r * a.Wp + c) * (uint32_t)BYTES;
+        sl.goff[j] = (uint32_t)(r * a.Wp + c) * (uint32_t)BYTES;
     }
 
     // Workgroup-uniform: can any sample of this tile be NO_DATA?
@@ -926,9 +1039,9 @@ __global__ __launch_bounds__(LDS_BLOCK, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void
                       (tc.tile_x0 + WAVE + gb[1] <= a.W) && (tc.tile_y0 + gb[2] >= 0) &&
                       (tc.tile_y0 + TILE_ROWS + gb[3] <= a.H);
     if (fast) {
-        lds_search_tile<KS, C, NB, CANON, SIGMAG, true>(a, tc, smem, dl, top, scratch);
+        lds_search_tile<KS, C, NB, CANON, SIGMAG, true>(a, tc, smem, sl, top, scratch);
     } else {
-        lds_search_tile<KS, C, NB, CANON, SIGMAG, false>(a, tc, smem, dl, top, scratch);
+        lds_search_tile<KS, C, NB, CANON, SIGMAG, false>(a, tc, smem, sl, top, scratch);
     }
     write_results<KS, SIGMAG>(a, tc, top, scratch);
 }
@@ -1229,6 +1342,7 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
     a.boxes = nullptr;
     a.lds_off = nullptr;
     a.global_box = nullptr;
+    a.origins = nullptr;
     a.padded = nullptr;
     a.Wp = a.Hp = a.px0 = a.py0 = 0;
     a.n_invalid = nullptr;
@@ -1251,18 +1365,21 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
         const size_t table_bytes = (size_t)a.n_chunks * a.T * CHUNK * sizeof(int2);
         const size_t off_bytes = ((size_t)a.n_chunks * a.T * CHUNK + 4 * CHUNK) * sizeof(int);  // + prefetch slack
         const size_t box_bytes = (size_t)a.n_chunks * a.T * sizeof(EpochBox);
+        const size_t org_bytes = (size_t)a.n_chunks * a.T * sizeof(int64_t);
         const size_t chunk_bytes = (size_t)a.n_chunks * sizeof(ChunkInfo);
         // NO_DATA pixel counter [1], unstaged (chunk, epoch) counter [1], staged shift box + tallest slab [5],
         // per-lane (chunk, epoch) counter [1]
         const size_t inv_bytes = 8 * sizeof(int);
         void* ws = nullptr;
-        if (ensure_workspace(0, table_bytes + off_bytes + box_bytes + chunk_bytes + inv_bytes, &ws)) return 1;
+        if (ensure_workspace(0, table_bytes + off_bytes + box_bytes + chunk_bytes + inv_bytes + org_bytes, &ws)) return 1;
         char* wsc = reinterpret_cast<char*>(ws);
         a.table = reinterpret_cast<const int2*>(wsc);
         a.lds_off = reinterpret_cast<const int*>(wsc + table_bytes);
         a.boxes = reinterpret_cast<const EpochBox*>(wsc + table_bytes + off_bytes);
         a.chunks = reinterpret_cast<const ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes);
         int* inv = reinterpret_cast<int*>(wsc + table_bytes + off_bytes + box_bytes + chunk_bytes);
+        int64_t* origins = reinterpret_cast<int64_t*>(wsc + table_bytes + off_bytes + box_bytes + chunk_bytes + inv_bytes);
+        a.origins = origins;
         int* n_invalid = inv;
         int* n_not_lds = inv + 1;
         int* gbox = inv + 2;
@@ -1297,8 +1414,12 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
                 const int64_t y_lo = (int64_t)params.y_start_min + back[3];
                 const int64_t y_hi =
                         (int64_t)params.y_start_min + (int64_t)TILE_ROWS * (a.tiles_y - 1) + back[4] + back[5];
-                const int64_t px0 = std::max<int64_t>(0, -x_lo), py0 = std::max<int64_t>(0, -y_lo);
-                const int64_t Wp = px0 + std::max<int64_t>(a.W, x_hi), Hp = py0 + std::max<int64_t>(a.H, y_hi);
+                int64_t px0 = std::max<int64_t>(0, -x_lo), py0 = std::max<int64_t>(0, -y_lo);
+                // slab alignment (kb_shift_table_kernel): x_start_min + px0 is a multiple of LDS_ALIGN_PX,
+                // the row pitch a multiple of 16 pixels
+                px0 += (((-(px0 + (int64_t)params.x_start_min)) % LDS_ALIGN_PX) + LDS_ALIGN_PX) % LDS_ALIGN_PX;
+                int64_t Wp = px0 + std::max<int64_t>(a.W, x_hi), Hp = py0 + std::max<int64_t>(a.H, y_hi);
+                Wp = (Wp + 15) / 16 * 16;
                 const uint64_t frame = (uint64_t)a.T * (uint64_t)Hp * (uint64_t)Wp;
                 const uint64_t image = (uint64_t)a.T * (uint64_t)a.H * (uint64_t)a.W;
                 // Canonical floats unless the caller keeps the array encoded or HBM is short.
@@ -1323,6 +1444,10 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
                     // bit 5 (debug): never take the count-free specialisation
                     a.all_staged = (back[0] == 0 && back[6] == 0 && (flags & 32u) == 0) ? 1 : 0;
                     launch_pad(a, canon, padded, n_invalid, stream);
+                    KB_HIP_TRY(hipGetLastError());
+                    const int64_t n_org = (int64_t)a.n_chunks * a.T;
+                    hipLaunchKernelGGL(kb_slab_origin_kernel, dim3((unsigned)((n_org + 255) / 256)), dim3(256), 0, stream,
+                                       a.boxes, n_org, a.T, a.Hp, a.Wp, a.px0, a.py0, (int)pair_bytes, origins);
                     KB_HIP_TRY(hipGetLastError());
                     which = canon ? 2 : 1;
                 }
