@@ -91,6 +91,11 @@ def main():
     ap.add_argument("--max-ang", type=float, default=1.5)
     ap.add_argument("--inset", type=int, default=0, help="shrink the start-pixel grid by this many pixels per side")
     ap.add_argument("--flags", type=int, default=0, help="kb_device_search_filter flags (1 exact positions, 4 LDS-staged kernel)")
+    ap.add_argument("--sigmag", action="store_true",
+                    help="BASELINE configs[2]: in-kernel sigma-G ([25, 75] percentiles, coeff 0.7413, min_lh 10), min_obs T/2")
+    ap.add_argument("--verify", action="store_true",
+                    help="after timing: size-independent checks of the last result buffer (both kernels agree bit for "
+                         "bit, per-pixel lists sorted, a start window re-done with exact per-lane positions agrees)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the CPU baseline sample")
     args = ap.parse_args()
@@ -163,8 +168,11 @@ def main():
     ins = args.inset
     S = (H - 2 * ins) * (W - 2 * ins)
     results = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
-    params = Params(0, 0.0, 0, 0.25, 0.75, -1.0, -1 if args.num_bytes in (-1, 4) else args.num_bytes, ins, W - ins, ins,
-                    H - ins, K, 0)
+    nb_param = -1 if args.num_bytes in (-1, 4) else args.num_bytes
+    if args.sigmag:
+        params = Params(T // 2, 10.0, 1, 0.25, 0.75, 0.7413, nb_param, ins, W - ins, ins, H - ins, K, 0)
+    else:
+        params = Params(0, 0.0, 0, 0.25, 0.75, -1.0, nb_param, ins, W - ins, ins, H - ins, K, 0)
     gathered = torch.empty((world, S * K, 7), dtype=torch.float32, device=dev) if world > 1 else None
     merged = torch.empty((S * K, 7), dtype=torch.float32, device=dev) if world > 1 else None
 
@@ -223,8 +231,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{T}x{H}x{W} psi/phi ({'float32' if args.num_bytes in (-1, 4) else 'uint%d' % (8 * args.num_bytes)}), "
-                        f"full {W}x{H} start grid x {n_local} (v,theta) candidates per GPU, K=8, sigma-G off "
-                        "(BASELINE configs[1])",
+                        f"full {W}x{H} start grid x {n_local} (v,theta) candidates per GPU, K=8, "
+                        f"sigma-G {'on, min_obs %d' % (T // 2) if args.sigmag else 'off'}",
             "frames": T, "height": H, "width": W, "candidates_per_gpu": n_local, "results_per_pixel": K,
             "sharding": "candidates (v,theta) by rank; psi/phi replicated; one RCCL all_gather + per-pixel merge"
                         if world > 1 else "none",
@@ -256,14 +264,55 @@ def main():
     except (OSError, ValueError):
         pass
 
+    if args.verify and world == 1:
+        out["verify"] = verify(lib, torch, meta, arr, times, params, cands, n_local, results, S, K, ins, W, H, last, stream)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lib, meta, arr, tcpu, vx[sl], vy[sl], args.cpu_seconds)
 
     if rank == 0:
         print(json.dumps(out))
     lib.kb_free_gpu_block(arr)
+    if args.verify and world == 1 and not all(v for k, v in out["verify"].items() if k.endswith("_ok")):
+        sys.exit(3)
     if world > 1:
         dist.destroy_process_group()
+
+
+def verify(lib, torch, meta, arr, times, params, cands, n_cands, results, S, K, ins, W, H, last, stream):
+    """Size-independent checks of one finished search (results = its buffer, on the device)."""
+    dev = results.device
+    sw = W - 2 * ins
+
+    def run(p, n_slots, flags):
+        buf = torch.empty((n_slots, 7), dtype=torch.float32, device=dev)
+        st = Stats()
+        check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), p, cands.data_ptr(), n_cands,
+                                               buf.data_ptr(), n_slots, flags, stream, C.byref(st)))
+        torch.cuda.synchronize()
+        return buf, st
+
+    out = {}
+    # 1. the other kernel, same search, bit for bit
+    was_lds = int(last.kernel_variant) // 10000 != 0
+    other, st = run(params, S * K, 2 if was_lds else 4)
+    out["other_kernel"] = "kb_search_direct" if int(st.kernel_variant) // 10000 == 0 else "kb_search_lds"
+    out["kernels_agree_ok"] = bool(torch.equal(results.view(torch.int32), other.view(torch.int32)))
+    del other
+    # 2. every per-pixel list is in descending likelihood order (the swap-down insertion's invariant)
+    lh = results[:, 2].view(S, K)
+    out["lists_sorted_ok"] = bool((lh[:, :-1] >= lh[:, 1:]).all().item())
+    # 3. a start window re-done with exact per-lane positions (no shift table, no staging) gives the same slots
+    x0 = ins + max(0, (sw - 96) // 2)
+    y0 = ins + max(0, (H - 2 * ins - 8) // 2)
+    x1, y1 = min(x0 + 96, W - ins), min(y0 + 8, H - ins)
+    wp = Params.from_buffer_copy(params)
+    wp.x_start_min, wp.x_start_max, wp.y_start_min, wp.y_start_max = x0, x1, y0, y1
+    win, _ = run(wp, (x1 - x0) * (y1 - y0) * K, 1)
+    full = results.view(H - 2 * ins, sw, K, 7)[y0 - ins:y1 - ins, x0 - ins:x1 - ins].reshape(-1, 7)
+    out["exact_window"] = [x0, x1, y0, y1]
+    out["exact_window_ok"] = bool(torch.equal(full.contiguous().view(torch.int32), win.view(torch.int32)))
+    return out
 
 
 def cpu_baseline(lib, meta, arr, times, vx, vy, target_s):
