@@ -144,6 +144,18 @@ int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t n, float m
 int kb_psi_phi_curves(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
                       const kb_trajectory* trjs_dev, uint64_t n, float* out_dev, void* stream);
 
+/* ---- batched sigma-G clipping of likelihood curves (SigmaGClipping.compute_clipped_sigma_g_matrix,
+ * src/kbmod/filters/sigma_g_filter.py:114-168; the step after get_all_psi_phi_curves in
+ * SearchRunner.load_and_filter_results, run_search.py:251-337).  lh: [n_rows][n_cols] float32 (NaN =
+ * masked point); valid: [n_rows][n_cols] bytes, 1 = inside median -+ n_sigma * coeff * (q_high - q_low),
+ * quantiles by linear interpolation over the non-NaN (and, with clip_negative, positive) points.
+ * low_pct / high_pct on the reference's [0, 100] scale; n_cols <= 4096.  Synchronises the stream. */
+int kb_sigma_g_clip_matrix(const float* lh_dev, uint64_t n_rows, int32_t n_cols, float low_pct, float high_pct,
+                           float n_sigma, float coeff, int32_t clip_negative, uint8_t* valid_dev, void* stream);
+/* same on host buffers (upload, clip, download) */
+int kb_sigma_g_clip_matrix_host(const float* lh_host, uint64_t n_rows, int32_t n_cols, float low_pct, float high_pct,
+                                float n_sigma, float coeff, int32_t clip_negative, uint8_t* valid_host);
+
 /* ---- multi-GPU: merge of per-rank top-K lists (new; the reference is single-GPU).
  * lists_dev: [n_lists][n_pixels][K] as gathered by one RCCL all_gather of each
  * rank's kb_device_search_filter output over its candidate slice; out_dev:

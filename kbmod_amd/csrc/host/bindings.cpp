@@ -308,6 +308,23 @@ PYBIND11_MODULE(search, m) {
         return res;
     });
 
+    // ---- batched sigma-G clipping on the device (filters/sigma_g_filter.py:114-168) ----
+    m.def(
+            "sigma_g_clip_matrix",
+            [](py::array_t<float, py::array::c_style | py::array::forcecast> lh, float low_bnd, float high_bnd,
+               float n_sigma, float coeff, bool clip_negative) {
+                if (lh.ndim() != 2) throw std::runtime_error("sigma_g_clip_matrix: expected an N x T matrix");
+                py::array_t<bool> valid({lh.shape(0), lh.shape(1)});
+                if (kb_sigma_g_clip_matrix_host(lh.data(), (uint64_t)lh.shape(0), (int32_t)lh.shape(1), low_bnd, high_bnd,
+                                                n_sigma, coeff, clip_negative ? 1 : 0,
+                                                reinterpret_cast<uint8_t*>(valid.mutable_data())) != 0) {
+                    throw std::runtime_error(kb_last_error());
+                }
+                return valid;
+            },
+            py::arg("lh"), py::arg("low_bnd") = 25.0f, py::arg("high_bnd") = 75.0f, py::arg("n_sigma") = 2.0f,
+            py::arg("coeff") = 0.7413f, py::arg("clip_negative") = false);
+
     // ---- cpu_search_algorithms.cpp:128-131 ----
     m.def("evaluate_trajectory_cpu", &evaluate_trajectory_cpu);
     m.def("search_cpu_only", &search_cpu_only);

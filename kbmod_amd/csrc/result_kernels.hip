@@ -8,6 +8,7 @@
 // reference's unstable sort may produce); the kernels around them are ours.
 #include <algorithm>
 #include <cstring>
+#include <string>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
@@ -94,6 +95,90 @@ struct Scratch {
     }
 };
 
+
+// ---------------------------------------------------------------------------
+// batched sigma-G clipping of likelihood curves
+// ---------------------------------------------------------------------------
+// SigmaGClipping.compute_clipped_sigma_g_matrix (src/kbmod/filters/sigma_g_filter.py:114-168):
+// per row the [low, 50, high] percentiles by torch.nanquantile's linear interpolation in float32
+// (sort with NaN last, rank = q * (n_valid - 1), lerp), delta = max(high - low, 1e-5),
+// bounds = median -+ n_sigma * coeff * delta, valid = isfinite(lh) && lower < lh < upper.
+// One wavefront per row; the row is sorted as order-preserving 32-bit keys in LDS (bitonic).
+constexpr int CLIP_ROWS_PER_BLOCK = 4;
+
+__device__ __forceinline__ uint32_t float_sort_key(float v) {
+    if (v != v) return 0xffffffffu;  // NaN after everything, +inf included
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    if (k == 0xffffffffu) return __uint_as_float(0x7fc00000u);
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// ATen native/Lerp.h, scalar form, float32, separately rounded operations
+__device__ __forceinline__ float lerp_aten(float a, float b, float w) {
+    const float d = b - a;
+    return (w < 0.5f) ? a + w * d : b - d * (1.0f - w);
+}
+
+__global__ __launch_bounds__(CLIP_ROWS_PER_BLOCK* WAVE) void kb_sigma_g_clip_kernel(
+        const float* __restrict__ lh, uint64_t n_rows, int n_cols, int P, float q_low, float q_high, float scale,
+        int clip_negative, uint8_t* __restrict__ valid) {
+    extern __shared__ uint32_t keys_all[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = threadIdx.x / WAVE;
+    const uint64_t row = (uint64_t)blockIdx.x * CLIP_ROWS_PER_BLOCK + wv;
+    uint32_t* keys = keys_all + (size_t)wv * P;
+    const bool active = row < n_rows;  // whole wave
+    const float* src = lh + (active ? row : 0) * (uint64_t)n_cols;
+
+    int n_valid = 0;
+    for (int i = lane; i < P; i += WAVE) {
+        float v = (active && i < n_cols) ? src[i] : __uint_as_float(0x7fc00000u);
+        if (clip_negative && !(v > 0.0f)) v = __uint_as_float(0x7fc00000u);  // torch.where(lh > 0, lh, nan)
+        n_valid += (v == v) ? 1 : 0;
+        keys[i] = float_sort_key(v);
+    }
+    for (int o = WAVE / 2; o > 0; o >>= 1) n_valid += __shfl_xor(n_valid, o);
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < P; i += WAVE) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const uint32_t a = keys[i], b = keys[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        keys[i] = b;
+                        keys[p] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!active) return;
+    float quant[3];
+    const float qs[3] = {q_low, 0.5f, q_high};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float rank = qs[i] * (float)(n_valid - 1);
+        if (rank < 0.0f) rank = 0.0f;
+        const float below = floorf(rank);
+        const int ib = (int)below, ia = (int)ceilf(rank);
+        quant[i] = lerp_aten(key_to_float(keys[ib]), key_to_float(keys[ia]), rank - below);
+    }
+    float delta = quant[2] - quant[0];
+    if (delta < 1e-5f) delta = 1e-5f;
+    const float n_sigma_g = scale * delta;
+    const float lower = quant[1] - n_sigma_g, upper = quant[1] + n_sigma_g;
+    uint8_t* dst = valid + row * (uint64_t)n_cols;
+    for (int i = lane; i < n_cols; i += WAVE) {
+        const float v = src[i];
+        dst[i] = (__builtin_isfinite(v) && v < upper && v > lower) ? 1 : 0;
+    }
+}
+
 }  // namespace kb
 
 extern "C" int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs,
@@ -168,4 +253,62 @@ extern "C" int kb_psi_phi_curves(const kb_psi_phi_meta* meta, const void* psi_ph
     KB_HIP_TRY(hipGetLastError());
     KB_HIP_TRY(hipStreamSynchronize(stream));
     return 0;
+}
+
+extern "C" int kb_sigma_g_clip_matrix(const float* lh_dev, uint64_t n_rows, int32_t n_cols, float low_pct, float high_pct,
+                                      float n_sigma, float coeff, int32_t clip_negative, uint8_t* valid_dev,
+                                      void* stream_v) {
+    using namespace kb;
+    if (n_rows == 0 || n_cols == 0) return 0;
+    if (lh_dev == nullptr || valid_dev == nullptr) return fail("sigma_g_clip_matrix: null pointer");
+    if (n_cols < 0 || n_cols > 4096) return fail("sigma_g_clip_matrix: curves longer than 4096 points are not supported");
+    if (!(low_pct > 0.0f) || !(high_pct < 100.0f) || low_pct > high_pct) {  // sigma_g_filter.py:38-39
+        return fail("Invalid bounds [" + std::to_string(low_pct) + ", " + std::to_string(high_pct) + "]");
+    }
+    if (!(n_sigma > 0.0f)) return fail("Invalid n_sigma " + std::to_string(n_sigma));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    int P = 1;
+    while (P < n_cols) P <<= 1;
+    if (P < 2) P = 2;
+    const uint64_t blocks = (n_rows + CLIP_ROWS_PER_BLOCK - 1) / CLIP_ROWS_PER_BLOCK;
+    if (blocks > 0x7fffffffull) return fail("sigma_g_clip_matrix: too many rows for one launch");
+    // the reference forms n_sigma * coeff in double and multiplies the float32 tensor by it
+    const float scale = (float)((double)n_sigma * (double)coeff);
+    hipLaunchKernelGGL(kb_sigma_g_clip_kernel, dim3((unsigned)blocks), dim3(CLIP_ROWS_PER_BLOCK * WAVE),
+                       (size_t)CLIP_ROWS_PER_BLOCK * P * sizeof(uint32_t), stream, lh_dev, n_rows, (int)n_cols, P,
+                       low_pct / 100.0f, high_pct / 100.0f, scale, (int)clip_negative, valid_dev);
+    KB_HIP_TRY(hipGetLastError());
+    KB_HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+extern "C" int kb_sigma_g_clip_matrix_host(const float* lh_host, uint64_t n_rows, int32_t n_cols, float low_pct,
+                                           float high_pct, float n_sigma, float coeff, int32_t clip_negative,
+                                           uint8_t* valid_host) {
+    using namespace kb;
+    if (n_rows == 0 || n_cols == 0) return 0;
+    if (lh_host == nullptr || valid_host == nullptr) return fail("sigma_g_clip_matrix: null pointer");
+    if (kb_device_count() == 0) return fail("GPU is not available for sigma-G clipping.");
+    const uint64_t n = n_rows * (uint64_t)n_cols;
+    float* lh_dev = nullptr;
+    uint8_t* valid_dev = nullptr;
+    KB_HIP_TRY(hipMalloc(&lh_dev, n * sizeof(float)));
+    if (hipMalloc(&valid_dev, n) != hipSuccess) {
+        (void)hipFree(lh_dev);
+        return fail("sigma_g_clip_matrix: out of device memory");
+    }
+    int rc = 0;
+    if (hipMemcpy(lh_dev, lh_host, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        rc = fail("sigma_g_clip_matrix: upload failed");
+    }
+    if (rc == 0) {
+        rc = kb_sigma_g_clip_matrix(lh_dev, n_rows, n_cols, low_pct, high_pct, n_sigma, coeff, clip_negative, valid_dev,
+                                    nullptr);
+    }
+    if (rc == 0 && hipMemcpy(valid_host, valid_dev, n, hipMemcpyDeviceToHost) != hipSuccess) {
+        rc = fail("sigma_g_clip_matrix: download failed");
+    }
+    (void)hipFree(lh_dev);
+    (void)hipFree(valid_dev);
+    return rc;
 }
