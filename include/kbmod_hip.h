@@ -156,6 +156,18 @@ int kb_sigma_g_clip_matrix(const float* lh_dev, uint64_t n_rows, int32_t n_cols,
 int kb_sigma_g_clip_matrix_host(const float* lh_host, uint64_t n_rows, int32_t n_cols, float low_pct, float high_pct,
                                 float n_sigma, float coeff, int32_t clip_negative, uint8_t* valid_host);
 
+/* ---- stamp coadds of result trajectories (append_coadds, src/kbmod/filters/stamp_filters.py:72-168:
+ * extract_stamp_stack + coadd_sum / coadd_mean / coadd_median / coadd_weighted of
+ * src/kbmod/core/stamp_utils.py:16-84, 241-344, 352-397).  sci_dev / var_dev: [T][H][W] float32 image
+ * stacks in HBM (var_dev only for KB_COADD_WEIGHTED); x_dev / y_dev: [n][T] integer stamp centres
+ * (predict_pixel_locations, trajectory_utils.py:28-75); include_dev: [n][T] bytes, 0 = epoch not used
+ * (obs_valid), or NULL for all epochs; out_dev: [n][2r+1][2r+1] float32.  Accumulates in double in
+ * epoch order like the reference and rounds once.  Synchronises the stream. */
+enum { KB_COADD_SUM = 0, KB_COADD_MEAN = 1, KB_COADD_MEDIAN = 2, KB_COADD_WEIGHTED = 3 };
+int kb_coadd_stamps(const float* sci_dev, const float* var_dev, int32_t num_times, int32_t height, int32_t width,
+                    const int32_t* x_dev, const int32_t* y_dev, const uint8_t* include_dev, uint64_t n, int32_t radius,
+                    int32_t coadd_type, float* out_dev, void* stream);
+
 /* ---- multi-GPU: merge of per-rank top-K lists (new; the reference is single-GPU).
  * lists_dev: [n_lists][n_pixels][K] as gathered by one RCCL all_gather of each
  * rank's kb_device_search_filter output over its candidate slice; out_dev:

@@ -12,6 +12,7 @@
 #include "image_utils.h"
 #include "psi_phi_array.h"
 #include "stack_search.h"
+#include "device_stack.h"
 #include "trajectory_list.h"
 
 namespace py = pybind11;
@@ -307,6 +308,16 @@ PYBIND11_MODULE(search, m) {
         if (!out.empty()) std::memcpy(res.mutable_data(), out.data(), out.size() * sizeof(Trajectory));
         return res;
     });
+
+    // ---- stamp coadds on the device (filters/stamp_filters.py:72-168, core/stamp_utils.py) ----
+    py::class_<DeviceImageStack>(m, "DeviceImageStack")
+            .def(py::init<DeviceImageStack::FloatArray, py::object>(), py::arg("sci"), py::arg("var") = py::none())
+            .def_property_readonly("num_times", &DeviceImageStack::num_times)
+            .def_property_readonly("height", &DeviceImageStack::height)
+            .def_property_readonly("width", &DeviceImageStack::width)
+            .def_property_readonly("has_variance", &DeviceImageStack::has_variance)
+            .def("coadds", &DeviceImageStack::coadds, py::arg("xvals"), py::arg("yvals"), py::arg("to_include") = py::none(),
+                 py::arg("radius") = 10, py::arg("coadd_types") = std::vector<std::string>{"mean"});
 
     // ---- batched sigma-G clipping on the device (filters/sigma_g_filter.py:114-168) ----
     m.def(

@@ -1,0 +1,136 @@
+// Science / variance image stack resident in HBM for the post-search stages that read pixels at
+// trajectory positions (stamp coadds: src/kbmod/filters/stamp_filters.py:72-168 over
+// ImageStackPy.sci / .var).  Not part of the reference's compiled module: the reference does this
+// stage on the host, one trajectory at a time.
+#ifndef KB_HOST_DEVICE_STACK_H_
+#define KB_HOST_DEVICE_STACK_H_
+
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kbmod_hip.h"
+
+namespace search {
+namespace py = pybind11;
+
+class DeviceImageStack {
+public:
+    typedef py::array_t<float, py::array::c_style | py::array::forcecast> FloatArray;
+    typedef py::array_t<int32_t, py::array::c_style | py::array::forcecast> IntArray;
+
+    // sci / var: T x H x W arrays (or lists of T H x W arrays); var may be None
+    DeviceImageStack(FloatArray sci, py::object var) {
+        if (kb_device_count() == 0) throw std::runtime_error("GPU is not available for the image stack.");
+        if (sci.ndim() != 3) throw std::runtime_error("expected a T x H x W science stack");
+        T_ = (int)sci.shape(0);
+        H_ = (int)sci.shape(1);
+        W_ = (int)sci.shape(2);
+        sci_ = upload(sci.data(), (uint64_t)sci.size() * sizeof(float));
+        if (!var.is_none()) {
+            FloatArray v = var.cast<FloatArray>();
+            if (v.ndim() != 3 || v.shape(0) != sci.shape(0) || v.shape(1) != sci.shape(1) || v.shape(2) != sci.shape(2)) {
+                release();
+                throw std::runtime_error("science and variance stacks differ in shape");
+            }
+            var_ = upload(v.data(), (uint64_t)v.size() * sizeof(float));
+        }
+    }
+    DeviceImageStack(const DeviceImageStack&) = delete;
+    DeviceImageStack& operator=(const DeviceImageStack&) = delete;
+    ~DeviceImageStack() { release(); }
+
+    int num_times() const { return T_; }
+    int height() const { return H_; }
+    int width() const { return W_; }
+    bool has_variance() const { return var_ != nullptr; }
+
+    // xvals / yvals: N x T integer stamp centres; to_include: N x T bool (None = every epoch);
+    // returns {type: N x (2r+1) x (2r+1) float32}
+    std::map<std::string, py::array_t<float>> coadds(IntArray xvals, IntArray yvals, py::object to_include, int radius,
+                                                     const std::vector<std::string>& coadd_types) {
+        if (radius <= 0) throw std::invalid_argument("Invalid stamp radius " + std::to_string(radius));
+        if (xvals.ndim() != 2 || yvals.ndim() != 2 || xvals.shape(0) != yvals.shape(0) || xvals.shape(1) != T_ ||
+            yvals.shape(1) != T_) {
+            throw std::invalid_argument("X and Y values must have the same length as the number of times.");
+        }
+        const uint64_t n = (uint64_t)xvals.shape(0);
+        const uint64_t nt = n * (uint64_t)T_;
+        const int S = 2 * radius + 1;
+        std::map<std::string, py::array_t<float>> out;
+        std::vector<int> types;
+        for (const std::string& c : coadd_types) {
+            if (c == "sum") types.push_back(KB_COADD_SUM);
+            else if (c == "mean") types.push_back(KB_COADD_MEAN);
+            else if (c == "median") types.push_back(KB_COADD_MEDIAN);
+            else if (c == "weighted") types.push_back(KB_COADD_WEIGHTED);
+            else throw std::invalid_argument("Unknown coadd type " + c);
+            if (c == "weighted" && var_ == nullptr) throw std::runtime_error("the weighted coadd needs the variance stack");
+        }
+        for (const std::string& c : coadd_types) {
+            out[c] = py::array_t<float>({(py::ssize_t)n, (py::ssize_t)S, (py::ssize_t)S});
+        }
+        if (n == 0 || types.empty()) return out;
+        py::array_t<uint8_t, py::array::c_style | py::array::forcecast> inc;
+        if (!to_include.is_none()) {
+            inc = to_include.cast<py::array_t<bool>>().cast<py::array_t<uint8_t, py::array::c_style | py::array::forcecast>>();
+            if (inc.ndim() != 2 || (uint64_t)inc.shape(0) != n || inc.shape(1) != T_) {
+                throw std::invalid_argument("Time mask must have the same length as the number of times.");
+            }
+        }
+        void *x_dev = nullptr, *y_dev = nullptr, *inc_dev = nullptr, *out_dev = nullptr;
+        auto cleanup = [&]() {
+            if (x_dev) kb_free_gpu_block(x_dev);
+            if (y_dev) kb_free_gpu_block(y_dev);
+            if (inc_dev) kb_free_gpu_block(inc_dev);
+            if (out_dev) kb_free_gpu_block(out_dev);
+        };
+        try {
+            x_dev = upload(xvals.data(), nt * sizeof(int32_t));
+            y_dev = upload(yvals.data(), nt * sizeof(int32_t));
+            if (!to_include.is_none()) inc_dev = upload(inc.data(), nt);
+            const uint64_t out_bytes = n * (uint64_t)S * S * sizeof(float);
+            check(kb_allocate_gpu_block(out_bytes, &out_dev));
+            for (size_t k = 0; k < types.size(); ++k) {
+                check(kb_coadd_stamps(sci_, var_, T_, H_, W_, (const int32_t*)x_dev, (const int32_t*)y_dev,
+                                      (const uint8_t*)inc_dev, n, radius, types[k], (float*)out_dev, nullptr));
+                check(kb_copy_block_to_cpu(out[coadd_types[k]].mutable_data(), out_dev, out_bytes));
+            }
+        } catch (...) {
+            cleanup();
+            throw;
+        }
+        cleanup();
+        return out;
+    }
+
+private:
+    static void check(int rc) {
+        if (rc != 0) throw std::runtime_error(kb_last_error());
+    }
+    static float* upload(const void* host, uint64_t bytes) {
+        void* dev = nullptr;
+        check(kb_allocate_gpu_block(bytes == 0 ? 4 : bytes, &dev));
+        if (bytes != 0 && kb_copy_block_to_gpu(host, dev, bytes) != 0) {
+            kb_free_gpu_block(dev);
+            throw std::runtime_error(kb_last_error());
+        }
+        return (float*)dev;
+    }
+    void release() {
+        if (sci_) kb_free_gpu_block(sci_);
+        if (var_) kb_free_gpu_block(var_);
+        sci_ = var_ = nullptr;
+    }
+    float* sci_ = nullptr;
+    float* var_ = nullptr;
+    int T_ = 0, H_ = 0, W_ = 0;
+};
+
+}  // namespace search
+#endif

@@ -106,3 +106,182 @@ def likelihood_curves(psi, phi, obs_valid=None, mask_value=0.0):
     out = np.full(psi.shape, mask_value, dtype=np.float32)
     out[valid] = psi[valid] / np.sqrt(phi[valid])
     return out
+
+
+# ---------------------------------------------------------------------------
+# stamps and coadds: src/kbmod/core/stamp_utils.py
+# ---------------------------------------------------------------------------
+# Pinned by the reference's known answers (tests/test_stamp_utils.py:20-273).  coadd_median delegates
+# to the third-party torch.nanmedian (PyTorch 2.10): per pixel the LOWER median of the non-NaN values
+# (index (n - 1) // 2 of the ascending order); checked against torch itself in
+# tests/test_oracle_stamps.py.
+
+
+def predict_pixel_locations(times, x0, vx, centered=True, as_int=True):
+    """src/kbmod/trajectory_utils.py:28-75 (truncation toward zero, not floor)."""
+    times, x0, vx = np.asarray(times), np.asarray(x0), np.asarray(vx)
+    if len(x0) != len(vx):
+        raise ValueError(f"x0 and vx must be same size. Found {len(x0)} vs {len(vx)}")
+    pos = vx[:, np.newaxis] * times[np.newaxis, :] + x0[:, np.newaxis]
+    if centered:
+        pos = pos + 0.5
+    if as_int:
+        pos = pos.astype(int)
+    return pos
+
+
+def extract_stamp(img, x_val, y_val, radius):
+    """stamp_utils.py:352-397: float64, NaN where there is no data."""
+    h, w = img.shape
+    s = 2 * radius + 1
+    stamp = np.full((s, s), np.nan)
+    for j in range(s):
+        yy = y_val - radius + j
+        if yy < 0 or yy >= h:
+            continue
+        for i in range(s):
+            xx = x_val - radius + i
+            if 0 <= xx < w:
+                stamp[j, i] = img[yy, xx]
+    return stamp
+
+
+def extract_stamp_stack(imgs, x_vals, y_vals, radius, to_include=None):
+    """stamp_utils.py:16-84 for an array of images (mask or index list in to_include)."""
+    num_times = len(imgs)
+    if radius < 1:
+        raise ValueError("Radius must be at least 1.")
+    if len(x_vals) != num_times or len(y_vals) != num_times:
+        raise ValueError("X and Y values must have the same length as the number of times.")
+    mask = np.full(num_times, True)
+    if to_include is not None:
+        to_include = np.asarray(to_include)
+        if to_include.dtype == bool:
+            if len(to_include) != num_times:
+                raise ValueError("Time mask must have the same length as the number of times.")
+            mask = to_include
+        else:
+            mask = np.full(num_times, False)
+            mask[to_include] = True
+    s = 2 * radius + 1
+    if num_times == 0 or np.count_nonzero(mask) == 0:
+        return np.empty((0, s, s))
+    x_vals = np.asarray(x_vals, dtype=int)
+    y_vals = np.asarray(y_vals, dtype=int)
+    return np.array([extract_stamp(np.asarray(imgs[t]), x_vals[t], y_vals[t], radius) for t in range(num_times) if mask[t]])
+
+
+def extract_curve_values(imgs, x_vals, y_vals):
+    """stamp_utils.py:87-141, 478-512."""
+    num_times = len(imgs)
+    x_vals = np.asanyarray(x_vals, dtype=int)
+    y_vals = np.asanyarray(y_vals, dtype=int)
+    single = x_vals.ndim == 1
+    if single:
+        x_vals, y_vals = x_vals[np.newaxis, :], y_vals[np.newaxis, :]
+    if x_vals.shape[1] != num_times or y_vals.shape[1] != num_times:
+        raise ValueError(f"X and Y values must have the same length as times ({num_times}).")
+    h, w = np.asarray(imgs[0]).shape
+    values = np.full(x_vals.shape, np.nan)
+    for r in range(x_vals.shape[0]):
+        for t in range(num_times):
+            x_i, y_i = x_vals[r, t], y_vals[r, t]
+            if 0 <= x_i < w and 0 <= y_i < h:
+                values[r, t] = imgs[t][y_i, x_i]
+    return values.flatten() if single else values
+
+
+def _sequential_sum(a):
+    """np.add.reduce over axis 0 of a C-contiguous (T, H, W) array adds the slices one after the other
+    starting from slice 0 (no pairwise blocking across the reduced outer axis); restated explicitly."""
+    out = np.array(a[0], dtype=np.float64, copy=True)
+    for t in range(1, a.shape[0]):
+        out = out + a[t]
+    return out
+
+
+def _mask_all_nans(stack):
+    """stamp_utils.py:214-238."""
+    stack = np.asarray(stack)
+    none_valid = np.all(np.isnan(stack), axis=0)
+    if np.any(none_valid):
+        stack = stack.copy()
+        stack[:, none_valid] = 0.0
+    return stack
+
+
+def coadd_sum(stack):
+    """stamp_utils.py:241-255 (np.nansum)."""
+    stack = np.asarray(stack, dtype=np.float64)
+    if stack.shape[0] == 0:
+        return np.zeros(stack.shape[1:])
+    return _sequential_sum(np.where(np.isnan(stack), 0.0, stack))
+
+
+def coadd_mean(stack):
+    """stamp_utils.py:258-275 (np.nanmean after masking all-NaN pixels to 0)."""
+    stack = np.asarray(stack, dtype=np.float64)
+    if stack.shape[0] == 0:
+        return np.zeros(stack.shape[1:])
+    stack = _mask_all_nans(stack)
+    cnt = np.sum(~np.isnan(stack), axis=0)
+    return _sequential_sum(np.where(np.isnan(stack), 0.0, stack)) / cnt
+
+
+def coadd_median(stack):
+    """stamp_utils.py:278-303 (torch.nanmedian: lower median; all-NaN pixel -> 0)."""
+    stack = np.asarray(stack, dtype=np.float64)
+    if stack.shape[0] == 0:
+        return np.zeros(stack.shape[1:])
+    srt = np.sort(stack, axis=0)  # NaN last
+    n = np.sum(~np.isnan(stack), axis=0)
+    idx = np.maximum((n - 1) // 2, 0)
+    out = np.take_along_axis(srt, idx[np.newaxis], axis=0)[0]
+    out[n == 0] = 0.0
+    return out
+
+
+def coadd_weighted(stack, var_stack):
+    """stamp_utils.py:306-344."""
+    stack = np.asarray(stack, dtype=np.float64)
+    var_stack = np.asarray(var_stack, dtype=np.float64)
+    if stack.shape[0] == 0:
+        return np.zeros(stack.shape[1:])
+    stack = _mask_all_nans(stack)
+    pix_valid = ~(np.isnan(stack) | np.isnan(var_stack) | (var_stack == 0.0))
+    weights = np.zeros(stack.shape)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        weights[pix_valid] = 1.0 / var_stack[pix_valid]
+        weighted_sci = np.zeros(stack.shape)
+        weighted_sci[pix_valid] = stack[pix_valid] * weights[pix_valid]
+        weighted_sum = _sequential_sum(weighted_sci)
+        sum_of_weights = _sequential_sum(weights)
+        sum_of_weights[sum_of_weights == 0.0] = 1e24
+        return weighted_sum / sum_of_weights
+
+
+COADDS = {"sum": coadd_sum, "mean": coadd_mean, "median": coadd_median}
+
+
+def coadds_for_trajectories(sci, var, xvals, yvals, obs_valid, radius, coadd_types):
+    """The loop of append_coadds (src/kbmod/filters/stamp_filters.py:72-168, nightly=False) on plain
+    arrays: float32 [N][S][S] per coadd type."""
+    if radius <= 0:
+        raise ValueError(f"Invalid stamp radius {radius}")
+    s = 2 * radius + 1
+    n = len(xvals)
+    out = {c: np.zeros((n, s, s), dtype=np.float32) for c in coadd_types}
+    for idx in range(n):
+        inc = None if obs_valid is None else obs_valid[idx]
+        import warnings
+
+        with warnings.catch_warnings(), np.errstate(invalid="ignore", divide="ignore"):
+            warnings.simplefilter("ignore")
+            sci_stack = extract_stamp_stack(sci, xvals[idx], yvals[idx], radius, to_include=inc)
+            for c in coadd_types:
+                if c == "weighted":
+                    var_stack = extract_stamp_stack(var, xvals[idx], yvals[idx], radius, to_include=inc)
+                    out[c][idx] = coadd_weighted(sci_stack, var_stack)
+                else:
+                    out[c][idx] = COADDS[c](sci_stack)
+    return out

@@ -7,7 +7,7 @@ FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-corr
 for v in NO_BARRIER:-DKB_ABL_NO_BARRIER NO_DMA_NO_BARRIER:"-DKB_ABL_NO_DMA -DKB_ABL_NO_BARRIER"; do
   name=${v%%:*}; defs=${v#*:}
   ( /opt/rocm/bin/hipcc $FL $defs -c kbmod_amd/csrc/search_kernels.hip -o /tmp/abl_$name.o && \
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/abl_$name.o kbmod_amd/_obj/device_memory.o kbmod_amd/_obj/image_kernels.o kbmod_amd/_obj/result_kernels.o -o tools/probe_bin/libkbmod_$name.so ) &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/abl_$name.o kbmod_amd/_obj/device_memory.o kbmod_amd/_obj/image_kernels.o kbmod_amd/_obj/result_kernels.o kbmod_amd/_obj/stamp_kernels.o -o tools/probe_bin/libkbmod_$name.so ) &
 done
 wait
 ls -la tools/probe_bin/*.so
