@@ -86,7 +86,7 @@ struct SearchArgs {
     const ChunkInfo* chunks;   // [n_chunks]
     const EpochBox* boxes;     // [n_chunks][T]
     const int64_t* origins;    // [n_chunks][T] byte offset of the slab origin inside the padded copy, relative
-                               // to the tile's own pixel (kb_slab_origin_kernel); -1 = not staged
+                               // to the tile's own pixel (kb_slab_origin_kernel)
     const int* lds_off;        // [n_chunks][T][C] byte offset of the shifted tile inside plane A
     const int* global_box;     // {dx_min, dx_max, dy_min, dy_max, rows_max} over every (candidate, epoch)
     const void* padded;        // [T][Hp][Wp] raw pairs, apron = NO_DATA (kb_search_lds only)
@@ -652,8 +652,10 @@ __global__ __launch_bounds__(256) void kb_slab_origin_kernel(const EpochBox* __r
     if (i >= n) return;
     const EpochBox box = boxes[i];
     const int t = (int)(i % T);
+    // an epoch that is not staged copies the slab at the tile's own pixel (inside the frame, never read by
+    // the sums): the search loop is spared a test per epoch
     origins[i] = (box.x == BOX_NOT_STAGED)
-                         ? -1
+                         ? (((int64_t)t * Hp + py0) * Wp + px0) * (int64_t)pair_bytes
                          : (((int64_t)t * Hp + box_dy(box) + py0) * Wp + box_dx(box) + px0) * (int64_t)pair_bytes;
 }
 
@@ -675,6 +677,16 @@ struct SlabRegs {
     Piece v[LDS_SLOTS];
 };
 
+// Offsets of a thread for slabs of slab_bytes: 0 (re-read the slab's first bytes) past the slab's end.
+__device__ __forceinline__ StageLane clip_lane(const StageLane& sl, int slab_bytes) {
+    StageLane out;
+#pragma unroll
+    for (int j = 0; j < LDS_SLOTS; ++j) {
+        out.goff[j] = (16 * ((int)threadIdx.x + 256 * j) < slab_bytes) ? sl.goff[j] : 0u;
+    }
+    return out;
+}
+
 // Issue the loads of one epoch's slab; `base` = its origin in the padded copy (uniform).  All LDS_SLOTS
 // loads are issued whatever the slab size (no branch, no exec mask -- the compiler would serialise
 // masked loads with vmcnt(0)): threads past the end of the slab re-read its first bytes and do not
@@ -691,7 +703,8 @@ __device__ __forceinline__ void load_slab(const SearchArgs& a, const StageLane& 
             const int r = p / LDS_COLS, c = p - r * LDS_COLS;
             goff = (uint32_t)(r * a.Wp + c) * (uint32_t)BYTES;
         }
-        const uint32_t off = (16 * (tid + 256 * (j0 + j)) < slab_bytes) ? goff : 0u;
+        // (round 0: sl already holds 0 for threads past the end of this chunk's slabs, see clip_lane)
+        const uint32_t off = (j0 == 0 || 16 * (tid + 256 * (j0 + j)) < slab_bytes) ? goff : 0u;
         // only BYTES-aligned: the hardware takes unaligned 16-byte global loads
         const PieceMem<(BYTES < 4 ? BYTES : 4)>* src = reinterpret_cast<const PieceMem<(BYTES < 4 ? BYTES : 4)>*>(base + off);
         regs.v[j] = Piece{src->w[0], src->w[1], src->w[2], src->w[3]};
@@ -831,17 +844,16 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     typedef const __attribute__((address_space(4))) int64_t* ConstI64Ptr;
     // this tile's own pixel inside the padded copy
     const char* tile_base = reinterpret_cast<const char*>(a.padded) + ((int64_t)tc.tile_y0 * a.Wp + tc.tile_x0) * BYTES;
+    StageLane n_sl = clip_lane(sl, plan.slab_bytes);  // staging map of the group being copied
     {
         const ConstI64Ptr org = (ConstI64Ptr)(uintptr_t)a.origins;
         const int n = min(plan.E, T);
         for (int e = 0; e < n; ++e) {
             const int64_t o = org[e];
-            if (o >= 0) {
-                load_slab<BYTES>(a, sl, tile_base + o, plan.slab_bytes, regs);
-                write_slab(smem + e * plan.slab_bytes, plan.slab_bytes, regs);
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-                copy_slab_tail<BYTES>(a, sl, tile_base + o, plan.slab_bytes, smem + e * plan.slab_bytes, regs);
-            }
+            load_slab<BYTES>(a, n_sl, tile_base + o, plan.slab_bytes, regs);
+            write_slab(smem + e * plan.slab_bytes, plan.slab_bytes, regs);
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            copy_slab_tail<BYTES>(a, sl, tile_base + o, plan.slab_bytes, smem + e * plan.slab_bytes, regs);
         }
     }
     __syncthreads();
@@ -853,7 +865,10 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
         if (n_t0 >= T) {
             n_chunk = chunk + 1;
             n_t0 = 0;
-            if (n_chunk < a.n_chunks) n_plan = chunk_plan<BYTES>(a, n_chunk);
+            if (n_chunk < a.n_chunks) {
+                n_plan = chunk_plan<BYTES>(a, n_chunk);
+                n_sl = clip_lane(sl, n_plan.slab_bytes);
+            }
         }
         const int n_next = (n_chunk < a.n_chunks) ? min(n_plan.E, T - n_t0) : 0;
         const ConstI64Ptr n_org = (ConstI64Ptr)(uintptr_t)(a.origins + (size_t)min(n_chunk, a.n_chunks - 1) * T + n_t0);
@@ -865,10 +880,8 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             return false;
 #endif
             if (e >= n_next) return false;
-            const int64_t o = n_org[e];
-            if (o < 0) return false;
-            n_base = tile_base + o;
-            load_slab<BYTES>(a, sl, n_base, n_plan.slab_bytes, regs);
+            n_base = tile_base + n_org[e];
+            load_slab<BYTES>(a, n_sl, n_base, n_plan.slab_bytes, regs);
             return true;
         };
         auto next_write = [&](int e) {
@@ -900,6 +913,8 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #endif
                 raw[c] = *reinterpret_cast<const typename R::type*>(cb + e * plan.slab_bytes + off);
             }
+            // one wait for the C reads instead of the compiler's one per read (instruction issue is the bound)
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 if constexpr (CANON) {
@@ -1409,6 +1424,11 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
             }
             if (back[1] <= back[2] && (uint64_t)back[0] * 10ull <= n_epochs) {
                 // Every slab [origin, origin + rows_max) x [origin, origin + LDS_COLS) lies inside the padded frame.
+                // (the zero shift is included: unstaged epochs copy the slab at the tile's own pixel)
+                back[1] = std::min(back[1], 0);
+                back[2] = std::max(back[2], 0);
+                back[3] = std::min(back[3], 0);
+                back[4] = std::max(back[4], 0);
                 const int64_t x_lo = (int64_t)params.x_start_min + back[1];
                 const int64_t x_hi = (int64_t)params.x_start_min + (int64_t)WAVE * (a.tiles_x - 1) + back[2] + LDS_COLS;
                 const int64_t y_lo = (int64_t)params.y_start_min + back[3];
