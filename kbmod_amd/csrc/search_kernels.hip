@@ -957,18 +957,35 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
         };
         if (FAST || plan.clean) {
 #endif
-            for (int e = 0; e < n_cur; ++e) {
-                int o[C];  // fetched before the slab origin, so that one wait covers both scalar loads
+            // A block alone on its CU is bound by the chain scalar table fetch -> LDS read -> adds -> slab
+            // landed -> LDS write of one epoch (measured 4.9 ms with one block per CU against 7.4 ms with
+            // four).  The table words of epoch e + 1 (slab offsets, slab origin) are therefore fetched at
+            // the END of epoch e, behind the adds: they travel while the slab loads are waited for and
+            // written, and the lgkmcnt wait of epoch e + 1's LDS reads finds them done.  The empty asm
+            // pins the fetch behind pin_sums(); both tables have slack behind their last entry.
+            int o_cur[C];
 #pragma unroll
-#ifdef KB_ABL_ZERO_OFF
-                for (int c = 0; c < C; ++c) o[c] = 8 * c;
-#else
-                for (int c = 0; c < C; ++c) o[c] = offs[e * C + c];
+            for (int c = 0; c < C; ++c) o_cur[c] = offs[c];
+            int64_t org_cur = n_org[0];
+            for (int e = 0; e < n_cur; ++e) {
+                const bool staging = e < n_next;
+#ifndef KB_ABL_NO_DMA
+                if (staging) {
+                    n_base = tile_base + org_cur;
+                    load_slab<BYTES>(a, n_sl, n_base, n_plan.slab_bytes, regs);
+                }
 #endif
-                const bool staging = next_load(e);
-                sum_epoch(o, e);
+                sum_epoch(o_cur, e);
                 pin_sums();
+                ConstIntPtr po = offs + (e + 1) * C;
+                ConstI64Ptr pg = n_org + (e + 1);
+                asm volatile("" : "+s"(po), "+s"(pg)::"memory");
+#pragma unroll
+                for (int c = 0; c < C; ++c) o_cur[c] = po[c];
+                org_cur = pg[0];
+#ifndef KB_ABL_NO_DMA
                 if (staging) next_write(e);
+#endif
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             }
         } else {
@@ -1380,7 +1397,7 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
         const size_t table_bytes = (size_t)a.n_chunks * a.T * CHUNK * sizeof(int2);
         const size_t off_bytes = ((size_t)a.n_chunks * a.T * CHUNK + 4 * CHUNK) * sizeof(int);  // + prefetch slack
         const size_t box_bytes = (size_t)a.n_chunks * a.T * sizeof(EpochBox);
-        const size_t org_bytes = (size_t)a.n_chunks * a.T * sizeof(int64_t);
+        const size_t org_bytes = ((size_t)a.n_chunks * a.T + 8) * sizeof(int64_t);  // + prefetch slack
         const size_t chunk_bytes = (size_t)a.n_chunks * sizeof(ChunkInfo);
         // NO_DATA pixel counter [1], unstaged (chunk, epoch) counter [1], staged shift box + tallest slab [5],
         // per-lane (chunk, epoch) counter [1]
