@@ -27,7 +27,8 @@ struct CoaddArgs {
     const int32_t* y;      // [N][T]
     const uint8_t* include;  // [N][T] or null (all epochs)
     float* out;            // [N][S][S]
-    float* scratch;        // median only: [batch][T][S*S]
+    float* scratch;        // median only, long stacks: [batch][T][S*S]
+    int lds_pixels;        // median only: stamp pixels per pass whose T-long columns fit the LDS buffer (0: use scratch)
     uint64_t n0;           // first trajectory of this launch
     int T, H, W, radius, S;
 };
@@ -48,8 +49,18 @@ __global__ __launch_bounds__(256) void kb_coadd_kernel(const CoaddArgs a) {
     const int32_t* __restrict__ ys = a.y + n * (uint64_t)a.T;
     const uint8_t* __restrict__ inc = a.include ? a.include + n * (uint64_t)a.T : nullptr;
     const size_t image = (size_t)a.H * a.W;
-    float* __restrict__ col = a.scratch ? a.scratch + (size_t)blockIdx.x * a.T * S2 : nullptr;
-    for (int pix = threadIdx.x; pix < S2; pix += blockDim.x) {
+    // median: the used values of one pixel form a column, kept in LDS ([slot][lds_pixels], this thread's
+    // pixel = one bank-conflict-free lane of it) or, for stacks too long for that, in an HBM scratch
+    extern __shared__ float lds_col[];
+    const bool in_lds = TYPE == KB_COADD_MEDIAN && a.lds_pixels > 0;
+    float* __restrict__ col = in_lds ? lds_col + threadIdx.x
+                                     : (a.scratch ? a.scratch + (size_t)blockIdx.x * a.T * S2 : nullptr);
+    const int col_stride = in_lds ? a.lds_pixels : S2;
+    const int per_pass = in_lds ? a.lds_pixels : (int)blockDim.x;
+    for (int pix0 = 0; pix0 < S2; pix0 += per_pass) {
+        const int pix = pix0 + (int)threadIdx.x;
+        if ((int)threadIdx.x >= per_pass || pix >= S2) continue;
+        float* __restrict__ mycol = in_lds ? col : col + pix;
         const int j = pix / a.S, i = pix - j * a.S;
         double sum = 0.0, wsum = 0.0;
         int used = 0, n_valid = 0;
@@ -60,7 +71,7 @@ __global__ __launch_bounds__(256) void kb_coadd_kernel(const CoaddArgs a) {
             const bool is_nan = v != v;
             n_valid += is_nan ? 0 : 1;
             if constexpr (TYPE == KB_COADD_MEDIAN) {
-                col[(size_t)used * S2 + pix] = v;
+                mycol[(size_t)used * col_stride] = v;
             } else if constexpr (TYPE == KB_COADD_WEIGHTED) {
                 // weights = 1 / var and sci * weights where sci, var are not NaN and var != 0; zeros elsewhere
                 const float vv = stamp_pixel(a.var + t * image, a.H, a.W, xs[t], ys[t], a.radius, j, i);
@@ -98,11 +109,11 @@ __global__ __launch_bounds__(256) void kb_coadd_kernel(const CoaddArgs a) {
             if (n_valid > 0) {
                 const int k = (n_valid - 1) / 2;
                 for (int c = 0; c < used; ++c) {
-                    const float vc = col[(size_t)c * S2 + pix];
+                    const float vc = mycol[(size_t)c * col_stride];
                     if (vc != vc) continue;
                     int before = 0;
                     for (int u = 0; u < used; ++u) {
-                        const float vu = col[(size_t)u * S2 + pix];
+                        const float vu = mycol[(size_t)u * col_stride];
                         before += (vu < vc || (vu == vc && u < c)) ? 1 : 0;
                     }
                     if (before == k) {
@@ -152,20 +163,29 @@ extern "C" int kb_coadd_stamps(const float* sci_dev, const float* var_dev, int32
     const unsigned threads = (unsigned)std::min<uint64_t>(256, (s2 + 63) / 64 * 64);
     uint64_t batch = std::min<uint64_t>(n, 1u << 20);
     std::unique_lock<std::mutex> lock(g_scratch_mutex, std::defer_lock);
+    constexpr int MEDIAN_LDS_BYTES = 32768;
+    a.lds_pixels = 0;
+    size_t lds_bytes = 0;
     if (coadd_type == KB_COADD_MEDIAN) {
-        // [batch][T][S*S] floats of scratch, at most 256 MiB per launch
-        lock.lock();
-        const uint64_t per = std::max<uint64_t>(1, (uint64_t)num_times) * s2 * sizeof(float);
-        batch = std::max<uint64_t>(1, std::min<uint64_t>(batch, (256ull << 20) / per));
-        const size_t need = (size_t)(batch * per);
-        if (g_scratch_bytes < need) {
-            if (g_scratch) (void)hipFree(g_scratch);
-            g_scratch = nullptr;
-            g_scratch_bytes = 0;
-            KB_HIP_TRY(hipMalloc(&g_scratch, need));
-            g_scratch_bytes = need;
+        const int fit = num_times > 0 ? MEDIAN_LDS_BYTES / (int)(sizeof(float) * num_times) : (int)threads;
+        if (fit >= 16) {
+            a.lds_pixels = std::min<int>((int)threads, fit);
+            lds_bytes = (size_t)a.lds_pixels * std::max(1, num_times) * sizeof(float);
+        } else {
+            // [batch][T][S*S] floats of scratch, at most 256 MiB per launch
+            lock.lock();
+            const uint64_t per = std::max<uint64_t>(1, (uint64_t)num_times) * s2 * sizeof(float);
+            batch = std::max<uint64_t>(1, std::min<uint64_t>(batch, (256ull << 20) / per));
+            const size_t need = (size_t)(batch * per);
+            if (g_scratch_bytes < need) {
+                if (g_scratch) (void)hipFree(g_scratch);
+                g_scratch = nullptr;
+                g_scratch_bytes = 0;
+                KB_HIP_TRY(hipMalloc(&g_scratch, need));
+                g_scratch_bytes = need;
+            }
+            a.scratch = g_scratch;
         }
-        a.scratch = g_scratch;
     }
     for (uint64_t n0 = 0; n0 < n; n0 += batch) {
         a.n0 = n0;
@@ -178,7 +198,7 @@ extern "C" int kb_coadd_stamps(const float* sci_dev, const float* var_dev, int32
                 hipLaunchKernelGGL((kb_coadd_kernel<KB_COADD_MEAN>), dim3(blocks), dim3(threads), 0, stream, a);
                 break;
             case KB_COADD_MEDIAN:
-                hipLaunchKernelGGL((kb_coadd_kernel<KB_COADD_MEDIAN>), dim3(blocks), dim3(threads), 0, stream, a);
+                hipLaunchKernelGGL((kb_coadd_kernel<KB_COADD_MEDIAN>), dim3(blocks), dim3(threads), lds_bytes, stream, a);
                 break;
             default:
                 hipLaunchKernelGGL((kb_coadd_kernel<KB_COADD_WEIGHTED>), dim3(blocks), dim3(threads), 0, stream, a);

@@ -89,6 +89,16 @@ def test_coadds_equal_oracle(su, radius, use_mask):
         assert np.array_equal(got[c], exp[c], equal_nan=True), c
 
 
+def test_median_of_a_long_stack_uses_the_scratch_path(su):
+    # more than 512 epochs: the per-pixel columns no longer fit the LDS buffer
+    sci, var, times, x0, y0, vx, vy, obs_valid = _random_case(77, 600, 24, 30, 6)
+    xv = ps.predict_pixel_locations(times, x0, vx * 0.2)
+    yv = ps.predict_pixel_locations(times, y0, vy * 0.2)
+    got = su.DeviceStack(sci).coadds(xv, yv, 2, ["median"], to_include=obs_valid)
+    exp = ps.coadds_for_trajectories(sci, None, xv, yv, obs_valid, 2, ["median"])
+    assert np.array_equal(got["median"], exp["median"])
+
+
 def test_append_coadds_table(su):
     sci, var, times, x0, y0, vx, vy, obs_valid = _random_case(5, 30, 64, 64, 200)
     table = {"x": x0, "y": y0, "vx": vx, "vy": vy, "obs_valid": obs_valid}
