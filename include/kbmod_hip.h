@@ -144,6 +144,14 @@ int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t n, float m
 int kb_psi_phi_curves(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
                       const kb_trajectory* trjs_dev, uint64_t n, float* out_dev, void* stream);
 
+/* ---- near-duplicate grid filter (apply_trajectory_grid_filter, src/kbmod/filters/clustering_grid.py:152-175,
+ * called from run_search.py:294-301): trajectories that fall into the same (start bin, end bin at
+ * max_time) of width bin_width are duplicates; the one with the largest lh survives (the earliest of
+ * equals).  kept_idx_dev: room for n indices; receives the survivors' indices in the order in which
+ * their bins first occur in the input; *n_kept_host their number.  Synchronises the stream. */
+int kb_grid_filter(const kb_trajectory* trjs_dev, uint64_t n, double bin_width, double max_time, uint32_t* kept_idx_dev,
+                   uint64_t* n_kept_host, void* stream);
+
 /* ---- batched sigma-G clipping of likelihood curves (SigmaGClipping.compute_clipped_sigma_g_matrix,
  * src/kbmod/filters/sigma_g_filter.py:114-168; the step after get_all_psi_phi_curves in
  * SearchRunner.load_and_filter_results, run_search.py:251-337).  lh: [n_rows][n_cols] float32 (NaN =

@@ -309,6 +309,39 @@ PYBIND11_MODULE(search, m) {
         return res;
     });
 
+    // ---- near-duplicate grid filter on the device (filters/clustering_grid.py:152-175) ----
+    m.def(
+            "grid_filter_indices",
+            [](const std::vector<Trajectory>& trjs, double bin_width, double max_dt) {
+                std::vector<uint32_t> kept(trjs.size());
+                uint64_t n_kept = 0;
+                if (!trjs.empty()) {
+                    if (kb_device_count() == 0) throw std::runtime_error("GPU is not available for the grid filter.");
+                    void *t_dev = nullptr, *k_dev = nullptr;
+                    auto check = [&](int rc) {
+                        if (rc != 0) {
+                            if (t_dev) kb_free_gpu_block(t_dev);
+                            if (k_dev) kb_free_gpu_block(k_dev);
+                            throw std::runtime_error(kb_last_error());
+                        }
+                    };
+                    check(kb_allocate_gpu_block(trjs.size() * sizeof(Trajectory), &t_dev));
+                    check(kb_allocate_gpu_block(trjs.size() * sizeof(uint32_t), &k_dev));
+                    check(kb_copy_block_to_gpu(trjs.data(), t_dev, trjs.size() * sizeof(Trajectory)));
+                    check(kb_grid_filter(reinterpret_cast<const kb_trajectory*>(t_dev), trjs.size(), bin_width, max_dt,
+                                         reinterpret_cast<uint32_t*>(k_dev), &n_kept, nullptr));
+                    if (n_kept) check(kb_copy_block_to_cpu(kept.data(), k_dev, n_kept * sizeof(uint32_t)));
+                    kb_free_gpu_block(t_dev);
+                    kb_free_gpu_block(k_dev);
+                } else {
+                    // same argument checks as the device entry point
+                    if (!(bin_width >= 1.0) || !(max_dt >= 0.0)) throw std::runtime_error("invalid bin width or max time");
+                }
+                kept.resize(n_kept);
+                return kept;
+            },
+            py::arg("trajectories"), py::arg("bin_width") = 10.0, py::arg("max_dt") = 1.0);
+
     // ---- stamp coadds on the device (filters/stamp_filters.py:72-168, core/stamp_utils.py) ----
     py::class_<DeviceImageStack>(m, "DeviceImageStack")
             .def(py::init<DeviceImageStack::FloatArray, py::object>(), py::arg("sci"), py::arg("var") = py::none())

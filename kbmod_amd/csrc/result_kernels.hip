@@ -7,10 +7,12 @@
 // (stable, so equal likelihoods keep their slot order -- one of the orders the
 // reference's unstable sort may produce); the kernels around them are ours.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <string>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_select.hpp>
 
 #include "kb_common.h"
@@ -179,6 +181,86 @@ __global__ __launch_bounds__(CLIP_ROWS_PER_BLOCK* WAVE) void kb_sigma_g_clip_ker
     }
 }
 
+// ---------------------------------------------------------------------------
+// near-duplicate grid filter
+// ---------------------------------------------------------------------------
+// apply_trajectory_grid_filter / TrajectoryClusterGrid (src/kbmod/filters/clustering_grid.py:58-92,
+// 152-175): key = (int(x / w), int(y / w), int((x + dt * vx) / w), int((y + dt * vy) / w)) in double
+// arithmetic with truncation; per key the trajectory with the largest lh survives (a later one replaces
+// only when strictly larger), keys come out in the order of their first occurrence.  The sequential
+// dictionary becomes: stable sort by lh descending, stable sort by key (two 64-bit halves) -> every run
+// of equal keys starts with its winner; the runs are then ordered by their smallest original index.
+__device__ __forceinline__ bool grid_bin(double v, double w, int32_t* out) {
+    const double q = trunc(v / w);
+    if (!(q > -2147483648.0 && q < 2147483648.0)) return false;  // also NaN
+    *out = (int32_t)q;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void kb_grid_keys_kernel(const kb_trajectory* __restrict__ trjs, uint64_t n,
+                                                           double bin_width, double max_time,
+                                                           uint64_t* __restrict__ key_hi, uint64_t* __restrict__ key_lo,
+                                                           float* __restrict__ lh, uint32_t* __restrict__ idx,
+                                                           int* __restrict__ bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const kb_trajectory t = trjs[i];
+    int32_t xs = 0, ys = 0, xe = 0, ye = 0;
+    bool ok = grid_bin((double)t.x, bin_width, &xs);
+    ok = grid_bin((double)t.y, bin_width, &ys) && ok;
+    ok = grid_bin(__dadd_rn((double)t.x, __dmul_rn(max_time, (double)t.vx)), bin_width, &xe) && ok;
+    ok = grid_bin(__dadd_rn((double)t.y, __dmul_rn(max_time, (double)t.vy)), bin_width, &ye) && ok;
+    if (!ok) atomicOr(bad, 1);
+    // order-preserving: flip the sign bit of each 32-bit bin
+    key_hi[i] = ((uint64_t)((uint32_t)xs ^ 0x80000000u) << 32) | ((uint32_t)ys ^ 0x80000000u);
+    key_lo[i] = ((uint64_t)((uint32_t)xe ^ 0x80000000u) << 32) | ((uint32_t)ye ^ 0x80000000u);
+    lh[i] = (t.lh == 0.0f) ? 0.0f : t.lh;  // -0 and +0 compare equal in the reference
+    idx[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void kb_gather_u64_kernel(const uint64_t* __restrict__ src,
+                                                            const uint32_t* __restrict__ idx, uint64_t n,
+                                                            uint64_t* __restrict__ dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+__global__ __launch_bounds__(256) void kb_run_heads_kernel(const uint64_t* __restrict__ hi,
+                                                           const uint64_t* __restrict__ lo, uint64_t n,
+                                                           uint32_t* __restrict__ head) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || hi[i] != hi[i - 1] || lo[i] != lo[i - 1]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void kb_run_reduce_kernel(const uint32_t* __restrict__ head,
+                                                            const uint32_t* __restrict__ run_of,  // inclusive scan of head
+                                                            const uint32_t* __restrict__ idx, uint64_t n,
+                                                            uint32_t* __restrict__ first, uint32_t* __restrict__ best) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = run_of[i] - 1;
+    if (head[i]) best[r] = idx[i];
+    atomicMin(&first[r], idx[i]);
+}
+
+template <typename K>
+static int sort_pairs(bool descending, K* keys_in, K* keys_out, uint32_t* val_in, uint32_t* val_out, size_t n,
+                      hipStream_t stream) {
+    Scratch tmp;
+    size_t bytes = 0;
+    if (descending) {
+        KB_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, bytes, keys_in, keys_out, val_in, val_out, n, 0, sizeof(K) * 8, stream));
+        KB_HIP_TRY(hipMalloc(&tmp.p, std::max<size_t>(bytes, 16)));
+        KB_HIP_TRY(rocprim::radix_sort_pairs_desc(tmp.p, bytes, keys_in, keys_out, val_in, val_out, n, 0, sizeof(K) * 8, stream));
+    } else {
+        KB_HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, val_in, val_out, n, 0, sizeof(K) * 8, stream));
+        KB_HIP_TRY(hipMalloc(&tmp.p, std::max<size_t>(bytes, 16)));
+        KB_HIP_TRY(rocprim::radix_sort_pairs(tmp.p, bytes, keys_in, keys_out, val_in, val_out, n, 0, sizeof(K) * 8, stream));
+    }
+    KB_HIP_TRY(hipStreamSynchronize(stream));  // tmp is freed on return
+    return 0;
+}
+
 }  // namespace kb
 
 extern "C" int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs,
@@ -311,4 +393,76 @@ extern "C" int kb_sigma_g_clip_matrix_host(const float* lh_host, uint64_t n_rows
     (void)hipFree(lh_dev);
     (void)hipFree(valid_dev);
     return rc;
+}
+
+extern "C" int kb_grid_filter(const kb_trajectory* trjs_dev, uint64_t n, double bin_width, double max_time,
+                              uint32_t* kept_idx_dev, uint64_t* n_kept_host, void* stream_v) {
+    using namespace kb;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (n_kept_host == nullptr) return fail("grid_filter: null count pointer");
+    *n_kept_host = 0;
+    // clustering_grid.py:44-50
+    if (!(bin_width >= 1.0) || !std::isfinite(bin_width)) return fail("Bin width must be at least 1. Got " + std::to_string(bin_width) + ".");
+    if (!(max_time >= 0.0) || !std::isfinite(max_time)) return fail("Max time must be >= 0. Got " + std::to_string(max_time) + ".");
+    if (n == 0) return 0;
+    if (trjs_dev == nullptr || kept_idx_dev == nullptr) return fail("grid_filter: null pointer");
+    if (n >= 0xffffffffull) return fail("grid_filter: more than 2^32 - 1 trajectories");
+
+    Scratch hi, lo, k_a, k_b, lh_a, lh_b, i_a, i_b, head, runs, first, best, bad, tmp;
+    KB_HIP_TRY(hipMalloc(&hi.p, n * 8));
+    KB_HIP_TRY(hipMalloc(&lo.p, n * 8));
+    KB_HIP_TRY(hipMalloc(&k_a.p, n * 8));
+    KB_HIP_TRY(hipMalloc(&k_b.p, n * 8));
+    KB_HIP_TRY(hipMalloc(&lh_a.p, n * 4));
+    KB_HIP_TRY(hipMalloc(&lh_b.p, n * 4));
+    KB_HIP_TRY(hipMalloc(&i_a.p, n * 4));
+    KB_HIP_TRY(hipMalloc(&i_b.p, n * 4));
+    KB_HIP_TRY(hipMalloc(&head.p, n * 4));
+    KB_HIP_TRY(hipMalloc(&runs.p, n * 4));
+    KB_HIP_TRY(hipMalloc(&first.p, n * 4));
+    KB_HIP_TRY(hipMalloc(&best.p, n * 4));
+    KB_HIP_TRY(hipMalloc(&bad.p, 4));
+    KB_HIP_TRY(hipMemsetAsync(bad.p, 0, 4, stream));
+    KB_HIP_TRY(hipMemsetAsync(first.p, 0xff, n * 4, stream));
+    uint64_t* key_hi = reinterpret_cast<uint64_t*>(hi.p);
+    uint64_t* key_lo = reinterpret_cast<uint64_t*>(lo.p);
+    uint64_t *ka = reinterpret_cast<uint64_t*>(k_a.p), *kb_ = reinterpret_cast<uint64_t*>(k_b.p);
+    uint32_t *ia = reinterpret_cast<uint32_t*>(i_a.p), *ib = reinterpret_cast<uint32_t*>(i_b.p);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+
+    hipLaunchKernelGGL(kb_grid_keys_kernel, dim3(blocks), dim3(256), 0, stream, trjs_dev, n, bin_width, max_time, key_hi,
+                       key_lo, reinterpret_cast<float*>(lh_a.p), ia, reinterpret_cast<int*>(bad.p));
+    KB_HIP_TRY(hipGetLastError());
+    int bad_host = 0;
+    KB_HIP_TRY(hipMemcpyAsync(&bad_host, bad.p, 4, hipMemcpyDeviceToHost, stream));
+    KB_HIP_TRY(hipStreamSynchronize(stream));
+    if (bad_host) return fail("grid_filter: a trajectory does not map to a finite 32-bit spatial bin");
+
+    // 1. lh descending (stable: equal lh keep their original order) -> ib
+    if (sort_pairs<float>(true, reinterpret_cast<float*>(lh_a.p), reinterpret_cast<float*>(lh_b.p), ia, ib, n, stream)) return 1;
+    // 2. stable by the end bins, then by the start bins -> lexicographic (start, end) order
+    hipLaunchKernelGGL(kb_gather_u64_kernel, dim3(blocks), dim3(256), 0, stream, key_lo, ib, n, ka);
+    if (sort_pairs<uint64_t>(false, ka, kb_, ib, ia, n, stream)) return 1;
+    hipLaunchKernelGGL(kb_gather_u64_kernel, dim3(blocks), dim3(256), 0, stream, key_hi, ia, n, ka);
+    if (sort_pairs<uint64_t>(false, ka, kb_, ia, ib, n, stream)) return 1;  // kb_ = sorted start keys, ib = order
+    hipLaunchKernelGGL(kb_gather_u64_kernel, dim3(blocks), dim3(256), 0, stream, key_lo, ib, n, ka);  // end keys, same order
+    // 3. runs of equal keys: head flags, run numbers, winner (= head) and first occurrence of every run
+    uint32_t* head_p = reinterpret_cast<uint32_t*>(head.p);
+    uint32_t* runs_p = reinterpret_cast<uint32_t*>(runs.p);
+    hipLaunchKernelGGL(kb_run_heads_kernel, dim3(blocks), dim3(256), 0, stream, kb_, ka, n, head_p);
+    size_t scan_bytes = 0;
+    KB_HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, head_p, runs_p, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    KB_HIP_TRY(hipMalloc(&tmp.p, std::max<size_t>(scan_bytes, 16)));
+    KB_HIP_TRY(rocprim::inclusive_scan(tmp.p, scan_bytes, head_p, runs_p, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    uint32_t n_runs = 0;
+    KB_HIP_TRY(hipMemcpyAsync(&n_runs, runs_p + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+    hipLaunchKernelGGL(kb_run_reduce_kernel, dim3(blocks), dim3(256), 0, stream, head_p, runs_p, ib, n,
+                       reinterpret_cast<uint32_t*>(first.p), reinterpret_cast<uint32_t*>(best.p));
+    KB_HIP_TRY(hipGetLastError());
+    KB_HIP_TRY(hipStreamSynchronize(stream));
+    // 4. dictionary order = order of first occurrence
+    if (sort_pairs<uint32_t>(false, reinterpret_cast<uint32_t*>(first.p), ia, reinterpret_cast<uint32_t*>(best.p), kept_idx_dev,
+                             (size_t)n_runs, stream)) return 1;
+    *n_kept_host = n_runs;
+    return 0;
 }

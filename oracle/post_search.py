@@ -285,3 +285,30 @@ def coadds_for_trajectories(sci, var, xvals, yvals, obs_valid, radius, coadd_typ
                 else:
                     out[c][idx] = COADDS[c](sci_stack)
     return out
+
+
+# ---------------------------------------------------------------------------
+# near-duplicate grid filter: src/kbmod/filters/clustering_grid.py
+# ---------------------------------------------------------------------------
+
+
+def grid_filter_indices(x, y, vx, vy, lh, bin_width=10, max_time=1.0):
+    """apply_trajectory_grid_filter (clustering_grid.py:152-175) / TrajectoryClusterGrid.add_trajectory
+    (:58-92) on columns: the index of the best trajectory (strictly larger lh replaces) of every
+    (start bin, end bin) key, in the order in which the keys were first seen."""
+    if bin_width < 1 or not np.isfinite(bin_width):
+        raise ValueError(f"Bin width must be at least 1. Got {bin_width}.")
+    if max_time < 0 or not np.isfinite(max_time):
+        raise ValueError(f"Max time must be >= 0. Got {max_time}.")
+    table, idx_table = {}, {}
+    for i in range(len(x)):
+        xi, yi, vxi, vyi = int(x[i]), int(y[i]), float(vx[i]), float(vy[i])
+        key = (int(xi / bin_width), int(yi / bin_width), int((xi + max_time * vxi) / bin_width),
+               int((yi + max_time * vyi) / bin_width))
+        if key not in table:
+            table[key] = lh[i]
+            idx_table[key] = i
+        elif lh[i] > table[key]:
+            table[key] = lh[i]
+            idx_table[key] = i
+    return list(idx_table.values())

@@ -110,3 +110,18 @@ def test_predict_pixel_locations():
     # truncation toward zero: -0.3 + 0.5 -> 0, -1.2 + 0.5 -> 0 (not -1)
     got = ps.predict_pixel_locations(np.array([0.0, 1.0, 2.0]), np.array([0, 5]), np.array([-0.6, 1.5]))
     assert np.array_equal(got, [[0, 0, 0], [5, 7, 8]])
+
+
+def test_grid_filter_known_answers():
+    # tests/test_clustering_grid.py:8-57, 93-108 (Trajectory(x, y, vx, vy, flux, lh, obs_count))
+    t = [(0, 0, 0.0, 0.0, 10.0), (21, 21, 10.0, 10.0, 10.0), (21, 21, 0.0, 0.0, 10.0), (21, 21, 0.0, 0.0, 100.0),
+         (0, 0, 0.0, 0.0, 5.0), (0, 0, 0.0, 0.0, 15.0)]
+    x, y, vx, vy, lh = (np.array(c) for c in zip(*t))
+    assert ps.grid_filter_indices(x[:1], y[:1], vx[:1], vy[:1], lh[:1]) == [0]
+    assert ps.grid_filter_indices(x[:4], y[:4], vx[:4], vy[:4], lh[:4]) == [0, 1, 3]
+    assert ps.grid_filter_indices(x[:5], y[:5], vx[:5], vy[:5], lh[:5]) == [0, 1, 3]
+    assert ps.grid_filter_indices(x, y, vx, vy, lh, bin_width=10, max_time=1.0) == [5, 1, 3]
+    with pytest.raises(ValueError):
+        ps.grid_filter_indices(x, y, vx, vy, lh, bin_width=0)
+    with pytest.raises(ValueError):
+        ps.grid_filter_indices(x, y, vx, vy, lh, max_time=-1.0)
