@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--flags", type=int, default=0, help="kb_device_search_filter flags (1 exact positions, 4 LDS-staged kernel)")
     ap.add_argument("--sigmag", action="store_true",
                     help="BASELINE configs[2]: in-kernel sigma-G ([25, 75] percentiles, coeff 0.7413, min_lh 10), min_obs T/2")
+    ap.add_argument("--min-lh", type=float, default=None, help="override the likelihood threshold (default 0, 10 with --sigmag)")
     ap.add_argument("--verify", action="store_true",
                     help="after timing: size-independent checks of the last result buffer (both kernels agree bit for "
                          "bit, per-pixel lists sorted, a start window re-done with exact per-lane positions agrees)")
@@ -170,9 +171,11 @@ def main():
     results = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
     nb_param = -1 if args.num_bytes in (-1, 4) else args.num_bytes
     if args.sigmag:
-        params = Params(T // 2, 10.0, 1, 0.25, 0.75, 0.7413, nb_param, ins, W - ins, ins, H - ins, K, 0)
+        params = Params(T // 2, 10.0 if args.min_lh is None else args.min_lh, 1, 0.25, 0.75, 0.7413, nb_param, ins, W - ins,
+                        ins, H - ins, K, 0)
     else:
-        params = Params(0, 0.0, 0, 0.25, 0.75, -1.0, nb_param, ins, W - ins, ins, H - ins, K, 0)
+        params = Params(0, 0.0 if args.min_lh is None else args.min_lh, 0, 0.25, 0.75, -1.0, nb_param, ins, W - ins, ins,
+                        H - ins, K, 0)
     gathered = torch.empty((world, S * K, 7), dtype=torch.float32, device=dev) if world > 1 else None
     merged = torch.empty((S * K, 7), dtype=torch.float32, device=dev) if world > 1 else None
 

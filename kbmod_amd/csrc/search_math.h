@@ -153,6 +153,84 @@ KB_HD void sigmag_filtered_indices_t(const VAL& values, int num_values, float sg
     *max_keep_idx = end - 1;
 }
 
+// The same exchange sort and bounds for the in-kernel clip, on (value, index) PAIRS sorted in place:
+// sv[k] carries values[idx[k]] along with idx[k], so that the inner loop reads two independent,
+// consecutive streams instead of an index and then the value it points to, and its loads can be
+// issued eight iterations ahead (iteration k only writes position k and the carried (ij, vj)).
+// The sequence of comparisons and swaps -- hence the permutation left among equal values -- is
+// that of sigmag_filtered_indices_t.  On exit sv is sorted and idx is the permutation.
+template <typename VAL, typename IDX>
+KB_HD void sigmag_sorted_bounds_t(const VAL& sv, int num_values, float sgl0, float sgl1, float sigmag_coeff, float width,
+                                  const IDX& idx_array, int* min_keep_idx, int* max_keep_idx) {
+    if (num_values == 0) {
+        *min_keep_idx = 0;
+        *max_keep_idx = -1;
+        return;
+    }
+    if ((double)sgl0 < 0.0001) sgl0 = (float)0.0001;
+    if ((double)sgl1 > 0.9999) sgl1 = (float)0.9999;
+
+    for (int j = 0; j < num_values; j++) idx_array[j] = j;
+    constexpr int B = 8;
+    for (int j = 0; j < num_values; j++) {
+        int ij = idx_array[j];
+        float vj = sv[j];
+        int k = j + 1;
+        for (; k + B <= num_values; k += B) {
+            int ik[B];
+            float vk[B];
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                ik[u] = idx_array[k + u];
+                vk[u] = sv[k + u];
+            }
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                if (vj > vk[u]) {
+                    idx_array[k + u] = ij;
+                    sv[k + u] = vj;
+                    ij = ik[u];
+                    vj = vk[u];
+                }
+            }
+        }
+        for (; k < num_values; k++) {
+            const int ik = idx_array[k];
+            const float vk = sv[k];
+            if (vj > vk) {
+                idx_array[k] = ij;
+                sv[k] = vj;
+                ij = ik;
+                vj = vk;
+            }
+        }
+        idx_array[j] = ij;
+        sv[j] = vj;
+    }
+    int pct_L = (int)((double)ceilf((float)num_values * sgl0) + 0.001) - 1;
+    pct_L = (pct_L < 0) ? 0 : pct_L;
+    pct_L = (pct_L >= num_values) ? (num_values - 1) : pct_L;
+    int pct_H = (int)((double)ceilf((float)num_values * sgl1) + 0.001) - 1;
+    pct_H = (pct_H < 0) ? 0 : pct_H;
+    pct_H = (pct_H >= num_values) ? (num_values - 1) : pct_H;
+    int median_ind = (int)(ceil((double)num_values * 0.5) + 0.001) - 1;
+    median_ind = (median_ind < 0) ? 0 : median_ind;
+    median_ind = (median_ind >= num_values) ? (num_values - 1) : median_ind;
+
+    const float sigma_g = sigmag_coeff * (sv[pct_H] - sv[pct_L]);
+    const float wsg = width * sigma_g;
+    const float vmed = sv[median_ind];
+    const float min_value = vmed - wsg;
+    const float max_value = vmed + wsg;
+
+    int start = 0;
+    while ((start < median_ind) && (sv[start] < min_value)) ++start;
+    *min_keep_idx = start;
+    int end = median_ind + 1;
+    while ((end < num_values) && (sv[end] <= max_value)) ++end;
+    *max_keep_idx = end - 1;
+}
+
 // Scratch for one clipped evaluation: 3 floats + 1 index per epoch.
 template <int STRIDE>
 struct SigmaGScratch {
@@ -204,8 +282,8 @@ KB_HD void evaluate_trajectory_full(const kb_psi_phi_meta& m, const void* arr, c
         scratch->lc[i] = (f != 0.0f) ? (scratch->psi[i] / f) : 0.0f;
     }
     int min_keep = 0, max_keep = num_seen - 1;
-    sigmag_filtered_indices_t(scratch->lc, num_seen, p.sgl_L, p.sgl_H, p.sigmag_coeff, 2.0f, scratch->idx,
-                              &min_keep, &max_keep);
+    sigmag_sorted_bounds_t(scratch->lc, num_seen, p.sgl_L, p.sgl_H, p.sigmag_coeff, 2.0f, scratch->idx, &min_keep,
+                           &max_keep);
     if (min_keep < 0) min_keep = 0;
     if (max_keep >= num_seen) max_keep = num_seen - 1;
     float new_psi = 0.0f, new_phi = 0.0f;
