@@ -426,37 +426,173 @@ __device__ __forceinline__ SigmaGScratch<WAVE> make_scratch(const SearchArgs& a,
     return s;
 }
 
+// Sigma-G clip of ONE trajectory by the whole wavefront (T <= 64): lane t gathers epoch t, the valid
+// samples' psi/phi ratios are sorted across the lanes (bitonic network on 64-bit keys
+// (ordered ratio, epoch)), the percentile bounds and keep range follow kernels.cu:77-147, and the
+// clipped sums are accumulated in sorted order, one fp32 add after the other, exactly like the
+// per-lane code of evaluate_trajectory_full.  The reference's exchange sort leaves a particular (not
+// stable) permutation among EQUAL ratios, which decides their summation order: when two valid
+// ratios are equal the function declines (returns false) and the caller runs the literal per-lane
+// code.  All 64 lanes must be active; x, y, vx, vy are wave-uniform.
+__device__ __forceinline__ uint32_t ratio_sort_key(float v) {
+    const uint32_t b = __float_as_uint((v == 0.0f) ? 0.0f : v);  // -0 and +0 compare equal
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ratio_from_key(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {  // lane: wave-uniform
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ bool clip_lh_wave(const kb_psi_phi_meta& meta, const void* __restrict__ psi_phi,
+                                          const double* __restrict__ times, float sgl0, float sgl1, float sigmag_coeff,
+                                          int x, int y, float vx, float vy, float* lh_out) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int T = (int)meta.num_times;
+    float psi = NAN, phi = NAN;
+    if (lane < T) {
+        const double t = times[lane];
+        int cx, cy;
+        const bool okx = predict_index(x, vx, t, &cx);
+        const bool oky = predict_index(y, vy, t, &cy);
+        if (okx && oky) read_psi_phi(meta, psi_phi, (uint64_t)lane, cy, cx, &psi, &phi);
+    }
+    const bool valid = __builtin_isfinite(psi) && __builtin_isfinite(phi);
+    const int n = __popcll(__ballot(valid));
+    if (n == 0) return false;
+    const float lc = valid ? ((phi != 0.0f) ? (psi / phi) : 0.0f) : 0.0f;
+    uint32_t khi = valid ? ratio_sort_key(lc) : 0xffffffffu;  // invalid samples sort behind every ratio
+    uint32_t klo = (uint32_t)lane;
+    for (int k = 2; k <= WAVE; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t phi_k = __shfl_xor(khi, j), plo_k = __shfl_xor(klo, j);
+            const bool mine_less = (khi < phi_k) || (khi == phi_k && klo < plo_k);
+            const bool keep_min = ((lane & k) == 0) == ((lane & j) == 0);
+            if (keep_min != mine_less) {
+                khi = phi_k;
+                klo = plo_k;
+            }
+        }
+    }
+    // lane i now holds the i-th smallest ratio and the epoch it came from
+    const float sv = ratio_from_key(khi);
+    const float sv_next = __shfl_down(sv, 1);
+    if (__ballot((lane + 1 < n) && (sv == sv_next)) != 0) return false;  // equal ratios: literal code decides
+    const float spsi = __shfl(psi, (int)klo), sphi = __shfl(phi, (int)klo);
+
+    if ((double)sgl0 < 0.0001) sgl0 = (float)0.0001;
+    if ((double)sgl1 > 0.9999) sgl1 = (float)0.9999;
+    int pct_L = (int)((double)ceilf((float)n * sgl0) + 0.001) - 1;
+    pct_L = (pct_L < 0) ? 0 : pct_L;
+    pct_L = (pct_L >= n) ? (n - 1) : pct_L;
+    int pct_H = (int)((double)ceilf((float)n * sgl1) + 0.001) - 1;
+    pct_H = (pct_H < 0) ? 0 : pct_H;
+    pct_H = (pct_H >= n) ? (n - 1) : pct_H;
+    int median_ind = (int)(ceil((double)n * 0.5) + 0.001) - 1;
+    median_ind = (median_ind < 0) ? 0 : median_ind;
+    median_ind = (median_ind >= n) ? (n - 1) : median_ind;
+    pct_L = __builtin_amdgcn_readfirstlane(pct_L);
+    pct_H = __builtin_amdgcn_readfirstlane(pct_H);
+    median_ind = __builtin_amdgcn_readfirstlane(median_ind);
+    const float sigma_g = sigmag_coeff * (lane_value(sv, pct_H) - lane_value(sv, pct_L));
+    const float wsg = 2.0f * sigma_g;
+    const float vmed = lane_value(sv, median_ind);
+    const float min_value = vmed - wsg;
+    const float max_value = vmed + wsg;
+    // the ratios are ascending, so both tests are true on a prefix of the lanes: the reference's two
+    // linear scans (kernels.cu:136-146) become population counts
+    const int below = __popcll(__ballot((lane < n) && (sv < min_value)));
+    const int upto = __popcll(__ballot((lane < n) && (sv <= max_value)));
+    const int min_keep = min(below, median_ind);
+    const int max_keep = max(median_ind + 1, upto) - 1;
+    float new_psi = 0.0f, new_phi = 0.0f;
+    for (int i = min_keep; i <= max_keep; ++i) {  // sorted-value order
+        new_psi += lane_value(spsi, i);
+        new_phi += lane_value(sphi, i);
+    }
+    *lh_out = lh_from_sums(new_psi, new_phi);
+    return true;
+}
+
 // Threshold / sigma-G / insertion of one chunk's C finished candidates.
 template <int KS, int C, bool SIGMAG>
 __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoords& tc, int chunk,
                                              const float (&ps)[C], const float (&ph)[C], const int (&cnt)[C],
                                              TopK<KS>& top, const SigmaGScratch<WAVE>& scratch) {
+    float lh[C];
+    bool take[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        lh[c] = lh_from_sums(ps[c], ph[c]);
+        take[c] = !(cnt[c] < a.params.min_observations);
+    }
+    if constexpr (SIGMAG) {
+        // kernels.cu:201-203: only trajectories that pass the unclipped thresholds are clipped (rare:
+        // min_lh rejects the noise); the rest either fail kernels.cu:318-320 or are the obs_count == 0
+        // corner.  Up to 64 epochs the wavefront clips them one at a time, together (clip_lh_wave).
+        uint64_t need[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const bool real = (chunk * C + c) < a.n_cands;  // uniform
+            need[c] = __ballot(real && take[c] && (cnt[c] != 0) && !(lh[c] < a.params.min_lh));
+        }
+        for (int c = 0; c < C; ++c) {  // not unrolled: one copy of the clip code
+            uint64_t m = 0;
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) m = (cc == c) ? need[cc] : m;
+            if (m == 0) continue;  // uniform
+            const int cand = chunk * C + c;
+            const float vx = a.cands[cand].vx, vy = a.cands[cand].vy;
+            float clipped = 0.0f;
+#ifndef KB_COOP_MAX
+#define KB_COOP_MAX 64  // ablation knob: clip cooperatively only when at most this many lanes need it
+#endif
+            // Measured on cfg2 + sigma-G (float array): every clip by the whole wave 54 ms, every clip by its
+            // own lane 295 ms, mixtures in between.  Quantised (uint8/uint16) arrays produce equal ratios all
+            // the time and end up in the per-lane code anyway (300 ms).
+            const bool cooperative = a.T <= WAVE && __popcll(m) <= KB_COOP_MAX;
+            uint64_t literal = cooperative ? 0 : m;  // lanes that run the literal per-lane code (all at once)
+            while (cooperative && m != 0) {
+                const int L = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                float r = 0.0f;
+                if (clip_lh_wave(a.meta, a.psi_phi, a.times, a.params.sgl_L, a.params.sgl_H, a.params.sigmag_coeff,
+                                 tc.tile_x0 + L, tc.y, vx, vy, &r)) {
+                    if (tc.lane == L) clipped = r;
+                } else {
+                    literal |= 1ull << L;  // equal ratios: the exchange sort's own order decides
+                }
+            }
+            if ((literal >> tc.lane) & 1) {
+                kb_trajectory trj;
+                trj.x = tc.x;
+                trj.y = tc.y;
+                trj.vx = vx;
+                trj.vy = vy;
+                evaluate_trajectory_full<WAVE>(a.meta, a.psi_phi, a.times, a.params, &trj, &scratch);
+                clipped = trj.lh;
+            }
+            uint64_t mc = 0;
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) mc = (cc == c) ? need[cc] : mc;
+            const bool mine = (mc >> tc.lane) & 1;
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                if (cc == c && mine) lh[cc] = clipped;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) take[c] = take[c] && !(lh[c] < a.params.min_lh);
+    }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const int cand = chunk * C + c;
         if (cand >= a.n_cands) break;  // uniform
-        float lh = lh_from_sums(ps[c], ph[c]);
-        bool take = !(cnt[c] < a.params.min_observations);
-        if constexpr (SIGMAG) {
-            // kernels.cu:201-203: only trajectories that pass the unclipped
-            // thresholds are clipped (rare: min_lh rejects the noise); the rest
-            // either fail kernels.cu:318-320 or are the obs_count == 0 corner.
-            const bool clip = take && (cnt[c] != 0) && !(lh < a.params.min_lh);
-            if (clip) {
-                kb_trajectory trj;
-                trj.x = tc.x;
-                trj.y = tc.y;
-                trj.vx = a.cands[cand].vx;
-                trj.vy = a.cands[cand].vy;
-                evaluate_trajectory_full<WAVE>(a.meta, a.psi_phi, a.times, a.params, &trj, &scratch);
-                lh = trj.lh;
-            }
-            take = take && !(lh < a.params.min_lh);
-        }
 #ifndef KB_SKIP_INSERT
-        if (take) top.insert(lh, cand);
+        if (take[c]) top.insert(lh[c], cand);
 #else
-        if (take && lh == 12345.0f) top.insert(lh, cand);
+        if (take[c] && lh[c] == 12345.0f) top.insert(lh[c], cand);
 #endif
     }
 }

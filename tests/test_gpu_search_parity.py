@@ -224,6 +224,32 @@ def test_sigma_g_low_threshold(kb, orc, kern):
     _check(got, exp)
 
 
+def test_sigma_g_more_than_64_epochs(kb, orc, kern):
+    # beyond one epoch per lane the clip runs per lane (the literal exchange sort)
+    st = util.make_stack(70, 24, 70, seed=6, objects=[(10, 8, 6.0, 2.0, 120.0)], mask_fraction=0.03)
+    vx, vy = fd.kbmod_v1_candidates(8, 2.0, 10.0, 5, 0.0, 0.8)
+    cfg = {"sigmag": (0.25, 0.75, 0.7413, 3.0), "min_obs": 20, "K": 4}
+    got, exp, _ = util.run_both(kb, orc, st, vx, vy, cfg, flags=KERNELS[kern])
+    _check(got, exp)
+    assert len(got) > 0
+
+
+def test_sigma_g_equal_ratios(kb, orc, kern):
+    # piecewise-constant images: many psi/phi ratios are exactly equal, and the order the reference's
+    # exchange sort leaves among them decides the summation order of the clipped sums
+    rng = np.random.default_rng(12)
+    st = util.make_stack(16, 30, 70, seed=12, noise=1.0, objects=[(12, 9, 5.0, 3.0, 90.0)])
+    for t in range(16):
+        st.sci[t][:, :] = np.round(st.sci[t] * 0.5) * 2.0  # a handful of distinct values
+        st.var[t][:, :] = np.float32(rng.choice([1.0, 2.0, 4.0]))
+    vx, vy = fd.kbmod_v1_candidates(8, 1.0, 9.0, 5, 0.0, 0.9)
+    cfg = {"sigmag": (0.25, 0.75, 0.7413, -100.0), "min_obs": 4, "K": 6}
+    got, exp, _ = util.run_both(kb, orc, st, vx, vy, cfg, flags=KERNELS[kern])
+    _check(got, exp)
+    got, exp, _ = util.run_both(kb, orc, st, vx, vy, cfg, num_bytes=1, flags=KERNELS[kern])
+    _check(got, exp)
+
+
 def test_half_integer_shifts_take_exact_path(kb, orc, kern):
     # vx * t + 0.5 lands exactly on integers: the shift table must refuse these.
     times = np.array([0.0, 0.25, 0.5, 0.75, 1.0, 1.5])
