@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void kb_coadd_kernel(const CoaddArgs a) {
 static std::mutex g_scratch_mutex;
 static float* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
+static int g_scratch_device = -1;
 
 }  // namespace kb
 
@@ -177,12 +178,15 @@ extern "C" int kb_coadd_stamps(const float* sci_dev, const float* var_dev, int32
             const uint64_t per = std::max<uint64_t>(1, (uint64_t)num_times) * s2 * sizeof(float);
             batch = std::max<uint64_t>(1, std::min<uint64_t>(batch, (256ull << 20) / per));
             const size_t need = (size_t)(batch * per);
-            if (g_scratch_bytes < need) {
+            int dev = 0;
+            KB_HIP_TRY(hipGetDevice(&dev));
+            if (g_scratch_bytes < need || g_scratch_device != dev) {
                 if (g_scratch) (void)hipFree(g_scratch);
                 g_scratch = nullptr;
                 g_scratch_bytes = 0;
                 KB_HIP_TRY(hipMalloc(&g_scratch, need));
                 g_scratch_bytes = need;
+                g_scratch_device = dev;
             }
             a.scratch = g_scratch;
         }
