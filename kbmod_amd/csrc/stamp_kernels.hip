@@ -127,6 +127,66 @@ __global__ __launch_bounds__(256) void kb_coadd_kernel(const CoaddArgs a) {
     }
 }
 
+// Median coadd for stacks of at most 64 epochs: the pixel's values live in 64 registers as
+// order-preserving keys (NaN and unused slots = maximum) and go through a fully unrolled bitonic
+// network (672 compare-exchanges of v_min_u32 / v_max_u32); the lower median is the key at index
+// (n_valid - 1) / 2.  No scratch, no data-dependent loop.
+__device__ __forceinline__ uint32_t median_key(float v) {
+    if (v != v) return 0xffffffffu;
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void kb_coadd_median64_kernel(const CoaddArgs a) {
+    const uint64_t n = a.n0 + blockIdx.x;
+    const int S2 = a.S * a.S;
+    const int32_t* __restrict__ xs = a.x + n * (uint64_t)a.T;
+    const int32_t* __restrict__ ys = a.y + n * (uint64_t)a.T;
+    const uint8_t* __restrict__ inc = a.include ? a.include + n * (uint64_t)a.T : nullptr;
+    const size_t image = (size_t)a.H * a.W;
+    for (int pix = threadIdx.x; pix < S2; pix += blockDim.x) {
+        const int j = pix / a.S, i = pix - j * a.S;
+        uint32_t key[64];
+        int n_valid = 0, used = 0;
+#pragma unroll
+        for (int t = 0; t < 64; ++t) {
+            float v = __uint_as_float(0x7fc00000u);
+            if (t < a.T && (!inc || inc[t])) {  // uniform
+                v = stamp_pixel(a.sci + t * image, a.H, a.W, xs[t], ys[t], a.radius, j, i);
+                ++used;
+            }
+            key[t] = median_key(v);
+            n_valid += (v == v) ? 1 : 0;
+        }
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+#pragma unroll
+                for (int p = 0; p < 64; ++p) {
+                    const int q = p ^ jj;
+                    if (q > p) {
+                        const uint32_t lo = min(key[p], key[q]), hi = max(key[p], key[q]);
+                        const bool up = (p & k) == 0;
+                        key[p] = up ? lo : hi;
+                        key[q] = up ? hi : lo;
+                    }
+                }
+            }
+        }
+        float res = 0.0f;  // nothing selected or nothing valid: zero (stamp_utils.py:294-302)
+        if (n_valid > 0) {
+            const int m = (n_valid - 1) / 2;
+            uint32_t km = 0;
+#pragma unroll
+            for (int t = 0; t < 64; ++t) km = (t == m) ? key[t] : km;
+            res = __uint_as_float((km & 0x80000000u) ? (km & 0x7fffffffu) : ~km);
+        }
+        (void)used;
+        a.out[n * (uint64_t)S2 + pix] = res;
+    }
+}
+
 static std::mutex g_scratch_mutex;
 static float* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
@@ -167,7 +227,8 @@ extern "C" int kb_coadd_stamps(const float* sci_dev, const float* var_dev, int32
     constexpr int MEDIAN_LDS_BYTES = 32768;
     a.lds_pixels = 0;
     size_t lds_bytes = 0;
-    if (coadd_type == KB_COADD_MEDIAN) {
+    const bool median64 = coadd_type == KB_COADD_MEDIAN && num_times <= 64;
+    if (coadd_type == KB_COADD_MEDIAN && !median64) {
         const int fit = num_times > 0 ? MEDIAN_LDS_BYTES / (int)(sizeof(float) * num_times) : (int)threads;
         if (fit >= 16) {
             a.lds_pixels = std::min<int>((int)threads, fit);
@@ -202,7 +263,11 @@ extern "C" int kb_coadd_stamps(const float* sci_dev, const float* var_dev, int32
                 hipLaunchKernelGGL((kb_coadd_kernel<KB_COADD_MEAN>), dim3(blocks), dim3(threads), 0, stream, a);
                 break;
             case KB_COADD_MEDIAN:
-                hipLaunchKernelGGL((kb_coadd_kernel<KB_COADD_MEDIAN>), dim3(blocks), dim3(threads), lds_bytes, stream, a);
+                if (median64) {
+                    hipLaunchKernelGGL(kb_coadd_median64_kernel, dim3(blocks), dim3(threads), 0, stream, a);
+                } else {
+                    hipLaunchKernelGGL((kb_coadd_kernel<KB_COADD_MEDIAN>), dim3(blocks), dim3(threads), lds_bytes, stream, a);
+                }
                 break;
             default:
                 hipLaunchKernelGGL((kb_coadd_kernel<KB_COADD_WEIGHTED>), dim3(blocks), dim3(threads), 0, stream, a);

@@ -89,6 +89,15 @@ def test_coadds_equal_oracle(su, radius, use_mask):
         assert np.array_equal(got[c], exp[c], equal_nan=True), c
 
 
+def test_median_between_65_and_512_epochs_uses_lds_columns(su):
+    sci, var, times, x0, y0, vx, vy, obs_valid = _random_case(78, 90, 24, 30, 8)
+    xv = ps.predict_pixel_locations(times, x0, vx * 0.3)
+    yv = ps.predict_pixel_locations(times, y0, vy * 0.3)
+    got = su.DeviceStack(sci).coadds(xv, yv, 3, ["median"], to_include=obs_valid)
+    exp = ps.coadds_for_trajectories(sci, None, xv, yv, obs_valid, 3, ["median"])
+    assert np.array_equal(got["median"], exp["median"])
+
+
 def test_median_of_a_long_stack_uses_the_scratch_path(su):
     # more than 512 epochs: the per-pixel columns no longer fit the LDS buffer
     sci, var, times, x0, y0, vx, vy, obs_valid = _random_case(77, 600, 24, 30, 6)
