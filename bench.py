@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--flags", type=int, default=0, help="kb_device_search_filter flags (1 exact positions, 4 LDS-staged kernel)")
     ap.add_argument("--sigmag", action="store_true",
                     help="BASELINE configs[2]: in-kernel sigma-G ([25, 75] percentiles, coeff 0.7413, min_lh 10), min_obs T/2")
+    ap.add_argument("--mask-fraction", type=float, default=0.0,
+                    help="fraction of science pixels set to NaN before psi/phi is built (default 0: the BASELINE stack "
+                         "has no masked pixels, so most tiles of kb_search_lds take its count-free path)")
     ap.add_argument("--min-lh", type=float, default=None, help="override the likelihood threshold (default 0, 10 with --sigmag)")
     ap.add_argument("--verify", action="store_true",
                     help="after timing: size-independent checks of the last result buffer (both kernels agree bit for "
@@ -143,6 +146,9 @@ def main():
             r = psf.shape[0] // 2
             if r <= px < W - r and r <= py < H - r:
                 sci[t, py - r:py + r + 1, px - r:px + r + 1] += torch.from_numpy(300.0 * psf).to(dev)
+
+    if args.mask_fraction > 0.0:
+        sci[torch.rand((T, H, W), generator=gen, device=dev) < args.mask_fraction] = float("nan")
 
     psf_all = np.ascontiguousarray(np.tile(psf.ravel(), T), dtype=np.float32)
     psf_dims = np.full(T, psf.shape[0], dtype=np.int32)
@@ -235,7 +241,8 @@ def main():
         "config": {
             "workload": f"{T}x{H}x{W} psi/phi ({'float32' if args.num_bytes in (-1, 4) else 'uint%d' % (8 * args.num_bytes)}), "
                         f"full {W}x{H} start grid x {n_local} (v,theta) candidates per GPU, K=8, "
-                        f"sigma-G {'on, min_obs %d' % (T // 2) if args.sigmag else 'off'}",
+                        f"sigma-G {'on, min_obs %d' % (T // 2) if args.sigmag else 'off'}"
+                        + (f", {args.mask_fraction:g} of the science pixels masked" if args.mask_fraction > 0 else ""),
             "frames": T, "height": H, "width": W, "candidates_per_gpu": n_local, "results_per_pixel": K,
             "sharding": "candidates (v,theta) by rank; psi/phi replicated; one RCCL all_gather + per-pixel merge"
                         if world > 1 else "none",
