@@ -13,11 +13,20 @@ resident in HBM (the psi/phi array is built on the device by the HIP builder
 before the timed region).  torch is plumbing only: device memory, the stream,
 and torch.distributed (RCCL) for the multi-GPU gather.
 
-Multi-GPU (N > 1): one process per GPU; the candidate list is sharded into N
-contiguous (v, theta) slices (weak scaling: every rank searches the full start
-grid over `--cands` candidates of its own, so per-GPU work is fixed), psi/phi is
-replicated, and the per-rank per-pixel top-K lists are exchanged with ONE RCCL
-all_gather followed by a per-pixel K-way merge on the device.
+Multi-GPU (N > 1): one process per GPU (started by the driver's torch.distributed.run
+command, or by this script itself when WORLD_SIZE is not set); the candidate list is
+sharded into N contiguous (v, theta) slices (weak scaling: every rank searches the full
+start grid over its own 1024 candidates, so per-GPU work is fixed), psi/phi is
+replicated, every rank leaves 16-byte records per slot (kb_device_search_compact) and
+ONE RCCL gather to rank 0 followed by a per-pixel K-way merge there (kb_merge_compact)
+produces the job's result lists.
+
+roofline: the 134 MB psi/phi array of the headline configuration lives in L2 / Infinity
+Cache and the sums read LDS, so the report names the binding resource it measured --
+LDS read bytes against the aggregate LDS rate for kb_search_lds -- next to the
+algorithmic rate, the nominal and the measured HBM peak (a device copy
+kernel timed in this run) and, where a rocprofv3 PMC profile of the same configuration
+exists under profiles/, the fabric-side bytes per launch.
 """
 
 import argparse
@@ -32,47 +41,32 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+LDS_PEAK_GBPS = 150000.0  # aggregate ds_read_b64 rate with every CU streaming (MI355X_MICROARCH.md, LDS section)
 
-
-class Meta(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("num_times", "width", "height", "pixels_per_image", "num_entries",
-                                          "block_size", "total_array_size")] + [
-        ("num_bytes", C.c_int32), ("psi_min_val", C.c_float), ("psi_max_val", C.c_float), ("psi_scale", C.c_float),
-        ("phi_min_val", C.c_float), ("phi_max_val", C.c_float), ("phi_scale", C.c_float)]
-
-
-class Params(C.Structure):
-    _fields_ = [("min_observations", C.c_int32), ("min_lh", C.c_float), ("do_sigmag_filter", C.c_uint8),
-                ("sgl_L", C.c_float), ("sgl_H", C.c_float), ("sigmag_coeff", C.c_float),
-                ("encode_num_bytes", C.c_int32), ("x_start_min", C.c_int32), ("x_start_max", C.c_int32),
-                ("y_start_min", C.c_int32), ("y_start_max", C.c_int32), ("results_per_pixel", C.c_uint32),
-                ("total_results", C.c_ulonglong)]
-
-
-class Stats(C.Structure):
-    _fields_ = [("search_kernel_ms", C.c_float), ("table_kernel_ms", C.c_float), ("num_evals", C.c_uint64),
-                ("algorithmic_bytes", C.c_uint64), ("kernel_variant", C.c_int32), ("num_search_launches", C.c_int32)]
-
-
-def load_lib():
-    path = os.environ.get("KBMOD_HIP_LIB", os.path.join(ROOT, "kbmod_amd", "lib", "libkbmod_hip.so"))
-    if not os.path.exists(path):
-        raise RuntimeError("libkbmod_hip.so is not built (run __graft_entry__.build()); there is no fallback path")
-    lib = C.CDLL(path)
-    lib.kb_last_error.restype = C.c_char_p
-    lib.kb_build_psi_phi_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                                 C.c_int32, C.c_int32, C.POINTER(Meta), C.POINTER(C.c_void_p), C.c_void_p]
-    lib.kb_device_search_filter.argtypes = [C.POINTER(Meta), C.c_void_p, C.c_void_p, Params, C.c_void_p, C.c_uint64,
-                                            C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
-    lib.kb_free_gpu_block.argtypes = [C.c_void_p]
-    lib.kb_copy_block_to_cpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
-    return lib
+from kbmod_amd.capi import Meta, Params, Stats, load_lib  # noqa: E402
 
 
 def check(lib, rc):
     if rc != 0:
         raise RuntimeError(lib.kb_last_error().decode())
+
+
+def self_launch(args_list, n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the
+    same command the driver would issue) and pass their output through."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + args_list
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -104,23 +98,28 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the CPU baseline sample")
     args = ap.parse_args()
 
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+
     import torch
     import torch.distributed as dist
 
     from kbmod_amd import distributed as kdist
     from kbmod_amd import fake_data as fd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the search has no CPU fallback")
+    if world != args.gpus:
+        raise RuntimeError(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
 
     lib = load_lib()
     T, H, W = args.frames, args.size, args.size
@@ -168,13 +167,13 @@ def main():
                                     args.max_ang)
     n_local = args.vel_steps * args.ang_steps
     sl = slice(rank * n_local, (rank + 1) * n_local)
-    cands_np = np.zeros((n_local, 7), dtype=np.float32)
-    cands_np[:, 0], cands_np[:, 1] = vx[sl], vy[sl]
-    cands = torch.from_numpy(cands_np).to(dev)
+    all_np = np.zeros((n_local * world, 7), dtype=np.float32)
+    all_np[:, 0], all_np[:, 1] = vx, vy
+    all_cands = torch.from_numpy(all_np).to(dev)   # the job-wide list (the merge on rank 0 indexes it)
+    cands = all_cands[sl]                           # this rank's slice
 
     ins = args.inset
     S = (H - 2 * ins) * (W - 2 * ins)
-    results = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
     nb_param = -1 if args.num_bytes in (-1, 4) else args.num_bytes
     if args.sigmag:
         params = Params(T // 2, 10.0 if args.min_lh is None else args.min_lh, 1, 0.25, 0.75, 0.7413, nb_param, ins, W - ins,
@@ -182,17 +181,26 @@ def main():
     else:
         params = Params(0, 0.0 if args.min_lh is None else args.min_lh, 0, 0.25, 0.75, -1.0, nb_param, ins, W - ins, ins,
                         H - ins, K, 0)
-    gathered = torch.empty((world, S * K, 7), dtype=torch.float32, device=dev) if world > 1 else None
-    merged = torch.empty((S * K, 7), dtype=torch.float32, device=dev) if world > 1 else None
+    if world > 1:
+        records = torch.empty((S * K, 4), dtype=torch.int32, device=dev)  # kb_compact_result per slot
+        gathered = torch.empty((world, S * K, 4), dtype=torch.int32, device=dev) if rank == 0 else None
+        results = torch.empty((S * K, 7), dtype=torch.float32, device=dev) if rank == 0 else None
+    else:
+        results = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
 
     kernel_ms = []
 
     def step(record):
         st = Stats()
-        check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), n_local,
-                                               results.data_ptr(), S * K, args.flags, stream, C.byref(st)))
         if world > 1:
-            kdist.gather_and_merge(results, S, K, gathered=gathered, out=merged)
+            check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), n_local,
+                                                    rank * n_local, records.data_ptr(), S * K, args.flags, stream,
+                                                    C.byref(st)))
+            kdist.gather_and_merge_compact(records, (ins, W - ins), (ins, H - ins), K, all_cands, gathered=gathered,
+                                           out=results)
+        else:
+            check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), n_local,
+                                                   results.data_ptr(), S * K, args.flags, stream, C.byref(st)))
         if record:
             kernel_ms.append(st.search_kernel_ms)
         return st
@@ -223,7 +231,37 @@ def main():
     k_ms = float(np.mean(kernel_ms))
     # kb_search_stats.kernel_variant: 0xxxx = kb_search_direct, 1xxxx / 2xxxx = kb_search_lds (encoded / float copy)
     kernel_name = "kb_search_direct" if int(last.kernel_variant) // 10000 == 0 else "kb_search_lds"
-    achieved = float(last.algorithmic_bytes) / (k_ms * 1e-3) / 1e9
+    alg_rate = float(last.algorithmic_bytes) / (k_ms * 1e-3) / 1e9
+    dtype = {-1: "f32", 4: "f32", 1: "u8", 2: "u16"}[args.num_bytes]
+
+    # measured HBM peak: a streaming device copy (1 GiB each way) timed with HIP events in this run
+    copy_gbps = C.c_double(0.0)
+    check(lib, lib.kb_measure_copy_bandwidth(1 << 30, 10, stream, C.byref(copy_gbps)))
+
+    # fabric-side traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (it cannot be
+    # read from inside this process); attached when the workload matches a profiled configuration.
+    traffic = traffic_source = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            table = json.load(fh)
+        key = f"{dtype}:{T}x{H}x{W}:{n_local}:{kernel_name}" + (":sigmag" if args.sigmag else "")
+        if key in table:
+            traffic, traffic_source = table[key]["bytes"], table[key]["source"]
+    except (OSError, ValueError):
+        pass
+
+    # The binding resource.  kb_search_lds sums out of LDS: every evaluation is one 8-byte ds_read_b64
+    # lane read.  When the array (and its padded float copy) exceeds the 256 MiB Infinity Cache the
+    # fabric-side bytes are HBM bytes and the HBM line is the one to read.
+    lds_rate = float(last.lds_read_bytes) / (k_ms * 1e-3) / 1e9
+    candidates = []
+    if last.lds_read_bytes:
+        candidates.append(("lds", lds_rate, LDS_PEAK_GBPS))
+    if traffic is not None:
+        candidates.append(("hbm", traffic / (k_ms * 1e-3) / 1e9, HBM_PEAK_GBPS))
+    if not candidates:  # kb_search_direct without a profile: the algorithmic rate is all there is
+        candidates.append(("hbm", alg_rate, HBM_PEAK_GBPS))
+    bound, achieved, peak = max(candidates, key=lambda c: c[1] / c[2])
 
     out = {
         "metric": "trajectory-epoch evals/sec",
@@ -236,7 +274,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {-1: "f32", 4: "f32", 1: "u8", 2: "u16"}[args.num_bytes],
+        "dtype": dtype,
         "data": "synthetic",
         "config": {
             "workload": f"{T}x{H}x{W} psi/phi ({'float32' if args.num_bytes in (-1, 4) else 'uint%d' % (8 * args.num_bytes)}), "
@@ -244,35 +282,37 @@ def main():
                         f"sigma-G {'on, min_obs %d' % (T // 2) if args.sigmag else 'off'}"
                         + (f", {args.mask_fraction:g} of the science pixels masked" if args.mask_fraction > 0 else ""),
             "frames": T, "height": H, "width": W, "candidates_per_gpu": n_local, "results_per_pixel": K,
-            "sharding": "candidates (v,theta) by rank; psi/phi replicated; one RCCL all_gather + per-pixel merge"
-                        if world > 1 else "none",
+            "sharding": "candidates (v,theta) by rank; psi/phi replicated; one RCCL gather of 16-byte records to rank 0 "
+                        "+ per-pixel merge" if world > 1 else "none",
             "psi_phi_build_ms": build_ms,
         },
         "roofline": {
-            "bound": "hbm",
+            "bound": bound,
             "achieved": achieved,
-            "peak": HBM_PEAK_GBPS,
+            "peak": peak,
             "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
+            "frac": achieved / peak,
+            "traffic": traffic,
+            "traffic_source": traffic_source,
             "kernel": kernel_name,
             "kernel_ms": k_ms,
-            "algorithmic_bytes_per_launch": int(last.algorithmic_bytes),
             "kernel_evals_per_s": evals_per_step_rank / (k_ms * 1e-3),
+            "lds_read_bytes_per_launch": int(last.lds_read_bytes),
+            "lds_read_GBps": lds_rate,
+            "lds_peak_GBps": LDS_PEAK_GBPS,
+            "algorithmic_bytes_per_launch": int(last.algorithmic_bytes),
+            "algorithmic_GBps": alg_rate,
+            "algorithmic_vs_hbm_peak": alg_rate / HBM_PEAK_GBPS,
+            "hbm_peak_nominal_GBps": HBM_PEAK_GBPS,
+            "hbm_measured_peak": float(copy_gbps.value),
+            "fabric_GBps": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9,
+            "fabric_frac_of_measured_peak": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9 / copy_gbps.value,
+            "psi_phi_bytes": int(meta.total_array_size),
         },
     }
-
-    # HBM-side traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (it cannot be
-    # read from inside this process); attached when the workload matches a profiled configuration.
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            traffic = json.load(fh)
-        key = f"{out['dtype']}:{T}x{H}x{W}:{n_local}:{kernel_name}"
-        if key in traffic:
-            out["roofline"]["traffic"] = traffic[key]["bytes"]
-            out["roofline"]["traffic_source"] = traffic[key]["source"]
-    except (OSError, ValueError):
-        pass
+    if args.sigmag:
+        out["config"]["sigmag_work_items"] = int(last.sigmag_work_items)
+        out["config"]["sigmag_trajectories_clipped"] = int(last.sigmag_trajectories)
 
     if args.verify and world == 1:
         out["verify"] = verify(lib, torch, meta, arr, times, params, cands, n_local, results, S, K, ins, W, H, last, stream)

@@ -61,6 +61,9 @@ typedef struct kb_search_stats {
     uint64_t algorithmic_bytes; /* num_evals*2*bs + S*K*28 + N_c*28 + T*8 */
     int32_t kernel_variant;   /* which template instance ran */
     int32_t num_search_launches;
+    uint64_t sigmag_work_items;   /* in-search sigma-G: (row of 64 start pixels, candidate) pairs with a trajectory to clip */
+    uint64_t sigmag_trajectories; /* ... and the trajectories clipped */
+    uint64_t lds_read_bytes;      /* kb_search_lds: bytes the sums read out of LDS (num_evals x staged pair size), else 0 */
 } kb_search_stats;
 
 const char* kb_last_error(void);
@@ -76,6 +79,9 @@ int kb_free_gpu_block(void* ptr_dev);                                           
 int kb_copy_block_to_gpu(const void* src_host, void* dst_dev, uint64_t memory_size); /* :112 */
 int kb_copy_block_to_cpu(void* dst_host, const void* src_dev, uint64_t memory_size); /* :124 */
 int kb_device_synchronize(void);
+/* new: streaming device-to-device copy of `bytes`, `iters` timed passes; *gbps_out = (read + written bytes) / time.
+ * The measured HBM peak of the roofline report (bench.py). */
+int kb_measure_copy_bandwidth(uint64_t bytes, int32_t iters, void* stream, double* gbps_out);
 
 /* ---- PSF convolution: kernels/image_kernels.cu:68-108 (deviceConvolve) --- */
 /* Host image in, host image out, one image.  empty_is_nan = 0 reproduces the
@@ -130,6 +136,20 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
 
 int kb_release_workspaces(void);
 
+/* ---- the same search with 16-byte result records (new; multi-GPU exchange format).  x / y follow from the
+ * slot, vx / vy from the candidate: a record carries (lh, flux, candidate index, obs_count), 16 instead of
+ * 28 bytes per slot on the wire.  cand holds cand_index_base + the index into cands_dev (the index into
+ * the job-wide candidate list when each GPU searches a contiguous slice); empty slots carry
+ * cand = -1, lh = -FLT_MAX.  results_per_pixel <= 32. */
+typedef struct kb_compact_result {
+    float lh, flux;
+    int32_t cand, obs_count;
+} kb_compact_result;
+int kb_device_search_compact(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
+                             kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
+                             int32_t cand_index_base, kb_compact_result* results_dev, uint64_t n_results, uint32_t flags,
+                             void* stream, kb_search_stats* stats_out);
+
 /* ---- result post-processing in HBM: the filter_by_likelihood / filter_by_obs_count /
  * sort_by_likelihood sequence of stack_search.cpp:266-281 (trajectory_list.cpp:96-126).
  * results_dev: n trajectories (the slots written by kb_device_search_filter); out_dev: room for n.
@@ -182,6 +202,12 @@ int kb_coadd_stamps(const float* sci_dev, const float* var_dev, int32_t num_time
  * [n_pixels][K].  Ties go to the lower list, then the lower slot. */
 int kb_merge_topk(const kb_trajectory* lists_dev, int32_t n_lists, uint64_t n_pixels, int32_t K,
                   kb_trajectory* out_dev, void* stream);
+/* Same merge on the compact records of kb_device_search_compact, gathered to one GPU as
+ * lists_dev = [n_lists][n_pixels][K]; writes full trajectories (x, y from the slot and the start bounds of
+ * params, vx / vy from all_cands_dev, the job-wide candidate list the records index).  The output equals
+ * what one GPU produces on the whole candidate list, ties included (lower list = lower candidate index). */
+int kb_merge_compact(const kb_compact_result* lists_dev, int32_t n_lists, kb_search_params params,
+                     const kb_trajectory* all_cands_dev, uint64_t n_all_cands, kb_trajectory* out_dev, void* stream);
 
 /* ---- host instantiations of the device functions ------------------------- */
 /* kernels.cu:154-242 evaluateTrajectory called with host pointers
@@ -191,6 +217,14 @@ int kb_evaluate_trajectory_host(const kb_psi_phi_meta* meta, const void* psi_phi
 /* kernels.cu:77-147 SigmaGFilteredIndicesCU (kernel_helpers.cpp:94). */
 void kb_sigmag_filtered_indices(const float* values, int num_values, float sgl0, float sgl1, float sigmag_coeff,
                                 float width, int* idx_array, int* min_keep_idx, int* max_keep_idx);
+
+/* ---- self-test of the wavefront primitives behind the in-search sigma-G clip (new; tests only).
+ * keys_dev: [n_waves][64] uint32 -> keys_out_dev ascending per wave, src_out_dev the lane each key came
+ * from (DPP / permlane-swap sorting network).  values_dev: [n_waves][64] float32, bounds_dev:
+ * [n_waves][2] (lo, hi) -> sums_dev[w] = ((0 + v[lo]) + v[lo+1]) + ... + v[hi] chained across the lanes.
+ * Either half may be skipped with NULL inputs.  Synchronises the stream. */
+int kb_debug_wave_ops(const uint32_t* keys_dev, uint32_t* keys_out_dev, uint32_t* src_out_dev, const float* values_dev,
+                      const int32_t* bounds_dev, float* sums_dev, uint64_t n_waves, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,8 +19,8 @@ _CSRC = os.path.join(_PKG, "csrc")
 _INC = os.path.join(_ROOT, "include")
 _LIBDIR = os.path.join(_PKG, "lib")
 
-HIP_SOURCES = ["device_memory.hip", "image_kernels.hip", "search_kernels.hip", "result_kernels.hip", "stamp_kernels.hip"]
-HIP_HEADERS = ["kb_common.h", "search_math.h"]
+HIP_SOURCES = ["device_memory.hip", "image_kernels.hip", "search_kernels.hip", "sigmag_kernels.hip", "result_kernels.hip", "stamp_kernels.hip"]
+HIP_HEADERS = ["kb_common.h", "search_math.h", "search_common.h", "wave_ops.h"]
 HOST_SOURCES = ["host/bindings.cpp"]
 HOST_HEADERS = ["host/common.h", "host/image_utils.h", "host/psi_phi_array.h", "host/trajectory_list.h",
                 "host/stack_search.h", "host/device_stack.h"]

@@ -1,6 +1,8 @@
 // Device discovery and raw HBM block management for libkbmod_hip.so.
 // Replaces kernels/kernel_memory.cu:15-136 of the reference (same roles, HIP
 // runtime underneath, status codes instead of exceptions across the C ABI).
+#include <algorithm>
+
 #include "kb_common.h"
 
 namespace kb {
@@ -9,6 +11,11 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 int fail(const std::string& msg) {
     set_error(msg);
     return 1;
+}
+// Streaming copy used to measure what HBM delivers on this device (the "measured peak" next to the
+// nominal 8 TB/s in the roofline report): 16 bytes per lane, grid-stride.
+__global__ __launch_bounds__(256) void kb_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 }  // namespace kb
 
@@ -95,6 +102,41 @@ int kb_copy_block_to_cpu(void* dst_host, const void* src_dev, uint64_t memory_si
     if (dst_host == nullptr) return kb::fail("Invalid CPU pointer");
     if (src_dev == nullptr) return kb::fail("Invalid GPU pointer");
     KB_HIP_TRY(hipMemcpy(dst_host, src_dev, memory_size, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Copies `bytes` (rounded down to 16) from one scratch block to another `iters` times after one untimed
+// pass and reports read + write bytes over the HIP-event time of the timed passes, in GB/s.
+int kb_measure_copy_bandwidth(uint64_t bytes, int32_t iters, void* stream_v, double* gbps_out) {
+    using namespace kb;
+    if (gbps_out == nullptr || iters <= 0 || bytes < 16) return fail("measure_copy_bandwidth: bad argument");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    const size_t n = (size_t)(bytes / 16);
+    void *src = nullptr, *dst = nullptr;
+    KB_HIP_TRY(hipMalloc(&src, n * 16));
+    if (hipMalloc(&dst, n * 16) != hipSuccess) {
+        (void)hipFree(src);
+        return fail("measure_copy_bandwidth: out of device memory");
+    }
+    (void)hipMemsetAsync(src, 1, n * 16, stream);
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+    float ms = 0.0f;
+    {
+        EventTimer timer(stream, true);
+        hipLaunchKernelGGL(kb_copy_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4*>(src),
+                           reinterpret_cast<uint4*>(dst), n);
+        timer.begin();
+        for (int i = 0; i < iters; ++i) {
+            hipLaunchKernelGGL(kb_copy_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4*>(src),
+                               reinterpret_cast<uint4*>(dst), n);
+        }
+        ms = timer.end();
+    }
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    KB_HIP_TRY(hipGetLastError());
+    if (!(ms > 0.0f)) return fail("measure_copy_bandwidth: no time measured");
+    *gbps_out = 2.0 * (double)(n * 16) * iters / ((double)ms * 1e-3) / 1e9;
     return 0;
 }
 

@@ -185,5 +185,50 @@ inline std::vector<Trajectory> merge_topk_host(const Trajectory* lists, int n_li
     return out;
 }
 
+// Host twin of kb_merge_compact: the same merge on the 16-byte exchange records
+// (kb_compact_result), producing full trajectories.  sw = width of the search area.
+inline std::vector<Trajectory> merge_compact_host(const kb_compact_result* lists, int n_lists, uint64_t n_pixels, int K,
+                                                  int sw, int x_min, int y_min, const Trajectory* all_cands,
+                                                  uint64_t n_all_cands) {
+    std::vector<Trajectory> out(n_pixels * (uint64_t)K);
+    const uint64_t stride = n_pixels * (uint64_t)K;
+    std::vector<int> head(n_lists);
+    for (uint64_t pix = 0; pix < n_pixels; ++pix) {
+        std::fill(head.begin(), head.end(), 0);
+        const int y_i = (int)(pix / (uint64_t)sw), x_i = (int)(pix % (uint64_t)sw);
+        for (int s = 0; s < K; ++s) {
+            int best = -1;
+            float best_lh = 0.0f;
+            for (int r = 0; r < n_lists; ++r) {
+                if (head[r] >= K) continue;
+                const float lh = lists[(uint64_t)r * stride + pix * K + head[r]].lh;
+                if (best < 0 || lh > best_lh) {
+                    best = r;
+                    best_lh = lh;
+                }
+            }
+            const kb_compact_result rec = lists[(uint64_t)best * stride + pix * K + head[best]];
+            head[best] += 1;
+            Trajectory t;
+            t.x = x_i + x_min;
+            t.y = y_i + y_min;
+            t.vx = 0.0f;
+            t.vy = 0.0f;
+            t.lh = -FLT_MAX;
+            t.flux = 0.0f;
+            t.obs_count = 0;
+            if (rec.cand >= 0 && (uint64_t)rec.cand < n_all_cands) {
+                t.vx = all_cands[rec.cand].vx;
+                t.vy = all_cands[rec.cand].vy;
+                t.lh = rec.lh;
+                t.flux = rec.flux;
+                t.obs_count = rec.obs_count;
+            }
+            out[pix * K + s] = t;
+        }
+    }
+    return out;
+}
+
 }  // namespace search
 #endif

@@ -1,0 +1,306 @@
+// Types and device helpers shared by the translation units of the trajectory search
+// (search_kernels.hip: shift table, kb_search_lds / kb_search_direct / kb_search_large_k and the
+// launcher; sigmag_kernels.hip: the sigma-G resolve passes).
+#ifndef KB_SEARCH_COMMON_H_
+#define KB_SEARCH_COMMON_H_
+
+#include "kb_common.h"
+#include "search_math.h"
+
+#pragma clang fp contract(off)
+
+namespace kb {
+
+constexpr int SHIFT_UNSAFE = INT32_MIN;  // dx marker: no uniform shift proven for this (candidate, epoch)
+constexpr int TILE_ROWS = 4;             // waves (rows) per 256-thread workgroup
+constexpr int CHUNK = 8;                 // candidates accumulated together per wave
+
+// LDS staging (kb_search_lds): per (chunk, epoch) the workgroup stages a slab of
+// rows_max(chunk) x LDS_COLS raw pairs -- the union footprint of its 64 x 4 tile
+// under the chunk's shifts -- straight from a padded HBM copy of the array into
+// LDS with LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), several epochs
+// per barrier, double-buffered.
+constexpr int LDS_COLS = 88;          // slab pitch in pixels: 64 start columns + up to 24 of dx spread
+                                      // (88 * {8,4,2} bytes are multiples of the 16-byte DMA granule)
+constexpr int LDS_GROUP_BYTES = 20480;  // one group buffer; two per workgroup = 40 KiB -> 4 workgroups per CU
+constexpr int LDS_ALIGN_PX = 8;         // slab origins are multiples of 8 columns of the padded frame
+constexpr int LDS_SLOTS = 3;            // 16-byte pieces a thread holds in registers at once; slabs beyond
+                                        // 3 x 4 KiB are copied in further, non-overlapped rounds
+
+struct ChunkInfo {
+    int dx_min, dx_max, dy_min, dy_max;  // bounding box of the chunk's shifts over all epochs
+    int unsafe;                          // any entry flagged SHIFT_UNSAFE
+    int lds_ok;                          // every epoch's footprint fits one LDS slab
+    int rows_max;                        // TILE_ROWS + largest dy spread of any epoch (slab height)
+    int pad;
+};
+
+// Per (chunk, epoch) footprint, packed for one 8-byte scalar load:
+//   x = (dy_min << 16) | (dx_min & 0xffff)   origin of the staged region relative to the tile
+//   y = (rows   << 16) | cols                64 + dx spread, TILE_ROWS + dy spread
+using EpochBox = int2;
+constexpr int BOX_NOT_STAGED = (int)0x80008000u;  // word 0 of an epoch that kb_search_lds does not stage
+constexpr int LDS_OFF_UNSTAGED = -1;
+constexpr int LDS_OFF_PER_LANE = -2;
+__host__ __device__ __forceinline__ int box_dx(EpochBox b) { return (int)(short)(b.x & 0xffff); }
+__host__ __device__ __forceinline__ int box_dy(EpochBox b) { return b.x >> 16; }
+__host__ __device__ __forceinline__ int box_cols(EpochBox b) { return b.y & 0xffff; }
+__host__ __device__ __forceinline__ int box_rows(EpochBox b) { return b.y >> 16; }
+
+// Sigma-G resolve (sigmag_kernels.hip).  With the in-search sigma-G filter the search kernels do not
+// keep a top-K: per (row of 64 start pixels, candidate) they emit the ballot of the lanes that pass the
+// unclipped thresholds (kernels.cu:201-203) as one work item; kb_sigmag_clip_kernel clips those
+// trajectories spread evenly over the whole device, kb_sigmag_select_kernel runs the per-pixel
+// insertion over the clipped likelihoods in candidate order.
+struct SgEntry {
+    uint32_t row;   // y_i * tiles_x + tx: 64 consecutive start pixels of one row
+    uint32_t cand;  // candidate index
+    uint64_t mask;  // lanes (start pixels) whose trajectory is clipped
+};
+struct SigmaGWork {
+    uint32_t* slots;   // [rows][batch_cands]: entry index + 1 of (row, candidate), 0 = nothing passed
+    SgEntry* entries;  // [capacity]
+    int* n_entries;    // device counter of the batch in flight
+    unsigned long long* totals;  // {work items, trajectories} of the whole search
+    float* lh;         // [capacity][64] clipped likelihood of the entry's lanes
+    float* flux;       // [capacity][64]
+    int* obs;          // [capacity][64]
+    int cand_lo;       // first candidate of the batch in flight
+    int batch_cands;   // candidates per batch (row pitch of slots)
+};
+
+// Where a per-pixel list goes: 28-byte trajectories (kb_device_search_filter) or the 16-byte records of
+// kb_device_search_compact.  Exactly one pointer is set.
+struct ResultSink {
+    kb_trajectory* full;
+    kb_compact_result* compact;
+    int cand_base;  // added to the candidate index of a compact record
+};
+// cand < 0: the placeholder of an empty slot (kernels.cu:293-301).
+__device__ __forceinline__ void store_result(const ResultSink& sink, size_t slot, const kb_trajectory& res, int cand) {
+    if (sink.compact != nullptr) {
+        kb_compact_result r;
+        r.lh = res.lh;
+        r.flux = res.flux;
+        r.cand = (cand < 0) ? -1 : sink.cand_base + cand;
+        r.obs_count = res.obs_count;
+        sink.compact[slot] = r;
+    } else {
+        sink.full[slot] = res;
+    }
+}
+__device__ __forceinline__ kb_trajectory placeholder_result(int x, int y) {
+    kb_trajectory p;
+    p.x = x;
+    p.y = y;
+    p.vx = 0.0f;
+    p.vy = 0.0f;
+    p.lh = -FLT_MAX;
+    p.flux = 0.0f;
+    p.obs_count = 0;
+    return p;
+}
+
+struct SearchArgs {
+    const void* psi_phi;
+    const double* times;
+    const kb_trajectory* cands;
+    ResultSink results;
+    const int2* table;         // [n_chunks][T][C] integer shifts (dx, dy)
+    const ChunkInfo* chunks;   // [n_chunks]
+    const EpochBox* boxes;     // [n_chunks][T]
+    const int64_t* origins;    // [n_chunks][T] byte offset of the slab origin inside the padded copy, relative
+                               // to the tile's own pixel (kb_slab_origin_kernel)
+    const int* lds_off;        // [n_chunks][T][C] byte offset of the shifted tile inside plane A
+    const int* global_box;     // {dx_min, dx_max, dy_min, dy_max, rows_max} over every (candidate, epoch)
+    const void* padded;        // [T][Hp][Wp] raw pairs, apron = NO_DATA (kb_search_lds only)
+    int Wp, Hp, px0, py0;      // padded pitch / height, position of image pixel (0,0) inside the padded frame
+    const int* n_invalid;      // device counter: NO_DATA pixels inside the image (written by kb_pad_kernel)
+    int all_staged;            // every (chunk, epoch) is staged through LDS
+    kb_psi_phi_meta meta;
+    kb_search_params params;
+    int T, W, H;
+    int n_cands, n_chunks;
+    int sw, sh;
+    int tiles_x, tiles_y, n_tiles;
+    int K;
+    int force_exact;
+    int fast_decode;    // uint8/uint16: the fp32-FMA decode was verified bit-identical for every code
+    float* sg_scratch;  // sigma-G per-lane scratch of the literal clip, or null
+    int chunk_lo, chunk_hi;  // candidate chunks [chunk_lo, chunk_hi) of this launch
+    SigmaGWork sg;
+};
+
+// Encoded sample -> float.  The reference decodes in double with two roundings
+// (search_math.h decode_code).  (code - 1) * scale is exact in double, so the
+// value is fl32(fl64(S)) with S = (code-1)*scale + min exact; a single fp32 FMA
+// gives fl32(S).  The host checks all 2^(8*bs)-1 codes of the array's scale
+// parameters once per search and enables the FMA form only if every code agrees
+// bit for bit (verify_fast_decode); otherwise the double form is used.
+__device__ __forceinline__ float decode_fast_or_exact(unsigned code, float scale, float min_val, int fast) {
+    if (fast) return fmaf((float)code - 1.0f, scale, min_val);
+    return decode_code((float)code, scale, min_val);
+}
+
+
+// ---------------------------------------------------------------------------
+// sample decode
+// ---------------------------------------------------------------------------
+template <int NB>
+struct RawPair;
+template <>
+struct RawPair<4> {
+    using type = float2;
+    __device__ static __forceinline__ type invalid() { return make_float2(NAN, NAN); }
+    __device__ static __forceinline__ void decode(type r, const SearchArgs&, float* psi, float* phi) {
+        *psi = r.x;
+        *phi = r.y;
+    }
+};
+template <>
+struct RawPair<2> {
+    using type = ushort2;
+    __device__ static __forceinline__ type invalid() { return make_ushort2(0, 0); }
+    __device__ static __forceinline__ void decode(type r, const SearchArgs& a, float* psi, float* phi) {
+        *psi = (r.x == 0) ? NAN : decode_code((float)r.x, a.meta.psi_scale, a.meta.psi_min_val);
+        *phi = (r.y == 0) ? NAN : decode_code((float)r.y, a.meta.phi_scale, a.meta.phi_min_val);
+    }
+};
+template <>
+struct RawPair<1> {
+    using type = uchar2;
+    __device__ static __forceinline__ type invalid() { return make_uchar2(0, 0); }
+    __device__ static __forceinline__ void decode(type r, const SearchArgs& a, float* psi, float* phi) {
+        *psi = (r.x == 0) ? NAN : decode_code((float)r.x, a.meta.psi_scale, a.meta.psi_min_val);
+        *phi = (r.y == 0) ? NAN : decode_code((float)r.y, a.meta.phi_scale, a.meta.phi_min_val);
+    }
+};
+
+// Fast formats (NB = 20 / 10): uint16 / uint8 with the verified fp32-FMA decode and
+// validity taken from the codes alone (the host also verified that every code
+// decodes to a finite value).
+template <>
+struct RawPair<20> {
+    using type = ushort2;
+    __device__ static __forceinline__ type invalid() { return make_ushort2(0, 0); }
+    __device__ static __forceinline__ void decode(type r, const SearchArgs& a, float* psi, float* phi) {
+        const bool ok = (r.x != 0) && (r.y != 0);
+        *psi = ok ? fmaf((float)r.x - 1.0f, a.meta.psi_scale, a.meta.psi_min_val) : NAN;
+        *phi = fmaf((float)r.y - 1.0f, a.meta.phi_scale, a.meta.phi_min_val);
+    }
+};
+template <>
+struct RawPair<10> {
+    using type = uchar2;
+    __device__ static __forceinline__ type invalid() { return make_uchar2(0, 0); }
+    __device__ static __forceinline__ void decode(type r, const SearchArgs& a, float* psi, float* phi) {
+        const bool ok = (r.x != 0) && (r.y != 0);
+        *psi = ok ? fmaf((float)r.x - 1.0f, a.meta.psi_scale, a.meta.psi_min_val) : NAN;
+        *phi = fmaf((float)r.y - 1.0f, a.meta.phi_scale, a.meta.phi_min_val);
+    }
+};
+// Bytes per encoded value of a format tag.
+__host__ __device__ constexpr int fmt_bytes(int nb) { return nb >= 10 ? nb / 10 : nb; }
+
+template <int NB>
+__device__ __forceinline__ void load_sample(const char* base, uint32_t voff, const SearchArgs& a, float* psi,
+                                            float* phi) {
+    using R = RawPair<NB>;
+    R::decode(*reinterpret_cast<const typename R::type*>(base + voff), a, psi, phi);
+}
+
+__device__ __forceinline__ void accumulate(float psi, float phi, bool ok, float& ps, float& ph, int& n) {
+    const bool valid = ok && __builtin_isfinite(psi) && __builtin_isfinite(phi);
+    // Adding +0.0f is the identity here: the running sums start at +0.0f and can
+    // therefore never be -0.0f.
+    ps += valid ? psi : 0.0f;
+    ph += valid ? phi : 0.0f;
+    n += valid ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// shared pieces of both search kernels
+// ---------------------------------------------------------------------------
+struct TileCoords {
+    int tx, ty, lane, wv;
+    int x_i, y_i, x, y, tile_x0, tile_y0;
+    bool row_active;
+};
+
+__device__ __forceinline__ TileCoords tile_coords(const SearchArgs& a, int b) {
+    // XCD-aware tile order: workgroup b runs on XCD (b % 8); give each XCD a
+    // contiguous band of tiles so that its private L2 sees one image region.
+    TileCoords c;
+    const int xcd = b & 7, local = b >> 3;
+    const int q = a.n_tiles >> 3, r = a.n_tiles & 7;
+    const int tile = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    c.ty = tile / a.tiles_x;
+    c.tx = tile - c.ty * a.tiles_x;
+    c.lane = threadIdx.x & (WAVE - 1);
+    c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.y_i = c.ty * TILE_ROWS + c.wv;
+    c.x_i = c.tx * WAVE + c.lane;
+    c.x = c.x_i + a.params.x_start_min;
+    c.y = c.y_i + a.params.y_start_min;
+    c.tile_x0 = c.tx * WAVE + a.params.x_start_min;
+    c.tile_y0 = c.ty * TILE_ROWS + a.params.y_start_min;
+    c.row_active = c.y_i < a.sh;
+    return c;
+}
+
+template <int KS>
+struct TopK {
+    float lh[KS];
+    int id[KS];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            lh[s] = -FLT_MAX;
+            id[s] = -1;
+        }
+    }
+    // kernels.cu:323-330: strict '>' swap-down, reproduced slot by slot.
+    __device__ __forceinline__ void insert(float cand_lh, int cand) {
+        if (cand_lh > lh[KS - 1]) {
+            float cl = cand_lh;
+            int cid = cand;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bool g = cl > lh[s];
+                const float tl = lh[s];
+                const int ti = id[s];
+                lh[s] = g ? cl : tl;
+                id[s] = g ? cid : ti;
+                cl = g ? tl : cl;
+                cid = g ? ti : cid;
+            }
+        }
+    }
+};
+
+// Lane-interleaved scratch of the literal sigma-G clip for the wave in slot wave_slot of its launch
+// (launches that use it are sized by resident waves, not by the search area): element i of a lane at
+// base[i * 64].
+__device__ __forceinline__ SigmaGScratch<WAVE> make_scratch(float* sg_scratch, int T, size_t wave_slot, int lane) {
+    SigmaGScratch<WAVE> s;
+    float* base = sg_scratch + wave_slot * (size_t)(4 * T) * WAVE + lane;
+    s.psi.p = base;
+    s.phi.p = base + (size_t)T * WAVE;
+    s.lc.p = base + (size_t)2 * T * WAVE;
+    s.idx.p = reinterpret_cast<int*>(base + (size_t)3 * T * WAVE);
+    return s;
+}
+
+__device__ __forceinline__ TileCoords tile_coords(const SearchArgs& a) { return tile_coords(a, (int)blockIdx.x); }
+
+// Words of a scratch slot.
+__host__ __device__ constexpr size_t scratch_words_per_wave(int T) { return (size_t)(4 * T) * WAVE; }
+
+// Launch geometry of the sigma-G resolve, implemented in sigmag_kernels.hip.
+// Clips every entry emitted by the search launch and merges the batch into the per-pixel lists:
+// prev (may be null for the first batch) -> next.
+int launch_sigmag_resolve(const SearchArgs& a, const ResultSink* prev, const ResultSink& next, int scratch_waves,
+                          hipStream_t stream);
+
+}  // namespace kb
+#endif

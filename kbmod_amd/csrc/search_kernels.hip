@@ -34,87 +34,11 @@
 #include <mutex>
 #include <vector>
 
-#include "kb_common.h"
-#include "search_math.h"
+#include "search_common.h"
 
 #pragma clang fp contract(off)
 
 namespace kb {
-
-constexpr int SHIFT_UNSAFE = INT32_MIN;  // dx marker: no uniform shift proven for this (candidate, epoch)
-constexpr int TILE_ROWS = 4;             // waves (rows) per 256-thread workgroup
-constexpr int CHUNK = 8;                 // candidates accumulated together per wave
-
-// LDS staging (kb_search_lds): per (chunk, epoch) the workgroup stages a slab of
-// rows_max(chunk) x LDS_COLS raw pairs -- the union footprint of its 64 x 4 tile
-// under the chunk's shifts -- straight from a padded HBM copy of the array into
-// LDS with LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), several epochs
-// per barrier, double-buffered.
-constexpr int LDS_COLS = 88;          // slab pitch in pixels: 64 start columns + up to 24 of dx spread
-                                      // (88 * {8,4,2} bytes are multiples of the 16-byte DMA granule)
-constexpr int LDS_GROUP_BYTES = 20480;  // one group buffer; two per workgroup = 40 KiB -> 4 workgroups per CU
-constexpr int LDS_ALIGN_PX = 8;         // slab origins are multiples of 8 columns of the padded frame
-constexpr int LDS_SLOTS = 3;            // 16-byte pieces a thread holds in registers at once; slabs beyond
-                                        // 3 x 4 KiB are copied in further, non-overlapped rounds
-
-struct ChunkInfo {
-    int dx_min, dx_max, dy_min, dy_max;  // bounding box of the chunk's shifts over all epochs
-    int unsafe;                          // any entry flagged SHIFT_UNSAFE
-    int lds_ok;                          // every epoch's footprint fits one LDS slab
-    int rows_max;                        // TILE_ROWS + largest dy spread of any epoch (slab height)
-    int pad;
-};
-
-// Per (chunk, epoch) footprint, packed for one 8-byte scalar load:
-//   x = (dy_min << 16) | (dx_min & 0xffff)   origin of the staged region relative to the tile
-//   y = (rows   << 16) | cols                64 + dx spread, TILE_ROWS + dy spread
-using EpochBox = int2;
-constexpr int BOX_NOT_STAGED = (int)0x80008000u;  // word 0 of an epoch that kb_search_lds does not stage
-constexpr int LDS_OFF_UNSTAGED = -1;
-constexpr int LDS_OFF_PER_LANE = -2;
-__host__ __device__ __forceinline__ int box_dx(EpochBox b) { return (int)(short)(b.x & 0xffff); }
-__host__ __device__ __forceinline__ int box_dy(EpochBox b) { return b.x >> 16; }
-__host__ __device__ __forceinline__ int box_cols(EpochBox b) { return b.y & 0xffff; }
-__host__ __device__ __forceinline__ int box_rows(EpochBox b) { return b.y >> 16; }
-
-struct SearchArgs {
-    const void* psi_phi;
-    const double* times;
-    const kb_trajectory* cands;
-    kb_trajectory* results;
-    const int2* table;         // [n_chunks][T][C] integer shifts (dx, dy)
-    const ChunkInfo* chunks;   // [n_chunks]
-    const EpochBox* boxes;     // [n_chunks][T]
-    const int64_t* origins;    // [n_chunks][T] byte offset of the slab origin inside the padded copy, relative
-                               // to the tile's own pixel (kb_slab_origin_kernel)
-    const int* lds_off;        // [n_chunks][T][C] byte offset of the shifted tile inside plane A
-    const int* global_box;     // {dx_min, dx_max, dy_min, dy_max, rows_max} over every (candidate, epoch)
-    const void* padded;        // [T][Hp][Wp] raw pairs, apron = NO_DATA (kb_search_lds only)
-    int Wp, Hp, px0, py0;      // padded pitch / height, position of image pixel (0,0) inside the padded frame
-    const int* n_invalid;      // device counter: NO_DATA pixels inside the image (written by kb_pad_kernel)
-    int all_staged;            // every (chunk, epoch) is staged through LDS
-    kb_psi_phi_meta meta;
-    kb_search_params params;
-    int T, W, H;
-    int n_cands, n_chunks;
-    int sw, sh;
-    int tiles_x, tiles_y, n_tiles;
-    int K;
-    int force_exact;
-    int fast_decode;    // uint8/uint16: the fp32-FMA decode was verified bit-identical for every code
-    float* sg_scratch;  // sigma-G per-lane scratch, or null
-};
-
-// Encoded sample -> float.  The reference decodes in double with two roundings
-// (search_math.h decode_code).  (code - 1) * scale is exact in double, so the
-// value is fl32(fl64(S)) with S = (code-1)*scale + min exact; a single fp32 FMA
-// gives fl32(S).  The host checks all 2^(8*bs)-1 codes of the array's scale
-// parameters once per search and enables the FMA form only if every code agrees
-// bit for bit (verify_fast_decode); otherwise the double form is used.
-__device__ __forceinline__ float decode_fast_or_exact(unsigned code, float scale, float min_val, int fast) {
-    if (fast) return fmaf((float)code - 1.0f, scale, min_val);
-    return decode_code((float)code, scale, min_val);
-}
 
 // ---------------------------------------------------------------------------
 // shift table
@@ -181,6 +105,12 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
                     epoch_unsafe = true;
                 }
             }
+        }
+        // Candidates past the end of the list (last chunk) repeat the chunk's first shift, so that the
+        // loads kb_search_direct issues for them stay inside the chunk's bounding box.
+#pragma unroll
+        for (int c = 1; c < C; ++c) {
+            if (chunk * C + c >= n_cands) sh[c] = sh[0];
         }
         // The slab starts on a multiple of LDS_ALIGN_PX columns of the padded frame (the host places the
         // image so that x_start_min + px0 is one): 16-byte pieces of a slab row are then 16-byte aligned
@@ -280,248 +210,15 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
     }
 }
 
-// ---------------------------------------------------------------------------
-// sample decode
-// ---------------------------------------------------------------------------
-template <int NB>
-struct RawPair;
-template <>
-struct RawPair<4> {
-    using type = float2;
-    __device__ static __forceinline__ type invalid() { return make_float2(NAN, NAN); }
-    __device__ static __forceinline__ void decode(type r, const SearchArgs&, float* psi, float* phi) {
-        *psi = r.x;
-        *phi = r.y;
-    }
-};
-template <>
-struct RawPair<2> {
-    using type = ushort2;
-    __device__ static __forceinline__ type invalid() { return make_ushort2(0, 0); }
-    __device__ static __forceinline__ void decode(type r, const SearchArgs& a, float* psi, float* phi) {
-        *psi = (r.x == 0) ? NAN : decode_code((float)r.x, a.meta.psi_scale, a.meta.psi_min_val);
-        *phi = (r.y == 0) ? NAN : decode_code((float)r.y, a.meta.phi_scale, a.meta.phi_min_val);
-    }
-};
-template <>
-struct RawPair<1> {
-    using type = uchar2;
-    __device__ static __forceinline__ type invalid() { return make_uchar2(0, 0); }
-    __device__ static __forceinline__ void decode(type r, const SearchArgs& a, float* psi, float* phi) {
-        *psi = (r.x == 0) ? NAN : decode_code((float)r.x, a.meta.psi_scale, a.meta.psi_min_val);
-        *phi = (r.y == 0) ? NAN : decode_code((float)r.y, a.meta.phi_scale, a.meta.phi_min_val);
-    }
-};
 
-// Fast formats (NB = 20 / 10): uint16 / uint8 with the verified fp32-FMA decode and
-// validity taken from the codes alone (the host also verified that every code
-// decodes to a finite value).
-template <>
-struct RawPair<20> {
-    using type = ushort2;
-    __device__ static __forceinline__ type invalid() { return make_ushort2(0, 0); }
-    __device__ static __forceinline__ void decode(type r, const SearchArgs& a, float* psi, float* phi) {
-        const bool ok = (r.x != 0) && (r.y != 0);
-        *psi = ok ? fmaf((float)r.x - 1.0f, a.meta.psi_scale, a.meta.psi_min_val) : NAN;
-        *phi = fmaf((float)r.y - 1.0f, a.meta.phi_scale, a.meta.phi_min_val);
-    }
-};
-template <>
-struct RawPair<10> {
-    using type = uchar2;
-    __device__ static __forceinline__ type invalid() { return make_uchar2(0, 0); }
-    __device__ static __forceinline__ void decode(type r, const SearchArgs& a, float* psi, float* phi) {
-        const bool ok = (r.x != 0) && (r.y != 0);
-        *psi = ok ? fmaf((float)r.x - 1.0f, a.meta.psi_scale, a.meta.psi_min_val) : NAN;
-        *phi = fmaf((float)r.y - 1.0f, a.meta.phi_scale, a.meta.phi_min_val);
-    }
-};
-// Bytes per encoded value of a format tag.
-__host__ __device__ constexpr int fmt_bytes(int nb) { return nb >= 10 ? nb / 10 : nb; }
-
-template <int NB>
-__device__ __forceinline__ void load_sample(const char* base, uint32_t voff, const SearchArgs& a, float* psi,
-                                            float* phi) {
-    using R = RawPair<NB>;
-    R::decode(*reinterpret_cast<const typename R::type*>(base + voff), a, psi, phi);
-}
-
-__device__ __forceinline__ void accumulate(float psi, float phi, bool ok, float& ps, float& ph, int& n) {
-    const bool valid = ok && __builtin_isfinite(psi) && __builtin_isfinite(phi);
-    // Adding +0.0f is the identity here: the running sums start at +0.0f and can
-    // therefore never be -0.0f.
-    ps += valid ? psi : 0.0f;
-    ph += valid ? phi : 0.0f;
-    n += valid ? 1 : 0;
-}
-
-// ---------------------------------------------------------------------------
-// shared pieces of both search kernels
-// ---------------------------------------------------------------------------
-struct TileCoords {
-    int tx, ty, lane, wv;
-    int x_i, y_i, x, y, tile_x0, tile_y0;
-    bool row_active;
-};
-
-__device__ __forceinline__ TileCoords tile_coords(const SearchArgs& a) {
-    // XCD-aware tile order: workgroup b runs on XCD (b % 8); give each XCD a
-    // contiguous band of tiles so that its private L2 sees one image region.
-    TileCoords c;
-    const int b = blockIdx.x;
-    const int xcd = b & 7, local = b >> 3;
-    const int q = a.n_tiles >> 3, r = a.n_tiles & 7;
-    const int tile = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-    c.ty = tile / a.tiles_x;
-    c.tx = tile - c.ty * a.tiles_x;
-    c.lane = threadIdx.x & (WAVE - 1);
-    c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    c.y_i = c.ty * TILE_ROWS + c.wv;
-    c.x_i = c.tx * WAVE + c.lane;
-    c.x = c.x_i + a.params.x_start_min;
-    c.y = c.y_i + a.params.y_start_min;
-    c.tile_x0 = c.tx * WAVE + a.params.x_start_min;
-    c.tile_y0 = c.ty * TILE_ROWS + a.params.y_start_min;
-    c.row_active = c.y_i < a.sh;
-    return c;
-}
-
-template <int KS>
-struct TopK {
-    float lh[KS];
-    int id[KS];
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            lh[s] = -FLT_MAX;
-            id[s] = -1;
-        }
-    }
-    // kernels.cu:323-330: strict '>' swap-down, reproduced slot by slot.
-    __device__ __forceinline__ void insert(float cand_lh, int cand) {
-        if (cand_lh > lh[KS - 1]) {
-            float cl = cand_lh;
-            int cid = cand;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const bool g = cl > lh[s];
-                const float tl = lh[s];
-                const int ti = id[s];
-                lh[s] = g ? cl : tl;
-                id[s] = g ? cid : ti;
-                cl = g ? tl : cl;
-                cid = g ? ti : cid;
-            }
-        }
-    }
-};
-
-__device__ __forceinline__ SigmaGScratch<WAVE> make_scratch(const SearchArgs& a, const TileCoords& tc) {
-    // Lane-interleaved sigma-G scratch: element i of this lane at base[i * 64].
-    SigmaGScratch<WAVE> s;
-    const size_t wave_id = (size_t)blockIdx.x * TILE_ROWS + tc.wv;
-    float* base = a.sg_scratch + wave_id * (size_t)(4 * a.T) * WAVE + tc.lane;
-    s.psi.p = base;
-    s.phi.p = base + (size_t)a.T * WAVE;
-    s.lc.p = base + (size_t)2 * a.T * WAVE;
-    s.idx.p = reinterpret_cast<int*>(base + (size_t)3 * a.T * WAVE);
-    return s;
-}
-
-// Sigma-G clip of ONE trajectory by the whole wavefront (T <= 64): lane t gathers epoch t, the valid
-// samples' psi/phi ratios are sorted across the lanes (bitonic network on 64-bit keys
-// (ordered ratio, epoch)), the percentile bounds and keep range follow kernels.cu:77-147, and the
-// clipped sums are accumulated in sorted order, one fp32 add after the other, exactly like the
-// per-lane code of evaluate_trajectory_full.  The reference's exchange sort leaves a particular (not
-// stable) permutation among EQUAL ratios, which decides their summation order: when two valid
-// ratios are equal the function declines (returns false) and the caller runs the literal per-lane
-// code.  All 64 lanes must be active; x, y, vx, vy are wave-uniform.
-__device__ __forceinline__ uint32_t ratio_sort_key(float v) {
-    const uint32_t b = __float_as_uint((v == 0.0f) ? 0.0f : v);  // -0 and +0 compare equal
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float ratio_from_key(uint32_t k) {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-__device__ __forceinline__ float lane_value(float v, int lane) {  // lane: wave-uniform
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-__device__ __forceinline__ bool clip_lh_wave(const kb_psi_phi_meta& meta, const void* __restrict__ psi_phi,
-                                          const double* __restrict__ times, float sgl0, float sgl1, float sigmag_coeff,
-                                          int x, int y, float vx, float vy, float* lh_out) {
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int T = (int)meta.num_times;
-    float psi = NAN, phi = NAN;
-    if (lane < T) {
-        const double t = times[lane];
-        int cx, cy;
-        const bool okx = predict_index(x, vx, t, &cx);
-        const bool oky = predict_index(y, vy, t, &cy);
-        if (okx && oky) read_psi_phi(meta, psi_phi, (uint64_t)lane, cy, cx, &psi, &phi);
-    }
-    const bool valid = __builtin_isfinite(psi) && __builtin_isfinite(phi);
-    const int n = __popcll(__ballot(valid));
-    if (n == 0) return false;
-    const float lc = valid ? ((phi != 0.0f) ? (psi / phi) : 0.0f) : 0.0f;
-    uint32_t khi = valid ? ratio_sort_key(lc) : 0xffffffffu;  // invalid samples sort behind every ratio
-    uint32_t klo = (uint32_t)lane;
-    for (int k = 2; k <= WAVE; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t phi_k = __shfl_xor(khi, j), plo_k = __shfl_xor(klo, j);
-            const bool mine_less = (khi < phi_k) || (khi == phi_k && klo < plo_k);
-            const bool keep_min = ((lane & k) == 0) == ((lane & j) == 0);
-            if (keep_min != mine_less) {
-                khi = phi_k;
-                klo = plo_k;
-            }
-        }
-    }
-    // lane i now holds the i-th smallest ratio and the epoch it came from
-    const float sv = ratio_from_key(khi);
-    const float sv_next = __shfl_down(sv, 1);
-    if (__ballot((lane + 1 < n) && (sv == sv_next)) != 0) return false;  // equal ratios: literal code decides
-    const float spsi = __shfl(psi, (int)klo), sphi = __shfl(phi, (int)klo);
-
-    if ((double)sgl0 < 0.0001) sgl0 = (float)0.0001;
-    if ((double)sgl1 > 0.9999) sgl1 = (float)0.9999;
-    int pct_L = (int)((double)ceilf((float)n * sgl0) + 0.001) - 1;
-    pct_L = (pct_L < 0) ? 0 : pct_L;
-    pct_L = (pct_L >= n) ? (n - 1) : pct_L;
-    int pct_H = (int)((double)ceilf((float)n * sgl1) + 0.001) - 1;
-    pct_H = (pct_H < 0) ? 0 : pct_H;
-    pct_H = (pct_H >= n) ? (n - 1) : pct_H;
-    int median_ind = (int)(ceil((double)n * 0.5) + 0.001) - 1;
-    median_ind = (median_ind < 0) ? 0 : median_ind;
-    median_ind = (median_ind >= n) ? (n - 1) : median_ind;
-    pct_L = __builtin_amdgcn_readfirstlane(pct_L);
-    pct_H = __builtin_amdgcn_readfirstlane(pct_H);
-    median_ind = __builtin_amdgcn_readfirstlane(median_ind);
-    const float sigma_g = sigmag_coeff * (lane_value(sv, pct_H) - lane_value(sv, pct_L));
-    const float wsg = 2.0f * sigma_g;
-    const float vmed = lane_value(sv, median_ind);
-    const float min_value = vmed - wsg;
-    const float max_value = vmed + wsg;
-    // the ratios are ascending, so both tests are true on a prefix of the lanes: the reference's two
-    // linear scans (kernels.cu:136-146) become population counts
-    const int below = __popcll(__ballot((lane < n) && (sv < min_value)));
-    const int upto = __popcll(__ballot((lane < n) && (sv <= max_value)));
-    const int min_keep = min(below, median_ind);
-    const int max_keep = max(median_ind + 1, upto) - 1;
-    float new_psi = 0.0f, new_phi = 0.0f;
-    for (int i = min_keep; i <= max_keep; ++i) {  // sorted-value order
-        new_psi += lane_value(spsi, i);
-        new_phi += lane_value(sphi, i);
-    }
-    *lh_out = lh_from_sums(new_psi, new_phi);
-    return true;
-}
-
-// Threshold / sigma-G / insertion of one chunk's C finished candidates.
+// Threshold / insertion of one chunk's C finished candidates.  With the sigma-G filter on nothing is
+// inserted here: the ballot of the lanes that pass the unclipped thresholds (kernels.cu:201-203 and
+// :318-320; this includes the obs_count == 0 corner, which the clip leaves alone) becomes one work item
+// per (row, candidate) for the resolve passes of sigmag_kernels.hip.
 template <int KS, int C, bool SIGMAG>
 __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoords& tc, int chunk,
                                              const float (&ps)[C], const float (&ph)[C], const int (&cnt)[C],
-                                             TopK<KS>& top, const SigmaGScratch<WAVE>& scratch) {
+                                             TopK<KS>& top) {
     float lh[C];
     bool take[C];
 #pragma unroll
@@ -530,106 +227,66 @@ __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoor
         take[c] = !(cnt[c] < a.params.min_observations);
     }
     if constexpr (SIGMAG) {
-        // kernels.cu:201-203: only trajectories that pass the unclipped thresholds are clipped (rare:
-        // min_lh rejects the noise); the rest either fail kernels.cu:318-320 or are the obs_count == 0
-        // corner.  Up to 64 epochs the wavefront clips them one at a time, together (clip_lh_wave).
+        const bool live = tc.x_i < a.sw;  // lanes past the right edge of the search area own no pixel
         uint64_t need[C];
+        int n_items = 0;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const bool real = (chunk * C + c) < a.n_cands;  // uniform
-            need[c] = __ballot(real && take[c] && (cnt[c] != 0) && !(lh[c] < a.params.min_lh));
+            need[c] = __ballot(real && live && take[c] && !(lh[c] < a.params.min_lh));
+            n_items += (need[c] != 0) ? 1 : 0;
         }
-        for (int c = 0; c < C; ++c) {  // not unrolled: one copy of the clip code
-            uint64_t m = 0;
+        if (n_items == 0) return;  // uniform
+        uint32_t base = 0;
+        if (tc.lane == 0) base = (uint32_t)atomicAdd(a.sg.n_entries, n_items);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t row = (uint32_t)(tc.y_i * a.tiles_x + tc.tx);
+        uint32_t* slot_row = a.sg.slots + (size_t)row * a.sg.batch_cands + (chunk * C - a.sg.cand_lo);
 #pragma unroll
-            for (int cc = 0; cc < C; ++cc) m = (cc == c) ? need[cc] : m;
-            if (m == 0) continue;  // uniform
-            const int cand = chunk * C + c;
-            const float vx = a.cands[cand].vx, vy = a.cands[cand].vy;
-            float clipped = 0.0f;
-#ifndef KB_COOP_MAX
-#define KB_COOP_MAX 64  // ablation knob: clip cooperatively only when at most this many lanes need it
-#endif
-            // Measured on cfg2 + sigma-G (float array): every clip by the whole wave 54 ms, every clip by its
-            // own lane 295 ms, mixtures in between.  Quantised (uint8/uint16) arrays produce equal ratios all
-            // the time and end up in the per-lane code anyway (300 ms).
-            const bool cooperative = a.T <= WAVE && __popcll(m) <= KB_COOP_MAX;
-            uint64_t literal = cooperative ? 0 : m;  // lanes that run the literal per-lane code (all at once)
-            while (cooperative && m != 0) {
-                const int L = __ffsll((unsigned long long)m) - 1;
-                m &= m - 1;
-                float r = 0.0f;
-                if (clip_lh_wave(a.meta, a.psi_phi, a.times, a.params.sgl_L, a.params.sgl_H, a.params.sigmag_coeff,
-                                 tc.tile_x0 + L, tc.y, vx, vy, &r)) {
-                    if (tc.lane == L) clipped = r;
-                } else {
-                    literal |= 1ull << L;  // equal ratios: the exchange sort's own order decides
+        for (int c = 0; c < C; ++c) {
+            if (need[c] != 0) {  // uniform
+                if (tc.lane == 0) {
+                    SgEntry e;
+                    e.row = row;
+                    e.cand = (uint32_t)(chunk * C + c);
+                    e.mask = need[c];
+                    a.sg.entries[base] = e;
+                    slot_row[c] = base + 1;
                 }
-            }
-            if ((literal >> tc.lane) & 1) {
-                kb_trajectory trj;
-                trj.x = tc.x;
-                trj.y = tc.y;
-                trj.vx = vx;
-                trj.vy = vy;
-                evaluate_trajectory_full<WAVE>(a.meta, a.psi_phi, a.times, a.params, &trj, &scratch);
-                clipped = trj.lh;
-            }
-            uint64_t mc = 0;
-#pragma unroll
-            for (int cc = 0; cc < C; ++cc) mc = (cc == c) ? need[cc] : mc;
-            const bool mine = (mc >> tc.lane) & 1;
-#pragma unroll
-            for (int cc = 0; cc < C; ++cc) {
-                if (cc == c && mine) lh[cc] = clipped;
+                base += 1;
             }
         }
+    } else {
 #pragma unroll
-        for (int c = 0; c < C; ++c) take[c] = take[c] && !(lh[c] < a.params.min_lh);
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const int cand = chunk * C + c;
-        if (cand >= a.n_cands) break;  // uniform
-#ifndef KB_SKIP_INSERT
-        if (take[c]) top.insert(lh[c], cand);
-#else
-        if (take[c] && lh[c] == 12345.0f) top.insert(lh[c], cand);
-#endif
+        for (int c = 0; c < C; ++c) {
+            const int cand = chunk * C + c;
+            if (cand >= a.n_cands) break;  // uniform
+            if (take[c]) top.insert(lh[c], cand);
+        }
     }
 }
 
-// Epilogue: the K winners are re-evaluated with exact per-lane positions to
-// produce flux / obs_count (and the clipped values when sigma-G is on); the
-// likelihood this yields is bit-identical to the one that won the slot.
-template <int KS, bool SIGMAG>
-__device__ __forceinline__ void write_results(const SearchArgs& a, const TileCoords& tc, const TopK<KS>& top,
-                                              const SigmaGScratch<WAVE>& scratch) {
+// Epilogue (no sigma-G; with it kb_sigmag_select_kernel writes the results): the K winners are
+// re-evaluated with exact per-lane positions to produce flux / obs_count; the likelihood this yields
+// is bit-identical to the one that won the slot.
+template <int KS>
+__device__ __forceinline__ void write_results(const SearchArgs& a, const TileCoords& tc, const TopK<KS>& top) {
     if (tc.x_i >= a.sw || !tc.row_active) return;
-    kb_trajectory* out = a.results + ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
+    const size_t slot0 = ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
     for (int s = 0; s < a.K; ++s) {
         int id_s = -1;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             if (k == s) id_s = top.id[k];
         }
-        kb_trajectory res;
-        res.x = tc.x;
-        res.y = tc.y;
-        if (id_s < 0) {  // kernels.cu:293-301 placeholder
-            res.vx = 0.0f;
-            res.vy = 0.0f;
-            res.lh = -FLT_MAX;
-            res.flux = 0.0f;
-            res.obs_count = 0;
-        } else {
+        kb_trajectory res = placeholder_result(tc.x, tc.y);  // kernels.cu:293-301
+        if (id_s >= 0) {
             res.vx = a.cands[id_s].vx;
             res.vy = a.cands[id_s].vy;
-#ifndef KB_SKIP_EPILOGUE
-            evaluate_trajectory_full<WAVE>(a.meta, a.psi_phi, a.times, a.params, &res, SIGMAG ? &scratch : nullptr);
-#endif
+            evaluate_trajectory_full<WAVE>(a.meta, a.psi_phi, a.times, a.params, &res,
+                                           static_cast<const SigmaGScratch<WAVE>*>(nullptr));
         }
-        out[s] = res;
+        store_result(a.results, slot0 + s, res, id_s);
     }
 }
 
@@ -698,10 +355,8 @@ __global__ __launch_bounds__(256, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_se
     const int pix0 = tc.y * a.W + tc.x;
     TopK<KS> top;
     top.init();
-    SigmaGScratch<WAVE> scratch = {};
-    if constexpr (SIGMAG) scratch = make_scratch(a, tc);
 
-    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+    for (int chunk = a.chunk_lo; chunk < a.chunk_hi; ++chunk) {
         float ps[C], ph[C];
         int cnt[C];
 #pragma unroll
@@ -721,9 +376,9 @@ __global__ __launch_bounds__(256, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_se
         } else {
             accumulate_chunk_direct<C, NB, 1>(a, chunk, tc.x, tc.y, pix0, ps, ph, cnt);
         }
-        finish_chunk<KS, C, SIGMAG>(a, tc, chunk, ps, ph, cnt, top, scratch);
+        finish_chunk<KS, C, SIGMAG>(a, tc, chunk, ps, ph, cnt, top);
     }
-    write_results<KS, SIGMAG>(a, tc, top, scratch);
+    if constexpr (!SIGMAG) write_results<KS>(a, tc, top);
 }
 
 // ---------------------------------------------------------------------------
@@ -961,7 +616,7 @@ __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) 
 // every shift, the array has no NO_DATA pixel, every epoch is staged): obs_count is T.
 template <int KS, int C, int NB, bool CANON, bool SIGMAG, bool FAST>
 __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileCoords& tc, char* smem,
-                                                const StageLane& sl, TopK<KS>& top, SigmaGScratch<WAVE>& scratch) {
+                                                const StageLane& sl, TopK<KS>& top) {
     constexpr int SF = CANON ? 4 : NB;  // staged format
     using R = RawPair<SF>;
     constexpr int BYTES = 2 * fmt_bytes(SF);
@@ -976,15 +631,15 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
         cnt[c] = 0;
     }
 
-    int chunk = 0, t0 = 0, buf = 0;
-    ChunkPlan plan = chunk_plan<BYTES>(a, 0);
+    int chunk = a.chunk_lo, t0 = 0, buf = 0;
+    ChunkPlan plan = chunk_plan<BYTES>(a, chunk);
     SlabRegs regs;
     typedef const __attribute__((address_space(4))) int64_t* ConstI64Ptr;
     // this tile's own pixel inside the padded copy
     const char* tile_base = reinterpret_cast<const char*>(a.padded) + ((int64_t)tc.tile_y0 * a.Wp + tc.tile_x0) * BYTES;
     StageLane n_sl = clip_lane(sl, plan.slab_bytes);  // staging map of the group being copied
     {
-        const ConstI64Ptr org = (ConstI64Ptr)(uintptr_t)a.origins;
+        const ConstI64Ptr org = (ConstI64Ptr)(uintptr_t)(a.origins + (size_t)chunk * T);
         const int n = min(plan.E, T);
         for (int e = 0; e < n; ++e) {
             const int64_t o = org[e];
@@ -996,37 +651,30 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     }
     __syncthreads();
 
-    while (chunk < a.n_chunks) {
+    while (chunk < a.chunk_hi) {
         // next group in flight during this group's arithmetic
         int n_chunk = chunk, n_t0 = t0 + plan.E;
         ChunkPlan n_plan = plan;
         if (n_t0 >= T) {
             n_chunk = chunk + 1;
             n_t0 = 0;
-            if (n_chunk < a.n_chunks) {
+            if (n_chunk < a.chunk_hi) {
                 n_plan = chunk_plan<BYTES>(a, n_chunk);
                 n_sl = clip_lane(sl, n_plan.slab_bytes);
             }
         }
-        const int n_next = (n_chunk < a.n_chunks) ? min(n_plan.E, T - n_t0) : 0;
-        const ConstI64Ptr n_org = (ConstI64Ptr)(uintptr_t)(a.origins + (size_t)min(n_chunk, a.n_chunks - 1) * T + n_t0);
+        const int n_next = (n_chunk < a.chunk_hi) ? min(n_plan.E, T - n_t0) : 0;
+        const ConstI64Ptr n_org = (ConstI64Ptr)(uintptr_t)(a.origins + (size_t)min(n_chunk, a.chunk_hi - 1) * T + n_t0);
         char* nb = smem + (1 - buf) * LDS_GROUP_BYTES;
         // slab e of the next group: loads issued before, LDS writes after the sums of epoch e
         const char* n_base = tile_base;
         auto next_load = [&](int e) -> bool {
-#ifdef KB_ABL_NO_DMA
-            return false;
-#endif
             if (e >= n_next) return false;
             n_base = tile_base + n_org[e];
             load_slab<BYTES>(a, n_sl, n_base, n_plan.slab_bytes, regs);
             return true;
         };
         auto next_write = [&](int e) {
-#ifdef KB_ABL_NO_WRITE
-            asm volatile("" ::"v"(regs.v[0]), "v"(regs.v[1]), "v"(regs.v[2]));
-            return;
-#endif
             write_slab(nb + e * n_plan.slab_bytes, n_plan.slab_bytes, regs);
             if (n_plan.slab_bytes > LDS_SLOTS * 4096) {  // uniform, rare
                 __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
@@ -1043,12 +691,6 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const int off = (BYTES == 8) ? o[c] : (o[c] >> 3) * BYTES;
-#ifdef KB_ABL_NO_LDSREAD
-                if constexpr (CANON) {
-                    raw[c] = make_float2(__int_as_float(off + tc.lane), 1.0f);
-                    continue;
-                }
-#endif
                 raw[c] = *reinterpret_cast<const typename R::type*>(cb + e * plan.slab_bytes + off);
             }
             // one wait for the C reads instead of the compiler's one per read (instruction issue is the bound)
@@ -1056,15 +698,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 if constexpr (CANON) {
-#ifdef KB_ABL_SCALAR_ADD
-                    float ax = acc[c].x, ay = acc[c].y;
-                    ax += raw[c].x;
-                    asm volatile("" : "+v"(ax));
-                    ay += raw[c].y;
-                    acc[c] = PairF{ax, ay};
-#else
                     acc[c] += PairF{raw[c].x, raw[c].y};
-#endif
                     if (!FAST) cnt[c] += (__float_as_uint(raw[c].y) != 0x80000000u) ? 1 : 0;
                 } else {
                     float psi, phi;
@@ -1079,9 +713,6 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 }
             }
         };
-#ifdef KB_ABL_NO_SUM
-        if (false) {
-#else
         // Keeps the epoch's sums in front of the LDS writes of the staged slab: left alone the compiler
         // sinks the adds behind the writes, whose vmcnt(0) then waits out the loads with nothing to overlap.
         auto pin_sums = [&]() {
@@ -1094,7 +725,6 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                          : "memory");
         };
         if (FAST || plan.clean) {
-#endif
             // A block alone on its CU is bound by the chain scalar table fetch -> LDS read -> adds -> slab
             // landed -> LDS write of one epoch (measured 4.9 ms with one block per CU against 7.4 ms with
             // four).  The table words of epoch e + 1 (slab offsets, slab origin) are therefore fetched at
@@ -1107,12 +737,10 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             int64_t org_cur = n_org[0];
             for (int e = 0; e < n_cur; ++e) {
                 const bool staging = e < n_next;
-#ifndef KB_ABL_NO_DMA
                 if (staging) {
                     n_base = tile_base + org_cur;
                     load_slab<BYTES>(a, n_sl, n_base, n_plan.slab_bytes, regs);
                 }
-#endif
                 sum_epoch(o_cur, e);
                 pin_sums();
                 ConstIntPtr po = offs + (e + 1) * C;
@@ -1121,17 +749,11 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
                 for (int c = 0; c < C; ++c) o_cur[c] = po[c];
                 org_cur = pg[0];
-#ifndef KB_ABL_NO_DMA
                 if (staging) next_write(e);
-#endif
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             }
         } else {
-#ifdef KB_ABL_NO_SUM
-            for (int e = 0; e < 0; ++e) {
-#else
             for (int e = 0; e < n_cur; ++e) {
-#endif
                 const bool staging = next_load(e);
                 int o[C];
 #pragma unroll
@@ -1164,7 +786,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     ph[c] = acc[c].y;
                     if (FAST) cnt[c] = T;
                 }
-                finish_chunk<KS, C, SIGMAG>(a, tc, chunk, ps, ph, cnt, top, scratch);
+                finish_chunk<KS, C, SIGMAG>(a, tc, chunk, ps, ph, cnt, top);
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
@@ -1172,9 +794,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 cnt[c] = 0;
             }
         }
-#ifndef KB_ABL_NO_BARRIER
         __syncthreads();
-#endif
         buf = 1 - buf;
         chunk = n_chunk;
         t0 = n_t0;
@@ -1192,8 +812,6 @@ __global__ __launch_bounds__(LDS_BLOCK, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void
     const TileCoords tc = tile_coords(a);  // rows past the search area stay alive (barriers)
     TopK<KS> top;
     top.init();
-    SigmaGScratch<WAVE> scratch = {};
-    if constexpr (SIGMAG) scratch = make_scratch(a, tc);
 
     StageLane sl;
 #pragma unroll
@@ -1209,11 +827,11 @@ __global__ __launch_bounds__(LDS_BLOCK, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void
                       (tc.tile_x0 + WAVE + gb[1] <= a.W) && (tc.tile_y0 + gb[2] >= 0) &&
                       (tc.tile_y0 + TILE_ROWS + gb[3] <= a.H);
     if (fast) {
-        lds_search_tile<KS, C, NB, CANON, SIGMAG, true>(a, tc, smem, sl, top, scratch);
+        lds_search_tile<KS, C, NB, CANON, SIGMAG, true>(a, tc, smem, sl, top);
     } else {
-        lds_search_tile<KS, C, NB, CANON, SIGMAG, false>(a, tc, smem, sl, top, scratch);
+        lds_search_tile<KS, C, NB, CANON, SIGMAG, false>(a, tc, smem, sl, top);
     }
-    write_results<KS, SIGMAG>(a, tc, top, scratch);
+    if constexpr (!SIGMAG) write_results<KS>(a, tc, top);
 }
 
 // ---------------------------------------------------------------------------
@@ -1226,37 +844,34 @@ __global__ __launch_bounds__(LDS_BLOCK, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void
 // cannot hold the list (few start pixels x many results in practice).
 template <bool SIGMAG>
 __global__ __launch_bounds__(256) void kb_search_large_k(const SearchArgs a) {
-    const TileCoords tc = tile_coords(a);
-    if (!tc.row_active || tc.x_i >= a.sw) return;
+    // A bounded grid walks the tiles (workgroup b takes tiles b, b + gridDim.x, ...), so that the
+    // sigma-G scratch is sized by the waves of the launch and not by the search area.
     SigmaGScratch<WAVE> scratch = {};
-    if constexpr (SIGMAG) scratch = make_scratch(a, tc);
-    kb_trajectory* slots = a.results + ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
-    for (int s = 0; s < a.K; ++s) {  // kernels.cu:293-301
-        kb_trajectory p;
-        p.x = tc.x;
-        p.y = tc.y;
-        p.vx = 0.0f;
-        p.vy = 0.0f;
-        p.lh = -FLT_MAX;
-        p.flux = 0.0f;
-        p.obs_count = 0;
-        slots[s] = p;
+    if constexpr (SIGMAG) {
+        scratch = make_scratch(a.sg_scratch, a.T, (size_t)blockIdx.x * TILE_ROWS + (threadIdx.x >> 6),
+                               threadIdx.x & (WAVE - 1));
     }
-    for (int cand = 0; cand < a.n_cands; ++cand) {
-        kb_trajectory cur;
-        cur.x = tc.x;
-        cur.y = tc.y;
-        cur.vx = a.cands[cand].vx;
-        cur.vy = a.cands[cand].vy;
-        evaluate_trajectory_full<WAVE>(a.meta, a.psi_phi, a.times, a.params, &cur, SIGMAG ? &scratch : nullptr);
-        if ((cur.obs_count < a.params.min_observations) || (a.params.do_sigmag_filter && cur.lh < a.params.min_lh))
-            continue;  // kernels.cu:318-320
-        if (!(cur.lh > slots[a.K - 1].lh)) continue;  // cannot displace anything
-        for (int s = 0; s < a.K; ++s) {  // kernels.cu:323-330
-            const kb_trajectory t = slots[s];
-            if (cur.lh > t.lh) {
-                slots[s] = cur;
-                cur = t;
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const TileCoords tc = tile_coords(a, tile);
+        if (!tc.row_active || tc.x_i >= a.sw) continue;
+        kb_trajectory* slots = a.results.full + ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
+        for (int s = 0; s < a.K; ++s) slots[s] = placeholder_result(tc.x, tc.y);  // kernels.cu:293-301
+        for (int cand = 0; cand < a.n_cands; ++cand) {
+            kb_trajectory cur;
+            cur.x = tc.x;
+            cur.y = tc.y;
+            cur.vx = a.cands[cand].vx;
+            cur.vy = a.cands[cand].vy;
+            evaluate_trajectory_full<WAVE>(a.meta, a.psi_phi, a.times, a.params, &cur, SIGMAG ? &scratch : nullptr);
+            if ((cur.obs_count < a.params.min_observations) || (a.params.do_sigmag_filter && cur.lh < a.params.min_lh))
+                continue;  // kernels.cu:318-320
+            if (!(cur.lh > slots[a.K - 1].lh)) continue;  // cannot displace anything
+            for (int s = 0; s < a.K; ++s) {  // kernels.cu:323-330
+                const kb_trajectory t = slots[s];
+                if (cur.lh > t.lh) {
+                    slots[s] = cur;
+                    cur = t;
+                }
             }
         }
     }
@@ -1295,6 +910,58 @@ __global__ __launch_bounds__(256) void kb_merge_topk_kernel(const kb_trajectory*
     }
 }
 
+// The same merge on the 16-byte records of kb_device_search_compact (the exchange format between GPUs),
+// writing full trajectories.  A workgroup owns 256 consecutive pixels: the n_lists x 256 x K records are
+// read as contiguous runs (256 * K * 16 bytes per list), each thread then merges its pixel's lists out
+// of registers -- the head record of every list -- advancing one list per output slot.
+template <int NL>  // upper bound of n_lists: lists live in registers, every loop is unrolled
+__global__ __launch_bounds__(256) void kb_merge_compact_kernel(const kb_compact_result* __restrict__ lists, int n_lists,
+                                                               uint64_t n_pixels, int K, int sw, int x_min, int y_min,
+                                                               const kb_trajectory* __restrict__ all_cands,
+                                                               uint64_t n_all_cands, kb_trajectory* __restrict__ out) {
+    const uint64_t pix = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= n_pixels) return;
+    const uint64_t list_stride = n_pixels * (uint64_t)K;
+    int head[NL];
+    float head_lh[NL];
+#pragma unroll
+    for (int r = 0; r < NL; ++r) {
+        head[r] = (r < n_lists) ? 0 : K;  // lists past n_lists are exhausted from the start
+        head_lh[r] = (r < n_lists) ? lists[(uint64_t)r * list_stride + pix * K].lh : -FLT_MAX;
+    }
+    const int y_i = (int)(pix / (uint64_t)sw), x_i = (int)(pix - (uint64_t)y_i * (uint64_t)sw);
+    for (int s = 0; s < K; ++s) {
+        int best = -1, best_head = 0;
+        float best_lh = 0.0f;
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {  // strict '>': equal likelihoods go to the lower list
+            const bool better = head[r] < K && (best < 0 || head_lh[r] > best_lh);
+            best = better ? r : best;
+            best_head = better ? head[r] : best_head;
+            best_lh = better ? head_lh[r] : best_lh;
+        }
+        const uint64_t at = (uint64_t)best * list_stride + pix * K + best_head;
+        const kb_compact_result rec = lists[at];
+        const float next_lh = (best_head + 1 < K) ? lists[at + 1].lh : -FLT_MAX;
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {
+            if (r == best) {
+                head[r] = best_head + 1;
+                head_lh[r] = next_lh;
+            }
+        }
+        kb_trajectory res = placeholder_result(x_i + x_min, y_i + y_min);
+        if (rec.cand >= 0 && (uint64_t)rec.cand < n_all_cands) {
+            res.vx = all_cands[rec.cand].vx;
+            res.vy = all_cands[rec.cand].vy;
+            res.lh = rec.lh;
+            res.flux = rec.flux;
+            res.obs_count = rec.obs_count;
+        }
+        out[pix * K + s] = res;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1304,7 +971,8 @@ struct Workspace {
     int device = -1;
 };
 static std::mutex g_ws_mutex;
-static Workspace g_ws[3];  // 0: shift table + chunk info, 1: sigma-G scratch, 2: padded array copy (LDS kernel)
+static Workspace g_ws[5];  // 0: shift table + chunk info, 1: literal sigma-G scratch, 2: padded array copy (LDS kernel),
+                            // 3: sigma-G work items + clipped values, 4: second per-pixel list buffer (sigma-G batches)
 
 static int ensure_workspace(int which, size_t bytes, void** out) {
     int dev = 0;
@@ -1368,10 +1036,12 @@ static void launch_variant(const SearchArgs& a, int which, hipStream_t stream) {
 
 template <int KS, int NB>
 static void launch_sigmag(const SearchArgs& a, bool sigmag, int which, hipStream_t stream) {
-    if (sigmag)
-        launch_variant<KS, NB, true>(a, which, stream);
-    else
+    if (sigmag) {
+        // the emitting instances keep no list: one set (KS = 8) serves every K
+        if constexpr (KS == 8) launch_variant<8, NB, true>(a, which, stream);
+    } else {
         launch_variant<KS, NB, false>(a, which, stream);
+    }
 }
 
 // Format code of the array for the templates: 4 = float, 2 / 1 = encoded with the reference's
@@ -1434,13 +1104,12 @@ static void launch_pad(const SearchArgs& a, bool canon, void* padded, int* n_inv
 
 }  // namespace kb
 
-extern "C" {
-
-int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
-                            kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
-                            kb_trajectory* results_dev, uint64_t n_results, uint32_t flags, void* stream_v,
-                            kb_search_stats* stats_out) {
-    using namespace kb;
+namespace kb {
+// kb_device_search_filter / kb_device_search_compact: `sink` says where the per-pixel lists go.
+static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
+                              kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
+                              const ResultSink sink, uint64_t n_results, uint32_t flags, void* stream_v,
+                              kb_search_stats* stats_out) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (meta == nullptr) return fail("deviceSearchFilter: null meta data");
     // kernels.cu:337-340
@@ -1452,8 +1121,9 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
     if (psi_phi_dev == nullptr) return fail("PsiPhi data has not been created.");
     if (times_dev == nullptr) return fail("GPU time data has not been created.");
     if (cands_dev == nullptr) return fail("Invalid test list pointer.");
-    if (results_dev == nullptr) return fail("Invalid result list pointer.");
+    if (sink.full == nullptr && sink.compact == nullptr) return fail("Invalid result list pointer.");
     if (kb_device_count() == 0) return fail("GPU is not available for search.");
+    (void)hipGetLastError();  // a stale error of this thread (another library's probing) is not ours
 
     // kernels.cu:371-378
     const int64_t sw = (int64_t)params.x_start_max - params.x_start_min;
@@ -1484,7 +1154,7 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
     a.psi_phi = psi_phi_dev;
     a.times = times_dev;
     a.cands = cands_dev;
-    a.results = results_dev;
+    a.results = sink;
     a.meta = *meta;
     a.params = params;
     a.T = (int)meta->num_times;
@@ -1632,30 +1302,99 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
     }
 
     const bool sigmag = params.do_sigmag_filter != 0;
+    a.chunk_lo = 0;
+    a.chunk_hi = a.n_chunks;
+    a.sg = SigmaGWork{};
+
+    // Sigma-G: the search launch emits work items, two more launches resolve them (sigmag_kernels.hip).
+    // Work items are bounded by rows x candidates; the candidate list is cut into batches of whole
+    // chunks so that one batch's worst case fits the work-item store (KBMOD_SIGMAG_CAP items, default 4 Mi).
+    const int n_rows = a.tiles_x * a.sh;  // rows of 64 start pixels
+    int batch_chunks = std::max(a.n_chunks, 1), n_batches = 1, resolve_waves = 0;
+    void* pingpong = nullptr;  // second list buffer, in the sink's record format
     if (sigmag) {
-        const size_t waves = (size_t)a.n_tiles * TILE_ROWS;
-        const size_t bytes = waves * (size_t)(4 * a.T) * WAVE * sizeof(float);
+        int cus = 256;
+        int dev = 0;
+        KB_HIP_TRY(hipGetDevice(&dev));
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        // literal-clip scratch: one slot per wave of the resolve launch (8 workgroups per CU), or per wave of
+        // the bounded kb_search_large_k grid
+        resolve_waves = std::max(cus, 1) * 8 * TILE_ROWS;
         void* sg = nullptr;
-        if (ensure_workspace(1, bytes, &sg)) return 1;
+        if (ensure_workspace(1, (size_t)resolve_waves * scratch_words_per_wave(a.T) * sizeof(float), &sg)) return 1;
         a.sg_scratch = reinterpret_cast<float*>(sg);
+    }
+    if (sigmag && a.K <= 32) {
+        uint64_t cap_limit = 4ull << 20;
+        if (const char* env = std::getenv("KBMOD_SIGMAG_CAP")) cap_limit = std::max<uint64_t>(1, std::strtoull(env, nullptr, 10));
+        batch_chunks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(a.n_chunks, 1),
+                                                                     cap_limit / ((uint64_t)n_rows * CHUNK)));
+        n_batches = std::max(1, (a.n_chunks + batch_chunks - 1) / batch_chunks);
+        const uint64_t capacity = (uint64_t)n_rows * (uint64_t)batch_chunks * CHUNK;
+        const size_t slot_bytes = (capacity * sizeof(uint32_t) + 255) / 256 * 256;
+        const size_t entry_bytes = capacity * sizeof(SgEntry);
+        const size_t out_bytes = capacity * WAVE * sizeof(float);
+        void* w = nullptr;
+        if (ensure_workspace(3, slot_bytes + 256 + entry_bytes + 3 * out_bytes, &w)) return 1;
+        char* wc = reinterpret_cast<char*>(w);
+        a.sg.slots = reinterpret_cast<uint32_t*>(wc);
+        a.sg.n_entries = reinterpret_cast<int*>(wc + slot_bytes);
+        a.sg.totals = reinterpret_cast<unsigned long long*>(wc + slot_bytes + 64);
+        KB_HIP_TRY(hipMemsetAsync(a.sg.totals, 0, 2 * sizeof(unsigned long long), stream));
+        a.sg.entries = reinterpret_cast<SgEntry*>(wc + slot_bytes + 256);
+        a.sg.lh = reinterpret_cast<float*>(wc + slot_bytes + 256 + entry_bytes);
+        a.sg.flux = reinterpret_cast<float*>(wc + slot_bytes + 256 + entry_bytes + out_bytes);
+        a.sg.obs = reinterpret_cast<int*>(wc + slot_bytes + 256 + entry_bytes + 2 * out_bytes);
+        a.sg.batch_cands = batch_chunks * CHUNK;
+        if (n_batches > 1) {
+            void* pp = nullptr;
+            if (ensure_workspace(4, (size_t)expected * sizeof(kb_trajectory), &pp)) return 1;
+            pingpong = pp;
+        }
     }
 
     search_timer.begin();
     int variant;
     if (a.K > 32) {
-        if (sigmag)
-            hipLaunchKernelGGL((kb_search_large_k<true>), dim3(a.n_tiles), dim3(256), 0, stream, a);
-        else
+        if (sink.compact != nullptr) return fail("compact results support results_per_pixel <= 32");
+        if (sigmag) {
+            const int blocks = std::max(1, std::min(a.n_tiles, resolve_waves / TILE_ROWS));
+            hipLaunchKernelGGL((kb_search_large_k<true>), dim3(blocks), dim3(256), 0, stream, a);
+        } else {
             hipLaunchKernelGGL((kb_search_large_k<false>), dim3(a.n_tiles), dim3(256), 0, stream, a);
+        }
         variant = 99;
+    } else if (sigmag) {
+        // batch b leaves its lists in buffer (n_batches - 1 - b) % 2: the last one in results_dev
+        ResultSink other = sink;
+        if (sink.compact != nullptr) {
+            other.compact = reinterpret_cast<kb_compact_result*>(pingpong);
+        } else {
+            other.full = reinterpret_cast<kb_trajectory*>(pingpong);
+        }
+        const ResultSink bufs[2] = {sink, other};
+        const ResultSink* prev = nullptr;
+        for (int b = 0; b < n_batches; ++b) {
+            a.chunk_lo = b * batch_chunks;
+            a.chunk_hi = std::min(a.n_chunks, a.chunk_lo + batch_chunks);
+            a.sg.cand_lo = a.chunk_lo * CHUNK;
+            KB_HIP_TRY(hipMemsetAsync(a.sg.slots, 0, (size_t)n_rows * a.sg.batch_cands * sizeof(uint32_t), stream));
+            KB_HIP_TRY(hipMemsetAsync(a.sg.n_entries, 0, sizeof(int), stream));
+            if (a.chunk_lo < a.chunk_hi) launch_search<8>(a, true, which, stream);  // the emitting instances keep no list
+            KB_HIP_TRY(hipGetLastError());
+            const ResultSink* next = &bufs[(n_batches - 1 - b) % 2];
+            if (launch_sigmag_resolve(a, prev, *next, resolve_waves, stream)) return 1;
+            prev = next;
+        }
+        variant = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
     } else if (a.K <= 8) {
-        launch_search<8>(a, sigmag, which, stream);
+        launch_search<8>(a, false, which, stream);
         variant = 8;
     } else if (a.K <= 16) {
-        launch_search<16>(a, sigmag, which, stream);
+        launch_search<16>(a, false, which, stream);
         variant = 16;
     } else {
-        launch_search<32>(a, sigmag, which, stream);
+        launch_search<32>(a, false, which, stream);
         variant = 32;
     }
     KB_HIP_TRY(hipGetLastError());
@@ -1676,12 +1415,44 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
         stats_out->algorithmic_bytes = stats_out->num_evals * 2ull * (uint64_t)meta->block_size +
                                        S * (uint64_t)a.K * 28ull + n_cands * 28ull + meta->num_times * 8ull;
         stats_out->kernel_variant = which * 10000 + variant * 100 + meta->num_bytes * 10 + (sigmag ? 1 : 0);
-        stats_out->num_search_launches = 1;
+        stats_out->num_search_launches = sigmag && a.K <= 32 ? 3 * n_batches : 1;
+        stats_out->lds_read_bytes = which == 2 ? stats_out->num_evals * 8ull
+                                               : (which == 1 ? stats_out->num_evals * 2ull * (uint64_t)meta->block_size : 0ull);
+        stats_out->sigmag_work_items = 0;
+        stats_out->sigmag_trajectories = 0;
+        if (a.sg.totals != nullptr) {
+            unsigned long long totals[2] = {0, 0};
+            KB_HIP_TRY(hipMemcpyAsync(totals, a.sg.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
+            KB_HIP_TRY(hipStreamSynchronize(stream));
+            stats_out->sigmag_work_items = totals[0];
+            stats_out->sigmag_trajectories = totals[1];
+        }
     } else {
         // kernels.cu:396 -- the reference call is synchronous.
         KB_HIP_TRY(hipStreamSynchronize(stream));
     }
     return 0;
+}
+}  // namespace kb
+
+extern "C" {
+
+int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
+                            kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
+                            kb_trajectory* results_dev, uint64_t n_results, uint32_t flags, void* stream,
+                            kb_search_stats* stats_out) {
+    const kb::ResultSink sink = {results_dev, nullptr, 0};
+    return kb::search_filter_impl(meta, psi_phi_dev, times_dev, params, cands_dev, n_cands, sink, n_results, flags, stream,
+                                  stats_out);
+}
+
+int kb_device_search_compact(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
+                             kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
+                             int32_t cand_index_base, kb_compact_result* results_dev, uint64_t n_results, uint32_t flags,
+                             void* stream, kb_search_stats* stats_out) {
+    const kb::ResultSink sink = {nullptr, results_dev, cand_index_base};
+    return kb::search_filter_impl(meta, psi_phi_dev, times_dev, params, cands_dev, n_cands, sink, n_results, flags, stream,
+                                  stats_out);
 }
 
 int kb_release_workspaces(void) {
@@ -1711,6 +1482,31 @@ int kb_merge_topk(const kb_trajectory* lists_dev, int32_t n_lists, uint64_t n_pi
     const unsigned blocks = (unsigned)((n_pixels + 255) / 256);
     hipLaunchKernelGGL(kb_merge_topk_kernel, dim3(blocks), dim3(256), 0, stream, lists_dev, n_lists, n_pixels, K,
                        out_dev);
+    KB_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int kb_merge_compact(const kb_compact_result* lists_dev, int32_t n_lists, kb_search_params params,
+                     const kb_trajectory* all_cands_dev, uint64_t n_all_cands, kb_trajectory* out_dev, void* stream_v) {
+    using namespace kb;
+    if (lists_dev == nullptr || out_dev == nullptr || all_cands_dev == nullptr) return fail("merge_compact: null pointer");
+    if (n_lists <= 0 || n_lists > MERGE_MAX_LISTS) return fail("merge_compact: unsupported number of lists");
+    const int64_t sw = (int64_t)params.x_start_max - params.x_start_min;
+    const int64_t sh = (int64_t)params.y_start_max - params.y_start_min;
+    const int K = (int)params.results_per_pixel;
+    if (sw <= 0 || sh <= 0) return fail("merge_compact: invalid search bounds");
+    if (K <= 0 || K > 32) return fail("merge_compact: unsupported K");
+    (void)hipGetLastError();
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    const uint64_t n_pixels = (uint64_t)sw * (uint64_t)sh;
+    const unsigned blocks = (unsigned)((n_pixels + 255) / 256);
+    if (n_lists <= 8) {
+        hipLaunchKernelGGL(kb_merge_compact_kernel<8>, dim3(blocks), dim3(256), 0, stream, lists_dev, n_lists, n_pixels, K,
+                           (int)sw, params.x_start_min, params.y_start_min, all_cands_dev, n_all_cands, out_dev);
+    } else {
+        hipLaunchKernelGGL(kb_merge_compact_kernel<MERGE_MAX_LISTS>, dim3(blocks), dim3(256), 0, stream, lists_dev, n_lists,
+                           n_pixels, K, (int)sw, params.x_start_min, params.y_start_min, all_cands_dev, n_all_cands, out_dev);
+    }
     KB_HIP_TRY(hipGetLastError());
     return 0;
 }

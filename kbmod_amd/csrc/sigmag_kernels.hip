@@ -1,0 +1,378 @@
+// In-search sigma-G filter for MI355X (gfx950): the resolve passes behind kb_device_search_filter
+// when params.do_sigmag_filter is set.
+//
+// Reference semantics (kernels/kernels.cu:199-241, 77-147, 304-331): a trajectory that passes the
+// unclipped thresholds is re-summed over the samples whose psi/phi ratio lies within
+// median +- 2 * coeff * (q_H - q_L), in ascending ratio order, and the per-pixel list is built from
+// the clipped likelihoods in candidate order.  Only a small, spatially clustered fraction of the
+// (start pixel, candidate) grid passes (the neighbourhood of every bright source), so clipping inside
+// the search kernel leaves the few tiles around the sources running long after the rest of the
+// device has finished.  Here the search kernels only EMIT the passing trajectories
+// (search_kernels.hip, finish_chunk) and two further launches resolve them:
+//
+//   * kb_sigmag_clip_kernel   : a device-filling grid of waves walks the work items; each trajectory
+//     is clipped by a whole wavefront -- lane t gathers epoch t, the ratios are sorted across the
+//     lanes with a DPP sorting network (wave_ops.h), the percentile bounds and the keep range become
+//     lane reads and population counts, and the clipped sums are chained across the lanes in sorted
+//     order, one fp32 add after the other (the arithmetic of the reference's per-thread loop).
+//   * kb_sigmag_select_kernel : one wave per row of 64 start pixels replays the candidate-order
+//     swap-down insertion (kernels.cu:323-330) over the clipped likelihoods and writes the results.
+//
+// Exactness.  The reference sorts with an exchange sort whose permutation among EQUAL ratios is
+// neither stable nor simple, and that permutation decides the order in which equal-ratio samples
+// are added.  If every run of equal ratios consists of bit-identical (psi, phi) pairs -- the only
+// kind of tie a quantised (uint8/uint16) array produces in practice, and it produces them all the
+// time -- the order inside the run cannot change a single bit of the sums, and the network's order
+// is as good as any.  Only a run that mixes different pairs is handed to the literal per-lane
+// restatement of the reference code (search_math.h), as are stacks deeper than 64 epochs.
+#include <algorithm>
+#include <cstdlib>
+
+#include "search_common.h"
+#include "wave_ops.h"
+
+#pragma clang fp contract(off)
+
+namespace kb {
+
+struct ResolveArgs {
+    kb_psi_phi_meta meta;
+    kb_search_params params;
+    const void* psi_phi;
+    const double* times;
+    const kb_trajectory* cands;
+    SigmaGWork sg;
+    float* sg_scratch;
+    ResultSink prev;  // per-pixel lists of the batches before this one (both pointers null: none)
+    ResultSink next;  // per-pixel lists after this batch
+    int T, K, sw, sh, tiles_x;
+    int n_rows;
+};
+
+// Monotone 32-bit key of a ratio: -0 and +0 share a key, like the comparison they replace.
+__device__ __forceinline__ uint32_t ratio_sort_key(float v) {
+    const uint32_t b = __float_as_uint((v == 0.0f) ? 0.0f : v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ratio_from_key(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {  // lane: wave-uniform
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// One trajectory's samples for the cooperative clip: lane t holds epoch t.
+struct Samples {
+    float psi, phi;
+};
+
+__device__ __forceinline__ Samples gather_samples(const ResolveArgs& a, int lane, double tm, bool y_ok, int cy, int x,
+                                                  float vx) {
+    Samples s;
+    s.psi = NAN;
+    s.phi = NAN;
+    if (lane < a.T) {
+        int cx;
+        const bool x_ok = predict_index(x, vx, tm, &cx);
+        if (x_ok && y_ok) read_psi_phi(a.meta, a.psi_phi, (uint64_t)lane, cy, cx, &s.psi, &s.phi);
+    }
+    return s;
+}
+
+// Clip of ONE trajectory by the whole wavefront (T <= 64, all 64 lanes active).  Returns false when a
+// run of equal ratios mixes different (psi, phi) pairs: the exchange sort's own order then matters
+// and the caller runs the literal code for that lane.
+__device__ __forceinline__ bool clip_wave(const ResolveArgs& a, int lane, const Samples s, float* lh_out, float* flux_out,
+                                          int* obs_out) {
+    const bool valid = __builtin_isfinite(s.psi) && __builtin_isfinite(s.phi);
+    const int n = __popcll(__ballot(valid));
+    *obs_out = n;
+    if (n == 0) {  // kernels.cu:201: nothing to clip, the unclipped values stand
+        *lh_out = -1.0f;
+        *flux_out = -1.0f;
+        return true;
+    }
+    const float lc = valid ? ((s.phi != 0.0f) ? (s.psi / s.phi) : 0.0f) : 0.0f;
+    uint32_t key = valid ? ratio_sort_key(lc) : 0xffffffffu;  // invalid samples sort behind every ratio
+    uint32_t src = (uint32_t)lane;
+    wave_sort64(key, src, lane);
+    // lane i now holds the i-th smallest ratio and the epoch it came from
+    const float spsi = __shfl(s.psi, (int)src), sphi = __shfl(s.phi, (int)src);
+    const uint32_t key_next = lane_next(key);
+    const uint32_t psi_next = lane_next(__float_as_uint(spsi)), phi_next = lane_next(__float_as_uint(sphi));
+    const bool mixed_tie = (lane + 1 < n) && (key == key_next) &&
+                           (psi_next != __float_as_uint(spsi) || phi_next != __float_as_uint(sphi));
+    if (__ballot(mixed_tie) != 0) return false;
+    const float sv = ratio_from_key(key);
+
+    float sgl0 = a.params.sgl_L, sgl1 = a.params.sgl_H;
+    if ((double)sgl0 < 0.0001) sgl0 = (float)0.0001;
+    if ((double)sgl1 > 0.9999) sgl1 = (float)0.9999;
+    int pct_L = (int)((double)ceilf((float)n * sgl0) + 0.001) - 1;
+    pct_L = (pct_L < 0) ? 0 : pct_L;
+    pct_L = (pct_L >= n) ? (n - 1) : pct_L;
+    int pct_H = (int)((double)ceilf((float)n * sgl1) + 0.001) - 1;
+    pct_H = (pct_H < 0) ? 0 : pct_H;
+    pct_H = (pct_H >= n) ? (n - 1) : pct_H;
+    int median_ind = (int)(ceil((double)n * 0.5) + 0.001) - 1;
+    median_ind = (median_ind < 0) ? 0 : median_ind;
+    median_ind = (median_ind >= n) ? (n - 1) : median_ind;
+    pct_L = __builtin_amdgcn_readfirstlane(pct_L);
+    pct_H = __builtin_amdgcn_readfirstlane(pct_H);
+    median_ind = __builtin_amdgcn_readfirstlane(median_ind);
+    const float sigma_g = a.params.sigmag_coeff * (lane_value(sv, pct_H) - lane_value(sv, pct_L));
+    const float wsg = 2.0f * sigma_g;
+    const float vmed = lane_value(sv, median_ind);
+    const float min_value = vmed - wsg;
+    const float max_value = vmed + wsg;
+    // the ratios ascend, so both tests hold on a prefix of the lanes: the reference's two linear scans
+    // (kernels.cu:136-146) become population counts
+    const int below = __popcll(__ballot((lane < n) && (sv < min_value)));
+    const int upto = __popcll(__ballot((lane < n) && (sv <= max_value)));
+    const int min_keep = min(below, median_ind);
+    const int max_keep = max(median_ind + 1, upto) - 1;
+    // ((0 + v[min_keep]) + v[min_keep + 1]) + ... + v[max_keep], chained across the lanes
+    float acc_psi = 0.0f, acc_phi = 0.0f;
+    for (int i = min_keep; i <= max_keep; ++i) {
+        acc_psi = chain_add(acc_psi, spsi);
+        acc_phi = chain_add(acc_phi, sphi);
+    }
+    const float new_psi = lane_value(acc_psi, max_keep), new_phi = lane_value(acc_phi, max_keep);
+    *lh_out = lh_from_sums(new_psi, new_phi);
+    *flux_out = flux_from_sums(new_psi, new_phi);
+    return true;
+}
+
+constexpr int CLIP_BLOCK = 256;
+
+__global__ __launch_bounds__(CLIP_BLOCK) void kb_sigmag_clip_kernel(const ResolveArgs a) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (CLIP_BLOCK / WAVE) + (threadIdx.x >> 6)));
+    const int n_waves = gridDim.x * (CLIP_BLOCK / WAVE);
+    const int n_entries = *a.sg.n_entries;
+    const bool cooperative = a.T <= WAVE;
+    const double tm = (lane < a.T) ? a.times[lane] : 0.0;
+    const SigmaGScratch<WAVE> scratch = make_scratch(a.sg_scratch, a.T, (size_t)wave, lane);
+
+    unsigned long long n_clipped = 0;
+    for (int e = wave; e < n_entries; e += n_waves) {
+        const SgEntry ent = a.sg.entries[e];
+        const uint64_t mask = ent.mask;
+        n_clipped += (unsigned long long)__popcll(mask);
+        const int ty = (int)(ent.row / (uint32_t)a.tiles_x), tx = (int)(ent.row - (uint32_t)ty * (uint32_t)a.tiles_x);
+        const int x0 = tx * WAVE + a.params.x_start_min, y = ty + a.params.y_start_min;
+        const float vx = a.cands[ent.cand].vx, vy = a.cands[ent.cand].vy;
+        float lh = 0.0f, flux = 0.0f;
+        int obs = 0;
+        uint64_t literal = mask;
+        if (cooperative) {
+            literal = 0;
+            int cy = 0;
+            const bool y_ok = (lane < a.T) && predict_index(y, vy, tm, &cy);
+            // the samples of the next trajectory are fetched while this one is sorted
+            uint64_t m = mask;
+            int L = __ffsll((unsigned long long)m) - 1;
+            Samples cur = gather_samples(a, lane, tm, y_ok, cy, x0 + L, vx);
+            while (m != 0) {
+                m &= m - 1;
+                const int L_next = (m != 0) ? __ffsll((unsigned long long)m) - 1 : L;
+                Samples nxt = cur;
+                if (m != 0) nxt = gather_samples(a, lane, tm, y_ok, cy, x0 + L_next, vx);
+                float r_lh, r_flux;
+                int r_obs;
+                if (clip_wave(a, lane, cur, &r_lh, &r_flux, &r_obs)) {
+                    if (lane == L) {
+                        lh = r_lh;
+                        flux = r_flux;
+                        obs = r_obs;
+                    }
+                } else {
+                    literal |= 1ull << L;
+                }
+                cur = nxt;
+                L = L_next;
+            }
+        }
+        if ((literal >> lane) & 1) {  // kernels.cu:154-242 as written, one trajectory per lane
+            kb_trajectory trj;
+            trj.x = x0 + lane;
+            trj.y = y;
+            trj.vx = vx;
+            trj.vy = vy;
+            evaluate_trajectory_full<WAVE>(a.meta, a.psi_phi, a.times, a.params, &trj, &scratch);
+            lh = trj.lh;
+            flux = trj.flux;
+            obs = trj.obs_count;
+        }
+        if ((mask >> lane) & 1) {
+            const size_t o = (size_t)e * WAVE + lane;
+            a.sg.lh[o] = lh;
+            a.sg.flux[o] = flux;
+            a.sg.obs[o] = obs;
+        }
+    }
+    if (lane == 0) {
+        if (wave == 0) atomicAdd(&a.sg.totals[0], (unsigned long long)n_entries);
+        if (n_clipped != 0) atomicAdd(&a.sg.totals[1], n_clipped);
+    }
+}
+
+// Per-pixel selection over the clipped likelihoods: kernels.cu:318-331 in candidate order.  One wave
+// per row of 64 start pixels; the list holds (lh, reference): reference >= 0 is an entry of this
+// batch, <= -2 slot -(reference + 2) of the lists left by the batches before, -1 an empty slot.
+template <int KS>
+__global__ __launch_bounds__(256) void kb_sigmag_select_kernel(const ResolveArgs a) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int row = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (row >= a.n_rows) return;
+    const int ty = row / a.tiles_x, tx = row - ty * a.tiles_x;
+    const int x_i = tx * WAVE + lane;
+    const bool live = x_i < a.sw;
+    const size_t pixel = (size_t)ty * a.sw + x_i;
+
+    TopK<KS> top;
+    top.init();
+    const bool have_prev = a.prev.full != nullptr || a.prev.compact != nullptr;
+    if (have_prev && live) {
+        for (int s = 0; s < a.K; ++s) {
+            const float old_lh = (a.prev.compact != nullptr) ? a.prev.compact[pixel * a.K + s].lh
+                                                              : a.prev.full[pixel * a.K + s].lh;
+            const bool filled = !(old_lh == -FLT_MAX);  // placeholders carry -FLT_MAX, which nothing inserted can
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                if (k == s && filled) {
+                    top.lh[k] = old_lh;
+                    top.id[k] = -(s + 2);
+                }
+            }
+        }
+    }
+
+    const uint32_t* slot_row = a.sg.slots + (size_t)row * a.sg.batch_cands;
+    for (int c0 = 0; c0 < a.sg.batch_cands; c0 += WAVE) {
+        const uint32_t slot = (c0 + lane < a.sg.batch_cands) ? slot_row[c0 + lane] : 0u;
+        uint64_t m = __ballot(slot != 0u);
+        while (m != 0) {  // candidate order
+            const int b = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const int e = __builtin_amdgcn_readlane((int)slot, b) - 1;
+            const uint64_t mask = a.sg.entries[e].mask;
+            const float lh = a.sg.lh[(size_t)e * WAVE + lane];
+            // kernels.cu:318-320 on the clipped value (obs_count was tested before the clip and is unchanged)
+            if (((mask >> lane) & 1) && !(lh < a.params.min_lh)) top.insert(lh, e);
+        }
+    }
+
+    if (!live) return;
+    const int x = x_i + a.params.x_start_min, y = ty + a.params.y_start_min;
+    for (int s = 0; s < a.K; ++s) {
+        int ref = -1;
+        float lh_s = -FLT_MAX;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            if (k == s) {
+                ref = top.id[k];
+                lh_s = top.lh[k];
+            }
+        }
+        const size_t slot = pixel * a.K + s;
+        if (ref <= -2) {  // carried over from an earlier batch
+            const size_t from = pixel * a.K + (size_t)(-(ref + 2));
+            if (a.next.compact != nullptr) {
+                a.next.compact[slot] = a.prev.compact[from];
+            } else {
+                a.next.full[slot] = a.prev.full[from];
+            }
+            continue;
+        }
+        kb_trajectory res = placeholder_result(x, y);  // kernels.cu:293-301
+        int cand = -1;
+        if (ref >= 0) {
+            cand = (int)a.sg.entries[ref].cand;
+            res.vx = a.cands[cand].vx;
+            res.vy = a.cands[cand].vy;
+            res.lh = lh_s;
+            res.flux = a.sg.flux[(size_t)ref * WAVE + lane];
+            res.obs_count = a.sg.obs[(size_t)ref * WAVE + lane];
+        }
+        store_result(a.next, slot, res, cand);
+    }
+}
+
+int launch_sigmag_resolve(const SearchArgs& s, const ResultSink* prev, const ResultSink& next, int scratch_waves,
+                          hipStream_t stream) {
+    ResolveArgs a;
+    a.meta = s.meta;
+    a.params = s.params;
+    a.psi_phi = s.psi_phi;
+    a.times = s.times;
+    a.cands = s.cands;
+    a.sg = s.sg;
+    a.sg_scratch = s.sg_scratch;
+    a.prev = (prev != nullptr) ? *prev : ResultSink{nullptr, nullptr, 0};
+    a.next = next;
+    a.T = s.T;
+    a.K = s.K;
+    a.sw = s.sw;
+    a.sh = s.sh;
+    a.tiles_x = s.tiles_x;
+    a.n_rows = s.tiles_x * s.sh;
+    const int clip_blocks = std::max(1, scratch_waves / (CLIP_BLOCK / WAVE));
+    hipLaunchKernelGGL(kb_sigmag_clip_kernel, dim3(clip_blocks), dim3(CLIP_BLOCK), 0, stream, a);
+    KB_HIP_TRY(hipGetLastError());
+    const dim3 grid((unsigned)((a.n_rows + 3) / 4)), block(256);
+    if (a.K <= 8) {
+        hipLaunchKernelGGL((kb_sigmag_select_kernel<8>), grid, block, 0, stream, a);
+    } else if (a.K <= 16) {
+        hipLaunchKernelGGL((kb_sigmag_select_kernel<16>), grid, block, 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((kb_sigmag_select_kernel<32>), grid, block, 0, stream, a);
+    }
+    KB_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Self-test kernels of the cross-lane primitives (kb_debug_wave_ops).
+__global__ __launch_bounds__(WAVE) void kb_debug_wave_sort_kernel(const uint32_t* __restrict__ keys,
+                                                                  uint32_t* __restrict__ keys_out,
+                                                                  uint32_t* __restrict__ src_out) {
+    const int lane = threadIdx.x;
+    uint32_t key = keys[(size_t)blockIdx.x * WAVE + lane], src = (uint32_t)lane;
+    wave_sort64(key, src, lane);
+    keys_out[(size_t)blockIdx.x * WAVE + lane] = key;
+    src_out[(size_t)blockIdx.x * WAVE + lane] = src;
+}
+
+__global__ __launch_bounds__(WAVE) void kb_debug_chain_sum_kernel(const float* __restrict__ values,
+                                                                  const int* __restrict__ bounds,
+                                                                  float* __restrict__ sums) {
+    const int lane = threadIdx.x;
+    const float v = values[(size_t)blockIdx.x * WAVE + lane];
+    const int lo = bounds[2 * blockIdx.x], hi = bounds[2 * blockIdx.x + 1];
+    float acc = 0.0f;
+    for (int i = lo; i <= hi; ++i) acc = chain_add(acc, v);
+    const float r = lane_value(acc, hi);
+    if (lane == 0) sums[blockIdx.x] = r;
+}
+
+}  // namespace kb
+
+extern "C" int kb_debug_wave_ops(const uint32_t* keys_dev, uint32_t* keys_out_dev, uint32_t* src_out_dev,
+                                 const float* values_dev, const int32_t* bounds_dev, float* sums_dev, uint64_t n_waves,
+                                 void* stream_v) {
+    using namespace kb;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (n_waves == 0) return 0;
+    (void)hipGetLastError();  // a stale error of this thread (another library's probing) is not ours
+    if (keys_dev != nullptr) {
+        hipLaunchKernelGGL(kb_debug_wave_sort_kernel, dim3((unsigned)n_waves), dim3(WAVE), 0, stream, keys_dev, keys_out_dev,
+                           src_out_dev);
+    }
+    if (values_dev != nullptr) {
+        hipLaunchKernelGGL(kb_debug_chain_sum_kernel, dim3((unsigned)n_waves), dim3(WAVE), 0, stream, values_dev, bounds_dev,
+                           sums_dev);
+    }
+    KB_HIP_TRY(hipGetLastError());
+    KB_HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}

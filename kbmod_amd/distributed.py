@@ -7,23 +7,35 @@ the per-pixel top-K couples candidates, so:
 * the candidate list is split into ``world`` contiguous slices (rank r owns the
   r-th slice: for the usual (theta outer, v inner) grid that is a band of
   angles), psi/phi is replicated in every GPU's HBM;
-* each rank runs the single-GPU search over all start pixels on its slice;
-* ONE all_gather (RCCL over xGMI on GPUs; gloo in the CPU tests) exchanges the
-  per-rank ``[S*K]`` result lists, and a per-pixel K-way merge (HIP kernel
-  ``kb_merge_topk`` on device tensors, the host twin on CPU tensors) selects the
-  global top-K.  Ties go to the lower rank, i.e. to the lower global candidate
-  index.
+* each rank runs the single-GPU search over all start pixels on its slice and
+  leaves 16-byte records (lh, flux, job-wide candidate index, obs_count) per
+  slot -- ``kb_device_search_compact``; x / y follow from the slot, vx / vy from
+  the candidate, so nothing else has to travel;
+* ONE gather to rank 0 (RCCL over xGMI on GPUs: seven point-to-point transfers
+  into the root, each on its own link; gloo in the CPU tests) collects the
+  per-rank ``[S*K]`` record lists, and a per-pixel K-way merge (HIP kernel
+  ``kb_merge_compact`` on device tensors, the host twin on CPU tensors) selects
+  the global top-K and writes full trajectories.  Ties go to the lower rank,
+  i.e. to the lower job-wide candidate index.
+
+Where a pixel's likelihoods are distinct the merged list equals the list one GPU
+builds from the whole candidate list.  Where equal likelihoods compete (start
+pixels whose trajectories leave the image over the same samples) the reference's
+swap-down insertion (kernels.cu:323-330) ROTATES a run of equal values every
+time something is inserted in front of it and drops the run's first member at
+the bottom of the list, so which members of a tie survive depends on the
+interleaving of all candidates; per-rank lists cannot carry that, and the merge
+keeps the lower candidate indices instead (same likelihood values in the same
+slots, possibly a different member of the tie).
 
 torch is plumbing only here: tensors as device buffers and torch.distributed
 as the RCCL front-end.
 """
 
-import ctypes as C
-import os
-
 import numpy as np
 
-TRJ_FLOATS = 7  # 28-byte Trajectory viewed as 7 x 32-bit words
+TRJ_FLOATS = 7      # 28-byte Trajectory viewed as 7 x 32-bit words
+COMPACT_WORDS = 4   # 16-byte kb_compact_result viewed as 4 x 32-bit words
 
 
 def shard_bounds(n_items, rank, world):
@@ -33,27 +45,77 @@ def shard_bounds(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-_lib = None
-
-
 def device_lib():
-    """libkbmod_hip.so via ctypes; raises when it is not built (no fallback)."""
-    global _lib
-    if _lib is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libkbmod_hip.so")
-        if not os.path.exists(path):
-            raise RuntimeError("libkbmod_hip.so is not built; run __graft_entry__.build()")
-        _lib = C.CDLL(path)
-        _lib.kb_last_error.restype = C.c_char_p
-        _lib.kb_merge_topk.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]
-    return _lib
+    """libkbmod_hip.so via ctypes (kbmod_amd.capi); raises when it is not built (no fallback)."""
+    from kbmod_amd import capi
+
+    return capi.load_lib()
+
+
+def _bounds(x_bounds, y_bounds, K):
+    from kbmod_amd import capi
+
+    p = capi.Params()
+    p.x_start_min, p.x_start_max = int(x_bounds[0]), int(x_bounds[1])
+    p.y_start_min, p.y_start_max = int(y_bounds[0]), int(y_bounds[1])
+    p.results_per_pixel = int(K)
+    return p
+
+
+def merge_compact(gathered, x_bounds, y_bounds, K, all_cands, out=None):
+    """Merge ``gathered`` = [world, S*K, 4] compact per-rank lists (32-bit words of kb_compact_result) into
+    [S*K, 7] full trajectories.  ``all_cands``: [n, 7] float32 tensor, the job-wide candidate list (vx, vy in
+    columns 0, 1) on the same device.  Device tensors go through the HIP kernel (C ABI); CPU tensors through
+    the host twin in the pybind11 module (used by the gloo tests)."""
+    import torch
+
+    world = gathered.shape[0]
+    n_slots = gathered.shape[1]
+    if out is None:
+        out = torch.empty((n_slots, TRJ_FLOATS), dtype=torch.float32, device=gathered.device)
+    if gathered.is_cuda:
+        lib = device_lib()
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = lib.kb_merge_compact(gathered.data_ptr(), world, _bounds(x_bounds, y_bounds, K), all_cands.data_ptr(),
+                                  all_cands.shape[0], out.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError(lib.kb_last_error().decode())
+    else:
+        import kbmod_amd.search as kb
+
+        cands = [kb.Trajectory(vx=float(v[0]), vy=float(v[1])) for v in all_cands.numpy()]
+        raw = np.ascontiguousarray(gathered.numpy()).view(np.uint8).reshape(-1)
+        res = kb.merge_compact_host(raw, world, K, int(x_bounds[0]), int(x_bounds[1]), int(y_bounds[0]),
+                                    int(y_bounds[1]), cands)
+        out.copy_(torch.from_numpy(res.view(np.float32).reshape(out.shape)))
+    return out
+
+
+def gather_and_merge_compact(local_records, x_bounds, y_bounds, K, all_cands, group=None, gathered=None, out=None,
+                             dst=0):
+    """The multi-GPU exchange step: ONE gather of the per-rank compact record lists to rank ``dst`` + the
+    per-pixel merge there.  ``local_records``: [S*K, 4] int32 tensor on the rank's device.  Returns the merged
+    [S*K, 7] float32 trajectories on rank ``dst`` and None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    local_records = local_records.contiguous()
+    if rank == dst:
+        if gathered is None:
+            gathered = torch.empty((world,) + tuple(local_records.shape), dtype=local_records.dtype,
+                                   device=local_records.device)
+        dist.gather(local_records, [gathered[r] for r in range(world)], dst=dst, group=group)
+        return merge_compact(gathered, x_bounds, y_bounds, K, all_cands, out)
+    dist.gather(local_records, None, dst=dst, group=group)
+    return None
 
 
 def merge_topk(gathered, n_pixels, K, out=None):
-    """Merge ``gathered`` = [world, n_pixels*K, 7] per-rank lists into [n_pixels*K, 7].
-
-    Device tensors go through the HIP kernel (C ABI); CPU tensors through the
-    host twin in the pybind11 module (used by the gloo tests)."""
+    """Merge ``gathered`` = [world, n_pixels*K, 7] per-rank lists of full 28-byte trajectories into
+    [n_pixels*K, 7] (the exchange format for results_per_pixel > 32, which the compact search does not
+    cover)."""
     import torch
 
     world = gathered.shape[0]
@@ -74,16 +136,20 @@ def merge_topk(gathered, n_pixels, K, out=None):
     return out
 
 
-def gather_and_merge(local_results, n_pixels, K, group=None, gathered=None, out=None):
-    """The multi-GPU exchange step: one all_gather of the per-rank top-K lists +
-    per-pixel merge.  ``local_results``: [n_pixels*K, 7] float32 tensor (the
-    28-byte trajectories of this rank's search, on the rank's device)."""
+def gather_and_merge(local_results, n_pixels, K, group=None, gathered=None, out=None, dst=0):
+    """Full-record variant of the exchange: one gather of [n_pixels*K, 7] float32 lists to rank ``dst`` +
+    merge there; None on the other ranks."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    if gathered is None:
-        gathered = torch.empty((world,) + tuple(local_results.shape), dtype=local_results.dtype,
-                               device=local_results.device)
-    dist.all_gather_into_tensor(gathered.view(-1), local_results.contiguous().view(-1), group=group)
-    return merge_topk(gathered, n_pixels, K, out)
+    rank = dist.get_rank(group)
+    local_results = local_results.contiguous()
+    if rank == dst:
+        if gathered is None:
+            gathered = torch.empty((world,) + tuple(local_results.shape), dtype=local_results.dtype,
+                                   device=local_results.device)
+        dist.gather(local_results, [gathered[r] for r in range(world)], dst=dst, group=group)
+        return merge_topk(gathered, n_pixels, K, out)
+    dist.gather(local_results, None, dst=dst, group=group)
+    return None
