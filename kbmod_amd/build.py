@@ -19,8 +19,9 @@ _CSRC = os.path.join(_PKG, "csrc")
 _INC = os.path.join(_ROOT, "include")
 _LIBDIR = os.path.join(_PKG, "lib")
 
-HIP_SOURCES = ["device_memory.hip", "image_kernels.hip", "search_kernels.hip", "sigmag_kernels.hip", "result_kernels.hip", "stamp_kernels.hip"]
-HIP_HEADERS = ["kb_common.h", "search_math.h", "search_common.h", "wave_ops.h"]
+HIP_SOURCES = ["search_lds.hip", "search_lds_encoded.hip", "search_direct.hip", "search_kernels.hip", "sigmag_kernels.hip",
+               "result_kernels.hip", "device_memory.hip", "image_kernels.hip", "stamp_kernels.hip"]
+HIP_HEADERS = ["kb_common.h", "search_math.h", "search_common.h", "search_device.h", "search_lds.h", "wave_ops.h"]
 HOST_SOURCES = ["host/bindings.cpp"]
 HOST_HEADERS = ["host/common.h", "host/image_utils.h", "host/psi_phi_array.h", "host/trajectory_list.h",
                 "host/stack_search.h", "host/device_stack.h"]
@@ -74,7 +75,7 @@ def build_hip(force=False, verbose=False):
             return obj, True
         return obj, False
 
-    with ThreadPoolExecutor(max_workers=4) as pool:
+    with ThreadPoolExecutor(max_workers=6) as pool:
         results = list(pool.map(compile_one, HIP_SOURCES))
     objs = [o for o, _ in results]
     out = hip_lib_path()

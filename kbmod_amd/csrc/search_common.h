@@ -12,20 +12,31 @@
 namespace kb {
 
 constexpr int SHIFT_UNSAFE = INT32_MIN;  // dx marker: no uniform shift proven for this (candidate, epoch)
-constexpr int TILE_ROWS = 4;             // waves (rows) per 256-thread workgroup
-constexpr int CHUNK = 8;                 // candidates accumulated together per wave
+// Tile geometry of the search kernels (compile-time; tools/build_variants.sh overrides them to time
+// other shapes).  A workgroup owns 64 x TILE_ROWS start pixels, one wavefront per row, and accumulates
+// CHUNK candidates at a time.
+#ifndef KB_TILE_ROWS
+#define KB_TILE_ROWS 8
+#endif
+#ifndef KB_CHUNK
+#define KB_CHUNK 8
+#endif
+constexpr int TILE_ROWS = KB_TILE_ROWS;          // waves (rows) per workgroup
+constexpr int CHUNK = KB_CHUNK;                  // candidates accumulated together per wave
+constexpr int SEARCH_BLOCK = TILE_ROWS * WAVE;   // threads per workgroup of the search kernels
+constexpr int STAGE_ROUND = SEARCH_BLOCK * 16;   // bytes one staging round of the workgroup moves (16 per thread)
 
 // LDS staging (kb_search_lds): per (chunk, epoch) the workgroup stages a slab of
-// rows_max(chunk) x LDS_COLS raw pairs -- the union footprint of its 64 x 4 tile
-// under the chunk's shifts -- straight from a padded HBM copy of the array into
-// LDS with LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), several epochs
-// per barrier, double-buffered.
+// rows_max(chunk) x LDS_COLS raw pairs -- the union footprint of its 64 x TILE_ROWS tile
+// under the chunk's shifts -- from a padded HBM copy of the array into a ring of slab slots in LDS.
 constexpr int LDS_COLS = 88;          // slab pitch in pixels: 64 start columns + up to 24 of dx spread
                                       // (88 * {8,4,2} bytes are multiples of the 16-byte DMA granule)
-constexpr int LDS_GROUP_BYTES = 20480;  // one group buffer; two per workgroup = 40 KiB -> 4 workgroups per CU
 constexpr int LDS_ALIGN_PX = 8;         // slab origins are multiples of 8 columns of the padded frame
+constexpr int LDS_GROUP_BYTES = 5120 * TILE_ROWS;  // one group buffer; two per workgroup: 160 KiB hold 16 waves per CU
+constexpr int LDS_SLAB_MAX = LDS_GROUP_BYTES;      // largest slab that is staged
 constexpr int LDS_SLOTS = 3;            // 16-byte pieces a thread holds in registers at once; slabs beyond
-                                        // 3 x 4 KiB are copied in further, non-overlapped rounds
+                                        // 3 rounds are copied in further, non-overlapped rounds
+constexpr int SLAB_REF_SLACK = 8;       // valid slab references behind the table's last entry (prefetched, never used)
 
 struct ChunkInfo {
     int dx_min, dx_max, dy_min, dy_max;  // bounding box of the chunk's shifts over all epochs
@@ -47,6 +58,14 @@ __host__ __device__ __forceinline__ int box_dy(EpochBox b) { return b.x >> 16; }
 __host__ __device__ __forceinline__ int box_cols(EpochBox b) { return b.y & 0xffff; }
 __host__ __device__ __forceinline__ int box_rows(EpochBox b) { return b.y >> 16; }
 
+// Per (chunk, epoch): where the slab starts in the padded copy (byte offset relative to the tile's own
+// pixel) and how large it is; 16 bytes, one scalar load.
+struct SlabRef {
+    int64_t origin;
+    int32_t bytes;
+    int32_t pad;
+};
+
 // Sigma-G resolve (sigmag_kernels.hip).  With the in-search sigma-G filter the search kernels do not
 // keep a top-K: per (row of 64 start pixels, candidate) they emit the ballot of the lanes that pass the
 // unclipped thresholds (kernels.cu:201-203) as one work item; kb_sigmag_clip_kernel clips those
@@ -65,7 +84,6 @@ struct SigmaGWork {
     float* lh;         // [capacity][64] clipped likelihood of the entry's lanes
     float* flux;       // [capacity][64]
     int* obs;          // [capacity][64]
-    int cand_lo;       // first candidate of the batch in flight
     int batch_cands;   // candidates per batch (row pitch of slots)
 };
 
@@ -101,34 +119,46 @@ __device__ __forceinline__ kb_trajectory placeholder_result(int x, int y) {
     return p;
 }
 
-struct SearchArgs {
-    const void* psi_phi;
+// Arguments of the search kernels, in two parts.  SearchArgs travels by value (kernel-argument
+// segment -> SGPRs) and holds only what the accumulation loops touch; everything else -- the
+// epilogue, the rare per-lane paths, the sigma-G emit -- sits in a SearchCold block in device memory
+// and is fetched through `cold` at the point of use.  (One 440-byte by-value struct kept 50-60
+// scalar registers spilled through VGPR lanes inside the loop.)
+struct SearchCold {
+    kb_psi_phi_meta meta;
+    kb_search_params params;
     const double* times;
     const kb_trajectory* cands;
     ResultSink results;
+    const EpochBox* boxes;     // [n_chunks][T]
+    int Hp, px0, py0;          // padded height, position of image pixel (0,0) inside the padded frame
+    int fast_decode;           // uint8/uint16: the fp32-FMA decode was verified bit-identical for every code
+    float* sg_scratch;         // sigma-G per-lane scratch of the literal clip, or null
+    SigmaGWork sg;
+};
+
+struct SearchArgs {
+    const SearchCold* cold;
+    const void* psi_phi;
+    const void* padded;        // [T][Hp][Wp] raw pairs, apron = NO_DATA (kb_search_lds only)
     const int2* table;         // [n_chunks][T][C] integer shifts (dx, dy)
     const ChunkInfo* chunks;   // [n_chunks]
-    const EpochBox* boxes;     // [n_chunks][T]
-    const int64_t* origins;    // [n_chunks][T] byte offset of the slab origin inside the padded copy, relative
-                               // to the tile's own pixel (kb_slab_origin_kernel)
-    const int* lds_off;        // [n_chunks][T][C] byte offset of the shifted tile inside plane A
+    const SlabRef* slabs;      // [n_chunks][T] slab origin inside the padded copy and slab size (kb_slab_ref_kernel)
+    const int* lds_off;        // [n_chunks][T][C] byte offset of the shifted tile inside the slab
     const int* global_box;     // {dx_min, dx_max, dy_min, dy_max, rows_max} over every (candidate, epoch)
-    const void* padded;        // [T][Hp][Wp] raw pairs, apron = NO_DATA (kb_search_lds only)
-    int Wp, Hp, px0, py0;      // padded pitch / height, position of image pixel (0,0) inside the padded frame
-    const int* n_invalid;      // device counter: NO_DATA pixels inside the image (written by kb_pad_kernel)
-    int all_staged;            // every (chunk, epoch) is staged through LDS
-    kb_psi_phi_meta meta;
-    kb_search_params params;
-    int T, W, H;
+    const int* n_invalid;      // device counter: non-zero when the image holds NO_DATA pixels (kb_pad_kernel)
+    int T, W, H, Wp;
     int n_cands, n_chunks;
+    int chunk_lo, chunk_hi;    // candidate chunks [chunk_lo, chunk_hi) of this launch
     int sw, sh;
     int tiles_x, tiles_y, n_tiles;
+    int x_start_min, y_start_min;
     int K;
+    int min_obs;
+    float min_lh;
+    int all_staged;            // every (chunk, epoch) is staged through LDS
     int force_exact;
-    int fast_decode;    // uint8/uint16: the fp32-FMA decode was verified bit-identical for every code
-    float* sg_scratch;  // sigma-G per-lane scratch of the literal clip, or null
-    int chunk_lo, chunk_hi;  // candidate chunks [chunk_lo, chunk_hi) of this launch
-    SigmaGWork sg;
+    float psi_scale, psi_min_val, phi_scale, phi_min_val;  // decode of encoded samples
 };
 
 // Encoded sample -> float.  The reference decodes in double with two roundings
@@ -162,8 +192,8 @@ struct RawPair<2> {
     using type = ushort2;
     __device__ static __forceinline__ type invalid() { return make_ushort2(0, 0); }
     __device__ static __forceinline__ void decode(type r, const SearchArgs& a, float* psi, float* phi) {
-        *psi = (r.x == 0) ? NAN : decode_code((float)r.x, a.meta.psi_scale, a.meta.psi_min_val);
-        *phi = (r.y == 0) ? NAN : decode_code((float)r.y, a.meta.phi_scale, a.meta.phi_min_val);
+        *psi = (r.x == 0) ? NAN : decode_code((float)r.x, a.psi_scale, a.psi_min_val);
+        *phi = (r.y == 0) ? NAN : decode_code((float)r.y, a.phi_scale, a.phi_min_val);
     }
 };
 template <>
@@ -171,8 +201,8 @@ struct RawPair<1> {
     using type = uchar2;
     __device__ static __forceinline__ type invalid() { return make_uchar2(0, 0); }
     __device__ static __forceinline__ void decode(type r, const SearchArgs& a, float* psi, float* phi) {
-        *psi = (r.x == 0) ? NAN : decode_code((float)r.x, a.meta.psi_scale, a.meta.psi_min_val);
-        *phi = (r.y == 0) ? NAN : decode_code((float)r.y, a.meta.phi_scale, a.meta.phi_min_val);
+        *psi = (r.x == 0) ? NAN : decode_code((float)r.x, a.psi_scale, a.psi_min_val);
+        *phi = (r.y == 0) ? NAN : decode_code((float)r.y, a.phi_scale, a.phi_min_val);
     }
 };
 
@@ -185,8 +215,8 @@ struct RawPair<20> {
     __device__ static __forceinline__ type invalid() { return make_ushort2(0, 0); }
     __device__ static __forceinline__ void decode(type r, const SearchArgs& a, float* psi, float* phi) {
         const bool ok = (r.x != 0) && (r.y != 0);
-        *psi = ok ? fmaf((float)r.x - 1.0f, a.meta.psi_scale, a.meta.psi_min_val) : NAN;
-        *phi = fmaf((float)r.y - 1.0f, a.meta.phi_scale, a.meta.phi_min_val);
+        *psi = ok ? fmaf((float)r.x - 1.0f, a.psi_scale, a.psi_min_val) : NAN;
+        *phi = fmaf((float)r.y - 1.0f, a.phi_scale, a.phi_min_val);
     }
 };
 template <>
@@ -195,8 +225,8 @@ struct RawPair<10> {
     __device__ static __forceinline__ type invalid() { return make_uchar2(0, 0); }
     __device__ static __forceinline__ void decode(type r, const SearchArgs& a, float* psi, float* phi) {
         const bool ok = (r.x != 0) && (r.y != 0);
-        *psi = ok ? fmaf((float)r.x - 1.0f, a.meta.psi_scale, a.meta.psi_min_val) : NAN;
-        *phi = fmaf((float)r.y - 1.0f, a.meta.phi_scale, a.meta.phi_min_val);
+        *psi = ok ? fmaf((float)r.x - 1.0f, a.psi_scale, a.psi_min_val) : NAN;
+        *phi = fmaf((float)r.y - 1.0f, a.phi_scale, a.phi_min_val);
     }
 };
 // Bytes per encoded value of a format tag.
@@ -240,10 +270,10 @@ __device__ __forceinline__ TileCoords tile_coords(const SearchArgs& a, int b) {
     c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     c.y_i = c.ty * TILE_ROWS + c.wv;
     c.x_i = c.tx * WAVE + c.lane;
-    c.x = c.x_i + a.params.x_start_min;
-    c.y = c.y_i + a.params.y_start_min;
-    c.tile_x0 = c.tx * WAVE + a.params.x_start_min;
-    c.tile_y0 = c.ty * TILE_ROWS + a.params.y_start_min;
+    c.x = c.x_i + a.x_start_min;
+    c.y = c.y_i + a.y_start_min;
+    c.tile_x0 = c.tx * WAVE + a.x_start_min;
+    c.tile_y0 = c.ty * TILE_ROWS + a.y_start_min;
     c.row_active = c.y_i < a.sh;
     return c;
 }
@@ -299,8 +329,15 @@ __host__ __device__ constexpr size_t scratch_words_per_wave(int T) { return (siz
 // Launch geometry of the sigma-G resolve, implemented in sigmag_kernels.hip.
 // Clips every entry emitted by the search launch and merges the batch into the per-pixel lists:
 // prev (may be null for the first batch) -> next.
-int launch_sigmag_resolve(const SearchArgs& a, const ResultSink* prev, const ResultSink& next, int scratch_waves,
-                          hipStream_t stream);
+// Launchers of the search kernels (search_direct.hip, search_lds.hip, search_lds_encoded.hip).  fmt: 4 = float,
+// 2 / 1 = encoded with the reference's double-precision decode, 20 / 10 = encoded with the verified single-FMA decode.
+void launch_search_direct(const SearchArgs& a, int fmt, bool sigmag, hipStream_t stream);
+void launch_search_large_k(const SearchArgs& a, bool sigmag, int blocks, hipStream_t stream);
+void launch_search_lds_canon(const SearchArgs& a, bool sigmag, hipStream_t stream);
+bool launch_search_lds_encoded(const SearchArgs& a, int fmt, bool sigmag, hipStream_t stream);  // false: no such instance
+
+int launch_sigmag_resolve(const SearchArgs& a, const SearchCold& cold, const ResultSink* prev, const ResultSink& next,
+                          int scratch_waves, hipStream_t stream);
 
 }  // namespace kb
 #endif

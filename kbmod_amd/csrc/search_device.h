@@ -1,0 +1,176 @@
+// Device-side pieces shared by the search kernels' translation units (search_direct.hip,
+// search_lds.hip, search_lds_encoded.hip): finishing a chunk of candidates (threshold, top-K insertion
+// or sigma-G work items), the epilogue, and the direct-load accumulation that the fallback kernel and
+// the ring kernel's rare paths both use.
+#ifndef KB_SEARCH_DEVICE_H_
+#define KB_SEARCH_DEVICE_H_
+
+#include <type_traits>
+
+#include "search_common.h"
+
+#pragma clang fp contract(off)
+
+namespace kb {
+
+// Tables are read through the constant address space: the DMA writes and barriers of
+// the main loop would otherwise make the compiler fetch them with vector loads, whose
+// vmcnt wait also waits for the slab DMA in flight.
+typedef const __attribute__((address_space(4))) int* ConstIntPtr;
+template <typename P>
+__device__ __forceinline__ ConstIntPtr as_const_ints(const P* p) {
+    return (ConstIntPtr)(uintptr_t)p;
+}
+
+
+// Threshold / insertion of one chunk's C finished candidates.  With the sigma-G filter on nothing is
+// inserted here: the ballot of the lanes that pass the unclipped thresholds (kernels.cu:201-203 and
+// :318-320; this includes the obs_count == 0 corner, which the clip leaves alone) becomes one work item
+// per (row, candidate) for the resolve passes of sigmag_kernels.hip.
+template <int KS, int C, bool SIGMAG>
+__device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoords& tc, int chunk,
+                                             const float (&ps)[C], const float (&ph)[C], const int (&cnt)[C],
+                                             TopK<KS>& top) {
+    float lh[C];
+    bool take[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        lh[c] = lh_from_sums(ps[c], ph[c]);
+        take[c] = !(cnt[c] < a.min_obs);
+    }
+    if constexpr (SIGMAG) {
+        const bool live = tc.x_i < a.sw;  // lanes past the right edge of the search area own no pixel
+        // two passes over the candidates (count, then write): the ballots are cheap to form again and C
+        // 64-bit masks kept alive would cost the surrounding loop its scalar registers
+        bool pass[C];
+        int n_items = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const bool real = (chunk * C + c) < a.n_cands;  // uniform
+            pass[c] = real && live && take[c] && !(lh[c] < a.min_lh);
+            n_items += (__ballot(pass[c]) != 0) ? 1 : 0;
+        }
+        if (n_items == 0) return;  // uniform
+        const SigmaGWork& sg = a.cold->sg;
+        uint32_t base = 0;
+        if (tc.lane == 0) base = (uint32_t)atomicAdd(sg.n_entries, n_items);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t row = (uint32_t)(tc.y_i * a.tiles_x + tc.tx);
+        uint32_t* slot_row = sg.slots + (size_t)row * sg.batch_cands + (chunk - a.chunk_lo) * C;
+        SgEntry* entries = sg.entries;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const uint64_t need = __ballot(pass[c]);
+            if (need != 0) {  // uniform
+                if (tc.lane == 0) {
+                    SgEntry e;
+                    e.row = row;
+                    e.cand = (uint32_t)(chunk * C + c);
+                    e.mask = need;
+                    entries[base] = e;
+                    slot_row[c] = base + 1;
+                }
+                base += 1;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int cand = chunk * C + c;
+            if (cand >= a.n_cands) break;  // uniform
+            if (take[c]) top.insert(lh[c], cand);
+        }
+    }
+}
+
+// Epilogue (no sigma-G; with it kb_sigmag_select_kernel writes the results): the K winners are
+// re-evaluated with exact per-lane positions to produce flux / obs_count; the likelihood this yields
+// is bit-identical to the one that won the slot.
+template <int KS>
+__device__ __forceinline__ void write_results(const SearchArgs& a, const TileCoords& tc, const TopK<KS>& top) {
+    if (tc.x_i >= a.sw || !tc.row_active) return;
+    const size_t slot0 = ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
+    for (int s = 0; s < a.K; ++s) {
+        int id_s = -1;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            if (k == s) id_s = top.id[k];
+        }
+        kb_trajectory res = placeholder_result(tc.x, tc.y);  // kernels.cu:293-301
+        if (id_s >= 0) {
+            res.vx = a.cold->cands[id_s].vx;
+            res.vy = a.cold->cands[id_s].vy;
+            evaluate_trajectory_full<WAVE>(a.cold->meta, a.psi_phi, a.cold->times, a.cold->params, &res,
+                                           static_cast<const SigmaGScratch<WAVE>*>(nullptr));
+        }
+        store_result(a.cold->results, slot0 + s, res, id_s);
+    }
+}
+
+
+// MODE 0: interior wave, table shifts, no per-lane bounds test.
+// MODE 1: table shifts with per-lane bounds test (image edges / off-image starts).
+// MODE 2: exact per-lane double positions (chunks with unproven shifts, or forced).
+template <int C, int C0, int HC, int NB, int MODE>
+__device__ __forceinline__ void accumulate_chunk_direct(const SearchArgs& a, int chunk, int x, int y, int pix0,
+                                                        float (&ps)[C], float (&ph)[C], int (&cnt)[C]) {
+    using R = RawPair<NB>;
+    constexpr int BYTES = 2 * fmt_bytes(NB);
+    const int2* __restrict__ tab = a.table + (size_t)chunk * a.T * C + C0;
+    const uint64_t image_bytes = ((uint64_t)a.W * (uint64_t)a.H) * (uint64_t)BYTES;
+    const char* base = reinterpret_cast<const char*>(a.psi_phi);
+#pragma unroll 2
+    for (int t = 0; t < a.T; ++t) {
+        // Phase 1: all HC loads of this epoch are issued before anything consumes them.
+        typename R::type raw[HC];
+        bool ok[HC];
+        if constexpr (MODE == 2) {
+            const double tm = a.cold->times[t];
+#pragma unroll
+            for (int c = 0; c < HC; ++c) {
+                const int ci = min(chunk * C + C0 + c, a.n_cands - 1);
+                int cx, cy;
+                bool in = predict_index(x, a.cold->cands[ci].vx, tm, &cx);
+                in = predict_index(y, a.cold->cands[ci].vy, tm, &cy) && in;
+                ok[c] = in && ((unsigned)cx < (unsigned)a.W) && ((unsigned)cy < (unsigned)a.H);
+                const uint32_t voff = ok[c] ? (uint32_t)(cy * a.W + cx) * (uint32_t)BYTES : 0u;
+                raw[c] = *reinterpret_cast<const typename R::type*>(base + voff);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < HC; ++c) {
+                const int2 s = tab[t * C + c];  // wave-uniform -> scalar loads
+                if constexpr (MODE == 0) {
+                    ok[c] = true;
+                    const uint32_t voff = (uint32_t)(pix0 + s.y * a.W + s.x) * (uint32_t)BYTES;
+                    raw[c] = *reinterpret_cast<const typename R::type*>(base + voff);
+                } else {
+                    const int cx = x + s.x, cy = y + s.y;
+                    ok[c] = ((unsigned)cx < (unsigned)a.W) && ((unsigned)cy < (unsigned)a.H);
+                    const uint32_t voff = ok[c] ? (uint32_t)(cy * a.W + cx) * (uint32_t)BYTES : 0u;
+                    raw[c] = *reinterpret_cast<const typename R::type*>(base + voff);
+                }
+            }
+        }
+        // Phase 2: decode + accumulate in candidate order (each candidate's sums stay in epoch order).
+#pragma unroll
+        for (int c = 0; c < HC; ++c) {
+            float psi, phi;
+            R::decode(raw[c], a, &psi, &phi);
+            accumulate(psi, phi, ok[c], ps[C0 + c], ph[C0 + c], cnt[C0 + c]);
+        }
+        base += image_bytes;
+    }
+}
+
+// All C candidates of a chunk, eight at a time.
+template <int C, int NB, int MODE>
+__device__ __forceinline__ void accumulate_chunk_direct_all(const SearchArgs& a, int chunk, int x, int y, int pix0,
+                                                            float (&ps)[C], float (&ph)[C], int (&cnt)[C]) {
+    static_assert(C == 8 || C == 16, "chunk size");
+    accumulate_chunk_direct<C, 0, 8, NB, MODE>(a, chunk, x, y, pix0, ps, ph, cnt);
+    if constexpr (C == 16) accumulate_chunk_direct<C, 8, 8, NB, MODE>(a, chunk, x, y, pix0, ps, ph, cnt);
+}
+
+}  // namespace kb
+#endif

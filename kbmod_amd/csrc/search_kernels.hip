@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
         if (ex0 <= ex1) ex0 -= ((ex0 % LDS_ALIGN_PX) + LDS_ALIGN_PX) % LDS_ALIGN_PX;
         // A slab of (TILE_ROWS + dy spread) x LDS_COLS 8-byte pairs must fit one group buffer.
         const bool fits = !epoch_wild && ex0 <= ex1 && (ex1 - ex0) <= (LDS_COLS - WAVE) &&
-                          (TILE_ROWS + ey1 - ey0) * LDS_COLS * 8 <= LDS_GROUP_BYTES && ex0 > -30000 && ex1 < 30000 &&
+                          (TILE_ROWS + ey1 - ey0) * LDS_COLS * 8 <= LDS_SLAB_MAX && ex0 > -30000 && ex1 < 30000 &&
                           ey0 > -30000 && ey1 < 30000;
         EpochBox box = make_int2(0, (TILE_ROWS << 16) | WAVE);
         if (fits) {
@@ -211,176 +211,6 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
 }
 
 
-// Threshold / insertion of one chunk's C finished candidates.  With the sigma-G filter on nothing is
-// inserted here: the ballot of the lanes that pass the unclipped thresholds (kernels.cu:201-203 and
-// :318-320; this includes the obs_count == 0 corner, which the clip leaves alone) becomes one work item
-// per (row, candidate) for the resolve passes of sigmag_kernels.hip.
-template <int KS, int C, bool SIGMAG>
-__device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoords& tc, int chunk,
-                                             const float (&ps)[C], const float (&ph)[C], const int (&cnt)[C],
-                                             TopK<KS>& top) {
-    float lh[C];
-    bool take[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        lh[c] = lh_from_sums(ps[c], ph[c]);
-        take[c] = !(cnt[c] < a.params.min_observations);
-    }
-    if constexpr (SIGMAG) {
-        const bool live = tc.x_i < a.sw;  // lanes past the right edge of the search area own no pixel
-        uint64_t need[C];
-        int n_items = 0;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const bool real = (chunk * C + c) < a.n_cands;  // uniform
-            need[c] = __ballot(real && live && take[c] && !(lh[c] < a.params.min_lh));
-            n_items += (need[c] != 0) ? 1 : 0;
-        }
-        if (n_items == 0) return;  // uniform
-        uint32_t base = 0;
-        if (tc.lane == 0) base = (uint32_t)atomicAdd(a.sg.n_entries, n_items);
-        base = __builtin_amdgcn_readfirstlane(base);
-        const uint32_t row = (uint32_t)(tc.y_i * a.tiles_x + tc.tx);
-        uint32_t* slot_row = a.sg.slots + (size_t)row * a.sg.batch_cands + (chunk * C - a.sg.cand_lo);
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            if (need[c] != 0) {  // uniform
-                if (tc.lane == 0) {
-                    SgEntry e;
-                    e.row = row;
-                    e.cand = (uint32_t)(chunk * C + c);
-                    e.mask = need[c];
-                    a.sg.entries[base] = e;
-                    slot_row[c] = base + 1;
-                }
-                base += 1;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int cand = chunk * C + c;
-            if (cand >= a.n_cands) break;  // uniform
-            if (take[c]) top.insert(lh[c], cand);
-        }
-    }
-}
-
-// Epilogue (no sigma-G; with it kb_sigmag_select_kernel writes the results): the K winners are
-// re-evaluated with exact per-lane positions to produce flux / obs_count; the likelihood this yields
-// is bit-identical to the one that won the slot.
-template <int KS>
-__device__ __forceinline__ void write_results(const SearchArgs& a, const TileCoords& tc, const TopK<KS>& top) {
-    if (tc.x_i >= a.sw || !tc.row_active) return;
-    const size_t slot0 = ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
-    for (int s = 0; s < a.K; ++s) {
-        int id_s = -1;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            if (k == s) id_s = top.id[k];
-        }
-        kb_trajectory res = placeholder_result(tc.x, tc.y);  // kernels.cu:293-301
-        if (id_s >= 0) {
-            res.vx = a.cands[id_s].vx;
-            res.vy = a.cands[id_s].vy;
-            evaluate_trajectory_full<WAVE>(a.meta, a.psi_phi, a.times, a.params, &res,
-                                           static_cast<const SigmaGScratch<WAVE>*>(nullptr));
-        }
-        store_result(a.results, slot0 + s, res, id_s);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// direct-load kernel (fallback)
-// ---------------------------------------------------------------------------
-// MODE 0: interior wave, table shifts, no per-lane bounds test.
-// MODE 1: table shifts with per-lane bounds test (image edges / off-image starts).
-// MODE 2: exact per-lane double positions (chunks with unproven shifts, or forced).
-template <int C, int NB, int MODE>
-__device__ __forceinline__ void accumulate_chunk_direct(const SearchArgs& a, int chunk, int x, int y, int pix0,
-                                                        float (&ps)[C], float (&ph)[C], int (&cnt)[C]) {
-    using R = RawPair<NB>;
-    constexpr int BYTES = 2 * fmt_bytes(NB);
-    const int2* __restrict__ tab = a.table + (size_t)chunk * a.T * C;
-    const uint64_t image_bytes = a.meta.pixels_per_image * (uint64_t)BYTES;
-    const char* base = reinterpret_cast<const char*>(a.psi_phi);
-#pragma unroll 2
-    for (int t = 0; t < a.T; ++t) {
-        // Phase 1: all C loads of this epoch are issued before anything consumes them.
-        typename R::type raw[C];
-        bool ok[C];
-        if constexpr (MODE == 2) {
-            const double tm = a.times[t];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int ci = min(chunk * C + c, a.n_cands - 1);
-                int cx, cy;
-                bool in = predict_index(x, a.cands[ci].vx, tm, &cx);
-                in = predict_index(y, a.cands[ci].vy, tm, &cy) && in;
-                ok[c] = in && ((unsigned)cx < (unsigned)a.W) && ((unsigned)cy < (unsigned)a.H);
-                const uint32_t voff = ok[c] ? (uint32_t)(cy * a.W + cx) * (uint32_t)BYTES : 0u;
-                raw[c] = *reinterpret_cast<const typename R::type*>(base + voff);
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int2 s = tab[t * C + c];  // wave-uniform -> scalar loads
-                if constexpr (MODE == 0) {
-                    ok[c] = true;
-                    const uint32_t voff = (uint32_t)(pix0 + s.y * a.W + s.x) * (uint32_t)BYTES;
-                    raw[c] = *reinterpret_cast<const typename R::type*>(base + voff);
-                } else {
-                    const int cx = x + s.x, cy = y + s.y;
-                    ok[c] = ((unsigned)cx < (unsigned)a.W) && ((unsigned)cy < (unsigned)a.H);
-                    const uint32_t voff = ok[c] ? (uint32_t)(cy * a.W + cx) * (uint32_t)BYTES : 0u;
-                    raw[c] = *reinterpret_cast<const typename R::type*>(base + voff);
-                }
-            }
-        }
-        // Phase 2: decode + accumulate in candidate order (each candidate's sums stay in epoch order).
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            float psi, phi;
-            R::decode(raw[c], a, &psi, &phi);
-            accumulate(psi, phi, ok[c], ps[c], ph[c], cnt[c]);
-        }
-        base += image_bytes;
-    }
-}
-
-template <int KS, int C, int NB, bool SIGMAG>
-__global__ __launch_bounds__(256, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_search_direct(const SearchArgs a) {
-    const TileCoords tc = tile_coords(a);
-    if (!tc.row_active) return;  // whole wave (no barriers in this kernel)
-    const int pix0 = tc.y * a.W + tc.x;
-    TopK<KS> top;
-    top.init();
-
-    for (int chunk = a.chunk_lo; chunk < a.chunk_hi; ++chunk) {
-        float ps[C], ph[C];
-        int cnt[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            ps[c] = 0.0f;
-            ph[c] = 0.0f;
-            cnt[c] = 0;
-        }
-        const ChunkInfo ci = a.chunks[chunk];
-        const bool exact = a.force_exact || ci.unsafe;
-        const bool interior = (tc.tile_x0 + ci.dx_min >= 0) && (tc.tile_x0 + WAVE - 1 + ci.dx_max < a.W) &&
-                              (tc.y + ci.dy_min >= 0) && (tc.y + ci.dy_max < a.H);
-        if (exact) {
-            accumulate_chunk_direct<C, NB, 2>(a, chunk, tc.x, tc.y, pix0, ps, ph, cnt);
-        } else if (interior) {
-            accumulate_chunk_direct<C, NB, 0>(a, chunk, tc.x, tc.y, pix0, ps, ph, cnt);
-        } else {
-            accumulate_chunk_direct<C, NB, 1>(a, chunk, tc.x, tc.y, pix0, ps, ph, cnt);
-        }
-        finish_chunk<KS, C, SIGMAG>(a, tc, chunk, ps, ph, cnt, top);
-    }
-    if constexpr (!SIGMAG) write_results<KS>(a, tc, top);
-}
-
 // ---------------------------------------------------------------------------
 // LDS-staged kernel (LDS-DMA from a padded copy, several epochs per barrier)
 // ---------------------------------------------------------------------------
@@ -393,19 +223,19 @@ __global__ __launch_bounds__(256, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_se
 //    sample unconditionally -- one packed add for (psi, phi) -- and tests only the
 //    marker phi == -0 for obs_count.  A valid phi of -0 becomes +0, equally neutral.
 //  * encoded (NB bytes per value, apron = code 0): the search decodes per sample.
-// n_invalid counts the NO_DATA pixels inside the image.
+// n_invalid becomes non-zero when the image holds any NO_DATA pixel (a lower bound of their number).
 template <int NB, bool CANON>
-__global__ __launch_bounds__(256) void kb_pad_kernel(const SearchArgs a, void* __restrict__ padded,
-                                                     int* __restrict__ n_invalid) {
+__global__ __launch_bounds__(256) void kb_pad_kernel(const SearchArgs a, int Hp, int px0, int py0,
+                                                     void* __restrict__ padded, int* __restrict__ n_invalid) {
     using R = RawPair<NB>;
     const int t = blockIdx.z;
     const int y = blockIdx.y;
-    const int sy = y - a.py0;
+    const int sy = y - py0;
     int bad = 0;
     for (int x = blockIdx.x * 256 + threadIdx.x; x < a.Wp; x += gridDim.x * 256) {
-        const int sx = x - a.px0;
+        const int sx = x - px0;
         const bool in = sx >= 0 && sx < a.W && sy >= 0 && sy < a.H;
-        const size_t d = ((size_t)t * a.Hp + y) * a.Wp + x;
+        const size_t d = ((size_t)t * Hp + y) * a.Wp + x;
         const size_t sidx = ((size_t)t * a.H + (in ? sy : 0)) * a.W + (in ? sx : 0);
         const typename R::type raw = in ? reinterpret_cast<const typename R::type*>(a.psi_phi)[sidx] : R::invalid();
         float psi, phi;
@@ -423,458 +253,33 @@ __global__ __launch_bounds__(256) void kb_pad_kernel(const SearchArgs a, void* _
             reinterpret_cast<typename R::type*>(padded)[d] = raw;
         }
     }
+    // Only "none at all" matters to the search (its count-free specialisation): once the counter is known to
+    // be non-zero further waves skip the atomic, which would otherwise serialise a masked stack's whole copy.
     for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
-    if ((threadIdx.x & 63) == 0 && bad != 0) atomicAdd(n_invalid, bad);
+    if ((threadIdx.x & 63) == 0 && bad != 0 && __atomic_load_n(n_invalid, __ATOMIC_RELAXED) == 0) atomicAdd(n_invalid, bad);
 }
 
-// Tables are read through the constant address space: the DMA writes and barriers of
-// the main loop would otherwise make the compiler fetch them with vector loads, whose
-// vmcnt wait also waits for the slab DMA in flight.
-typedef const __attribute__((address_space(4))) int* ConstIntPtr;
-template <typename P>
-__device__ __forceinline__ ConstIntPtr as_const_ints(const P* p) {
-    return (ConstIntPtr)(uintptr_t)p;
-}
-
-// Slab origins as byte offsets, once the host has fixed the padded frame: the search kernel adds
-// the tile's own offset and is spared the 64-bit index arithmetic per (chunk, epoch).
-__global__ __launch_bounds__(256) void kb_slab_origin_kernel(const EpochBox* __restrict__ boxes, int64_t n, int T, int Hp,
-                                                             int Wp, int px0, int py0, int pair_bytes,
-                                                             int64_t* __restrict__ origins) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+// Slab references, once the host has fixed the padded frame: byte offset of the slab origin relative to
+// the tile's own pixel (the search kernel is spared the 64-bit index arithmetic per (chunk, epoch)) and
+// the slab's size, one 16-byte scalar load per (chunk, epoch).
+__global__ __launch_bounds__(256) void kb_slab_ref_kernel(const EpochBox* __restrict__ boxes,
+                                                          const ChunkInfo* __restrict__ chunks, int64_t n, int T, int Hp,
+                                                          int Wp, int px0, int py0, int pair_bytes,
+                                                          SlabRef* __restrict__ refs) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= n + SLAB_REF_SLACK) return;
+    const int64_t i = slot < n ? slot : n - 1;  // the entries of slack repeat the last one (loaded, never summed)
     const EpochBox box = boxes[i];
     const int t = (int)(i % T);
+    SlabRef r;
     // an epoch that is not staged copies the slab at the tile's own pixel (inside the frame, never read by
     // the sums): the search loop is spared a test per epoch
-    origins[i] = (box.x == BOX_NOT_STAGED)
-                         ? (((int64_t)t * Hp + py0) * Wp + px0) * (int64_t)pair_bytes
-                         : (((int64_t)t * Hp + box_dy(box) + py0) * Wp + box_dx(box) + px0) * (int64_t)pair_bytes;
-}
-
-// Staging map.  A slab (rows x LDS_COLS raw pairs, dense) is copied in workgroup-wide steps of
-// 4 KiB: in step j thread tid moves the 16 bytes at slab offset o = 16 * (tid + 256 j), i.e.
-// pixel p = o / BYTES = (row, col) = divmod(p, LDS_COLS) of the slab, from the padded array at
-// the slab origin plus (row * Wp + col) * BYTES.  The copy goes through registers
-// (global_load_dwordx4 -> ds_write_b128): measured on MI355X the LDS-DMA form of the same copy
-// (global_load_lds_dwordx4) sustains only ~12 B/clk/CU and stalls the issuing wave.
-struct StageLane {
-    uint32_t goff[LDS_SLOTS];
-};
-typedef uint32_t Piece __attribute__((ext_vector_type(4)));
-template <int ALIGN>
-struct __attribute__((packed, aligned(ALIGN))) PieceMem {
-    uint32_t w[4];
-};
-struct SlabRegs {
-    Piece v[LDS_SLOTS];
-};
-
-// Offsets of a thread for slabs of slab_bytes: 0 (re-read the slab's first bytes) past the slab's end.
-__device__ __forceinline__ StageLane clip_lane(const StageLane& sl, int slab_bytes) {
-    StageLane out;
-#pragma unroll
-    for (int j = 0; j < LDS_SLOTS; ++j) {
-        out.goff[j] = (16 * ((int)threadIdx.x + 256 * j) < slab_bytes) ? sl.goff[j] : 0u;
-    }
-    return out;
-}
-
-// Issue the loads of one epoch's slab; `base` = its origin in the padded copy (uniform).  All LDS_SLOTS
-// loads are issued whatever the slab size (no branch, no exec mask -- the compiler would serialise
-// masked loads with vmcnt(0)): threads past the end of the slab re-read its first bytes and do not
-// write them to LDS.
-template <int BYTES>
-__device__ __forceinline__ void load_slab(const SearchArgs& a, const StageLane& sl, const char* base, int slab_bytes,
-                                          SlabRegs& regs, int j0 = 0) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < LDS_SLOTS; ++j) {
-        uint32_t goff = sl.goff[j];
-        if (j0 != 0) {  // uniform, rare: rounds after the first compute their map on the fly
-            const int p = 16 * (tid + 256 * (j0 + j)) / BYTES;
-            const int r = p / LDS_COLS, c = p - r * LDS_COLS;
-            goff = (uint32_t)(r * a.Wp + c) * (uint32_t)BYTES;
-        }
-        // (round 0: sl already holds 0 for threads past the end of this chunk's slabs, see clip_lane)
-        const uint32_t off = (j0 == 0 || 16 * (tid + 256 * (j0 + j)) < slab_bytes) ? goff : 0u;
-        // only BYTES-aligned: the hardware takes unaligned 16-byte global loads
-        const PieceMem<(BYTES < 4 ? BYTES : 4)>* src = reinterpret_cast<const PieceMem<(BYTES < 4 ? BYTES : 4)>*>(base + off);
-        regs.v[j] = Piece{src->w[0], src->w[1], src->w[2], src->w[3]};
-    }
-}
-
-__device__ __forceinline__ void write_slab(char* dst, int slab_bytes, const SlabRegs& regs, int j0 = 0) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < LDS_SLOTS; ++j) {
-        if (4096 * (j0 + j) < slab_bytes) {  // uniform
-            const int o = 16 * (tid + 256 * (j0 + j));
-            if (o < slab_bytes) *reinterpret_cast<Piece*>(dst + o) = regs.v[j];
-        }
-    }
-}
-
-// Rounds after the first of a slab larger than LDS_SLOTS x 4 KiB (load, then write, no overlap).
-template <int BYTES>
-__device__ __forceinline__ void copy_slab_tail(const SearchArgs& a, const StageLane& sl, const char* base, int slab_bytes,
-                                               char* dst, SlabRegs& regs) {
-    for (int j0 = LDS_SLOTS; 4096 * j0 < slab_bytes; j0 += LDS_SLOTS) {
-        load_slab<BYTES>(a, sl, base, slab_bytes, regs, j0);
-        write_slab(dst, slab_bytes, regs, j0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    }
-}
-
-typedef float PairF __attribute__((ext_vector_type(2)));
-
-// One epoch that is not staged (a shift inside the guard band of a rounding boundary,
-// or a footprint larger than a slab): every lane predicts its own pixel exactly and
-// reads the array itself, like kb_search_direct's exact mode.
-template <int C, int NB>
-__device__ __forceinline__ void unstaged_epoch(const SearchArgs& a, int x, int y, int chunk, int t, PairF (&acc)[C],
-                                            int (&cnt)[C]) {
-    using R = RawPair<NB>;
-    constexpr int BYTES = 2 * fmt_bytes(NB);
-    const double tm = a.times[t];
-    const char* base = reinterpret_cast<const char*>(a.psi_phi) + (uint64_t)t * a.meta.pixels_per_image * BYTES;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const int ci = min(chunk * C + c, a.n_cands - 1);
-        int cx, cy;
-        bool in = predict_index(x, a.cands[ci].vx, tm, &cx);
-        in = predict_index(y, a.cands[ci].vy, tm, &cy) && in;
-        const bool ok = in && ((unsigned)cx < (unsigned)a.W) && ((unsigned)cy < (unsigned)a.H);
-        const uint32_t voff = ok ? (uint32_t)(cy * a.W + cx) * (uint32_t)BYTES : 0u;
-        const typename R::type raw = *reinterpret_cast<const typename R::type*>(base + voff);
-        float psi, phi;
-        R::decode(raw, a, &psi, &phi);
-        float s0 = acc[c].x, s1 = acc[c].y;
-        accumulate(psi, phi, ok, s0, s1, cnt[c]);
-        acc[c] = PairF{s0, s1};
-    }
-}
-
-// One staged epoch in which some candidate's shift is known only to +-1 pixel (v*t + 0.5 on a
-// rounding boundary): every lane predicts its own pixel with the reference's arithmetic and reads
-// it from the slab, which was sized with that slack.  No global memory traffic.
-template <int C, int SF, bool CANON>
-__device__ __forceinline__ void per_lane_epoch(const SearchArgs& a, const TileCoords& tc, int chunk, int t, int box_word,
-                                               int slab_bytes, const char* slab, PairF (&acc)[C], int (&cnt)[C]) {
-    using R = RawPair<SF>;
-    constexpr int BYTES = 2 * fmt_bytes(SF);
-    typedef const __attribute__((address_space(4))) double* ConstDoublePtr;
-    const double tm = ((ConstDoublePtr)(uintptr_t)a.times)[t];
-    const EpochBox box = make_int2(box_word, 0);
-    const int ox = tc.tile_x0 + box_dx(box), oy = tc.tile_y0 + box_dy(box);  // image coordinates of slab pixel (0, 0)
-    const int rows = slab_bytes / (LDS_COLS * BYTES);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const int ci = min(chunk * C + c, a.n_cands - 1);
-        const ConstIntPtr cw = as_const_ints(a.cands + ci);  // {vx, vy, ...}
-        int cx, cy;
-        bool in = predict_index(tc.x, __int_as_float(cw[0]), tm, &cx);
-        in = predict_index(tc.y, __int_as_float(cw[1]), tm, &cy) && in;
-        const int rx = cx - ox, ry = cy - oy;
-        const bool ok = in && ((unsigned)rx < (unsigned)LDS_COLS) && ((unsigned)ry < (unsigned)rows);
-        const int off = ok ? (ry * LDS_COLS + rx) * BYTES : 0;
-        const typename R::type raw = *reinterpret_cast<const typename R::type*>(slab + off);
-        float psi, phi;
-        R::decode(raw, a, &psi, &phi);
-        if (CANON) {
-            acc[c] += ok ? PairF{psi, phi} : PairF{0.0f, 0.0f};
-            cnt[c] += (ok && __float_as_uint(phi) != 0x80000000u) ? 1 : 0;
-        } else {
-            float s0 = acc[c].x, s1 = acc[c].y;
-            accumulate(psi, phi, ok, s0, s1, cnt[c]);
-            acc[c] = PairF{s0, s1};
-        }
-    }
-}
-
-// Staging schedule of one chunk.
-struct ChunkPlan {
-    int slab_bytes;  // rows_max * LDS_COLS * BYTES
-    int E;           // epochs per group
-    int clean;       // every epoch is staged with uniform shifts: the summing loop needs no per-epoch test
-};
-template <int BYTES>
-__device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) {
-    ChunkPlan p;
-    const ConstIntPtr ci = as_const_ints(&a.chunks[chunk]);  // {dx_min, dx_max, dy_min, dy_max, unsafe, lds_ok, rows_max}
-    p.slab_bytes = ci[6] * LDS_COLS * BYTES;
-    p.E = max(1, min(a.T, LDS_GROUP_BYTES / p.slab_bytes));
-    p.clean = (ci[4] == 0 && ci[5] != 0) ? 1 : 0;
-    return p;
-}
-
-// The whole search of one tile.  One flat software pipeline over (chunk, group): while
-// group g is summed out of one LDS buffer, group g+1 -- possibly the first group of the next
-// chunk -- is copied into the other, one slab per summed epoch: its loads are issued before
-// the epoch's sums and written to LDS after them.
-// FAST: no sample of this tile can be NO_DATA (the tile stays inside the image under
-// every shift, the array has no NO_DATA pixel, every epoch is staged): obs_count is T.
-template <int KS, int C, int NB, bool CANON, bool SIGMAG, bool FAST>
-__device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileCoords& tc, char* smem,
-                                                const StageLane& sl, TopK<KS>& top) {
-    constexpr int SF = CANON ? 4 : NB;  // staged format
-    using R = RawPair<SF>;
-    constexpr int BYTES = 2 * fmt_bytes(SF);
-    const int T = a.T;
-    const int lane_b = (tc.wv * LDS_COLS + tc.lane) * BYTES;  // this lane's start pixel inside a slab
-
-    PairF acc[C];  // (psi_sum, phi_sum) as pairs: one v_pk_add_f32 per sample
-    int cnt[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        acc[c] = PairF{0.0f, 0.0f};
-        cnt[c] = 0;
-    }
-
-    int chunk = a.chunk_lo, t0 = 0, buf = 0;
-    ChunkPlan plan = chunk_plan<BYTES>(a, chunk);
-    SlabRegs regs;
-    typedef const __attribute__((address_space(4))) int64_t* ConstI64Ptr;
-    // this tile's own pixel inside the padded copy
-    const char* tile_base = reinterpret_cast<const char*>(a.padded) + ((int64_t)tc.tile_y0 * a.Wp + tc.tile_x0) * BYTES;
-    StageLane n_sl = clip_lane(sl, plan.slab_bytes);  // staging map of the group being copied
-    {
-        const ConstI64Ptr org = (ConstI64Ptr)(uintptr_t)(a.origins + (size_t)chunk * T);
-        const int n = min(plan.E, T);
-        for (int e = 0; e < n; ++e) {
-            const int64_t o = org[e];
-            load_slab<BYTES>(a, n_sl, tile_base + o, plan.slab_bytes, regs);
-            write_slab(smem + e * plan.slab_bytes, plan.slab_bytes, regs);
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            copy_slab_tail<BYTES>(a, sl, tile_base + o, plan.slab_bytes, smem + e * plan.slab_bytes, regs);
-        }
-    }
-    __syncthreads();
-
-    while (chunk < a.chunk_hi) {
-        // next group in flight during this group's arithmetic
-        int n_chunk = chunk, n_t0 = t0 + plan.E;
-        ChunkPlan n_plan = plan;
-        if (n_t0 >= T) {
-            n_chunk = chunk + 1;
-            n_t0 = 0;
-            if (n_chunk < a.chunk_hi) {
-                n_plan = chunk_plan<BYTES>(a, n_chunk);
-                n_sl = clip_lane(sl, n_plan.slab_bytes);
-            }
-        }
-        const int n_next = (n_chunk < a.chunk_hi) ? min(n_plan.E, T - n_t0) : 0;
-        const ConstI64Ptr n_org = (ConstI64Ptr)(uintptr_t)(a.origins + (size_t)min(n_chunk, a.chunk_hi - 1) * T + n_t0);
-        char* nb = smem + (1 - buf) * LDS_GROUP_BYTES;
-        // slab e of the next group: loads issued before, LDS writes after the sums of epoch e
-        const char* n_base = tile_base;
-        auto next_load = [&](int e) -> bool {
-            if (e >= n_next) return false;
-            n_base = tile_base + n_org[e];
-            load_slab<BYTES>(a, n_sl, n_base, n_plan.slab_bytes, regs);
-            return true;
-        };
-        auto next_write = [&](int e) {
-            write_slab(nb + e * n_plan.slab_bytes, n_plan.slab_bytes, regs);
-            if (n_plan.slab_bytes > LDS_SLOTS * 4096) {  // uniform, rare
-                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-                copy_slab_tail<BYTES>(a, sl, n_base, n_plan.slab_bytes, nb + e * n_plan.slab_bytes, regs);
-            }
-        };
-
-        const ConstIntPtr offs = as_const_ints(a.lds_off + ((size_t)chunk * T + t0) * C);  // offsets for 8-byte pairs
-        const char* cb = smem + buf * LDS_GROUP_BYTES + lane_b;
-        const int n_cur = min(plan.E, T - t0);
-        // C samples of one staged epoch with uniform shifts: slab offsets o[] (scalars) -> LDS reads -> sums
-        auto sum_epoch = [&](const int (&o)[C], int e) {
-            typename R::type raw[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int off = (BYTES == 8) ? o[c] : (o[c] >> 3) * BYTES;
-                raw[c] = *reinterpret_cast<const typename R::type*>(cb + e * plan.slab_bytes + off);
-            }
-            // one wait for the C reads instead of the compiler's one per read (instruction issue is the bound)
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                if constexpr (CANON) {
-                    acc[c] += PairF{raw[c].x, raw[c].y};
-                    if (!FAST) cnt[c] += (__float_as_uint(raw[c].y) != 0x80000000u) ? 1 : 0;
-                } else {
-                    float psi, phi;
-                    R::decode(raw[c], a, &psi, &phi);
-                    if (FAST) {
-                        acc[c] += PairF{psi, phi};
-                    } else {
-                        float s0 = acc[c].x, s1 = acc[c].y;
-                        accumulate(psi, phi, true, s0, s1, cnt[c]);
-                        acc[c] = PairF{s0, s1};
-                    }
-                }
-            }
-        };
-        // Keeps the epoch's sums in front of the LDS writes of the staged slab: left alone the compiler
-        // sinks the adds behind the writes, whose vmcnt(0) then waits out the loads with nothing to overlap.
-        auto pin_sums = [&]() {
-            static_assert(C == 8, "operand list below");
-            asm volatile(""
-                         : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
-                           "+v"(acc[7]), "+v"(cnt[0]), "+v"(cnt[1]), "+v"(cnt[2]), "+v"(cnt[3]), "+v"(cnt[4]), "+v"(cnt[5]),
-                           "+v"(cnt[6]), "+v"(cnt[7])
-                         :
-                         : "memory");
-        };
-        if (FAST || plan.clean) {
-            // A block alone on its CU is bound by the chain scalar table fetch -> LDS read -> adds -> slab
-            // landed -> LDS write of one epoch (measured 4.9 ms with one block per CU against 7.4 ms with
-            // four).  The table words of epoch e + 1 (slab offsets, slab origin) are therefore fetched at
-            // the END of epoch e, behind the adds: they travel while the slab loads are waited for and
-            // written, and the lgkmcnt wait of epoch e + 1's LDS reads finds them done.  The empty asm
-            // pins the fetch behind pin_sums(); both tables have slack behind their last entry.
-            int o_cur[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) o_cur[c] = offs[c];
-            int64_t org_cur = n_org[0];
-            for (int e = 0; e < n_cur; ++e) {
-                const bool staging = e < n_next;
-                if (staging) {
-                    n_base = tile_base + org_cur;
-                    load_slab<BYTES>(a, n_sl, n_base, n_plan.slab_bytes, regs);
-                }
-                sum_epoch(o_cur, e);
-                pin_sums();
-                ConstIntPtr po = offs + (e + 1) * C;
-                ConstI64Ptr pg = n_org + (e + 1);
-                asm volatile("" : "+s"(po), "+s"(pg)::"memory");
-#pragma unroll
-                for (int c = 0; c < C; ++c) o_cur[c] = po[c];
-                org_cur = pg[0];
-                if (staging) next_write(e);
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            }
-        } else {
-            for (int e = 0; e < n_cur; ++e) {
-                const bool staging = next_load(e);
-                int o[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = offs[e * C + c];
-                if (o[0] >= 0) {
-                    sum_epoch(o, e);
-                } else if (o[0] == LDS_OFF_UNSTAGED) {
-                    unstaged_epoch<C, NB>(a, tc.x, tc.y, chunk, t0 + e, acc, cnt);
-                } else {
-                    const int bw = as_const_ints(a.boxes + (size_t)chunk * T + t0 + e)[0];
-                    per_lane_epoch<C, SF, CANON>(a, tc, chunk, t0 + e, bw, plan.slab_bytes,
-                                                 smem + buf * LDS_GROUP_BYTES + e * plan.slab_bytes, acc, cnt);
-                }
-                pin_sums();
-                if (staging) next_write(e);
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            }
-        }
-        for (int e = n_cur; e < n_next; ++e) {  // the next group holds more epochs than this one
-            if (next_load(e)) next_write(e);
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        }
-
-        if (n_chunk != chunk) {  // chunk complete: likelihoods + top-K, while the next chunk's first group lands
-            if (tc.row_active) {
-                float ps[C], ph[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    ps[c] = acc[c].x;
-                    ph[c] = acc[c].y;
-                    if (FAST) cnt[c] = T;
-                }
-                finish_chunk<KS, C, SIGMAG>(a, tc, chunk, ps, ph, cnt, top);
-            }
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                acc[c] = PairF{0.0f, 0.0f};
-                cnt[c] = 0;
-            }
-        }
-        __syncthreads();
-        buf = 1 - buf;
-        chunk = n_chunk;
-        t0 = n_t0;
-        plan = n_plan;
-    }
-}
-
-constexpr int LDS_BLOCK = TILE_ROWS * WAVE;
-
-template <int KS, int C, int NB, bool CANON, bool SIGMAG>
-// second launch bound = waves per SIMD: 4 / 3 / 2 four-wave workgroups per CU for K <= 8 / 16 / 32
-__global__ __launch_bounds__(LDS_BLOCK, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_search_lds(const SearchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // two group buffers
-    constexpr int BYTES = 2 * fmt_bytes(CANON ? 4 : NB);
-    const TileCoords tc = tile_coords(a);  // rows past the search area stay alive (barriers)
-    TopK<KS> top;
-    top.init();
-
-    StageLane sl;
-#pragma unroll
-    for (int j = 0; j < LDS_SLOTS; ++j) {
-        const int p = 16 * ((int)threadIdx.x + 256 * j) / BYTES;  // first pixel of this thread's 16 bytes
-        const int r = p / LDS_COLS, c = p - r * LDS_COLS;
-        sl.goff[j] = (uint32_t)(r * a.Wp + c) * (uint32_t)BYTES;
-    }
-
-    // Workgroup-uniform: can any sample of this tile be NO_DATA?
-    const ConstIntPtr gb = as_const_ints(a.global_box);
-    const bool fast = a.all_staged && as_const_ints(a.n_invalid)[0] == 0 && (tc.tile_x0 + gb[0] >= 0) &&
-                      (tc.tile_x0 + WAVE + gb[1] <= a.W) && (tc.tile_y0 + gb[2] >= 0) &&
-                      (tc.tile_y0 + TILE_ROWS + gb[3] <= a.H);
-    if (fast) {
-        lds_search_tile<KS, C, NB, CANON, SIGMAG, true>(a, tc, smem, sl, top);
-    } else {
-        lds_search_tile<KS, C, NB, CANON, SIGMAG, false>(a, tc, smem, sl, top);
-    }
-    if constexpr (!SIGMAG) write_results<KS>(a, tc, top);
-}
-
-// ---------------------------------------------------------------------------
-// large-K kernel (results_per_pixel > 32, e.g. TrajectoryExplorer's K up to 10 000)
-// ---------------------------------------------------------------------------
-// One lane per start pixel, candidates evaluated one at a time with exact
-// per-lane positions, the K-slot list kept in the result array itself and
-// updated with the reference's swap-down (kernels.cu:304-331).  This is the
-// reference kernel's own structure; it is only used where the register top-K
-// cannot hold the list (few start pixels x many results in practice).
-template <bool SIGMAG>
-__global__ __launch_bounds__(256) void kb_search_large_k(const SearchArgs a) {
-    // A bounded grid walks the tiles (workgroup b takes tiles b, b + gridDim.x, ...), so that the
-    // sigma-G scratch is sized by the waves of the launch and not by the search area.
-    SigmaGScratch<WAVE> scratch = {};
-    if constexpr (SIGMAG) {
-        scratch = make_scratch(a.sg_scratch, a.T, (size_t)blockIdx.x * TILE_ROWS + (threadIdx.x >> 6),
-                               threadIdx.x & (WAVE - 1));
-    }
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const TileCoords tc = tile_coords(a, tile);
-        if (!tc.row_active || tc.x_i >= a.sw) continue;
-        kb_trajectory* slots = a.results.full + ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
-        for (int s = 0; s < a.K; ++s) slots[s] = placeholder_result(tc.x, tc.y);  // kernels.cu:293-301
-        for (int cand = 0; cand < a.n_cands; ++cand) {
-            kb_trajectory cur;
-            cur.x = tc.x;
-            cur.y = tc.y;
-            cur.vx = a.cands[cand].vx;
-            cur.vy = a.cands[cand].vy;
-            evaluate_trajectory_full<WAVE>(a.meta, a.psi_phi, a.times, a.params, &cur, SIGMAG ? &scratch : nullptr);
-            if ((cur.obs_count < a.params.min_observations) || (a.params.do_sigmag_filter && cur.lh < a.params.min_lh))
-                continue;  // kernels.cu:318-320
-            if (!(cur.lh > slots[a.K - 1].lh)) continue;  // cannot displace anything
-            for (int s = 0; s < a.K; ++s) {  // kernels.cu:323-330
-                const kb_trajectory t = slots[s];
-                if (cur.lh > t.lh) {
-                    slots[s] = cur;
-                    cur = t;
-                }
-            }
-        }
-    }
+    r.origin = (box.x == BOX_NOT_STAGED)
+                       ? (((int64_t)t * Hp + py0) * Wp + px0) * (int64_t)pair_bytes
+                       : (((int64_t)t * Hp + box_dy(box) + py0) * Wp + box_dx(box) + px0) * (int64_t)pair_bytes;
+    r.bytes = chunks[i / T].rows_max * LDS_COLS * pair_bytes;
+    r.pad = 0;
+    refs[slot] = r;
 }
 
 // ---------------------------------------------------------------------------
@@ -971,8 +376,9 @@ struct Workspace {
     int device = -1;
 };
 static std::mutex g_ws_mutex;
-static Workspace g_ws[5];  // 0: shift table + chunk info, 1: literal sigma-G scratch, 2: padded array copy (LDS kernel),
-                            // 3: sigma-G work items + clipped values, 4: second per-pixel list buffer (sigma-G batches)
+static Workspace g_ws[6];  // 0: shift table + chunk info, 1: literal sigma-G scratch, 2: padded array copy (LDS kernel),
+                            // 3: sigma-G work items + clipped values, 4: second per-pixel list buffer (sigma-G batches),
+                            // 5: cold block of the kernel arguments
 
 static int ensure_workspace(int which, size_t bytes, void** out) {
     int dev = 0;
@@ -992,6 +398,14 @@ static int ensure_workspace(int which, size_t bytes, void** out) {
     return 0;
 }
 
+// ensure_workspace without the error: false when the allocation fails (the caller has a plan B).
+static bool try_workspace(int which, size_t bytes, void** out) {
+    if (ensure_workspace(which, bytes, out) == 0) return true;
+    (void)hipGetLastError();
+    *out = nullptr;
+    return false;
+}
+
 // True when fmaf(code - 1, scale, min) equals the reference's double-rounded decode for every code.
 static bool verify_fast_decode(float scale, float min_val, int num_bytes) {
     const unsigned max_code = (1u << (8 * num_bytes)) - 1u;
@@ -1004,100 +418,54 @@ static bool verify_fast_decode(float scale, float min_val, int num_bytes) {
     return true;
 }
 
-template <typename KernelT>
-static void debug_occupancy(const char* name, KernelT kernel, size_t lds, int block = 256) {
-    if (std::getenv("KBMOD_DEBUG") == nullptr) return;
-    int blocks = -1;
-    hipFuncAttributes attr;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, block, lds);
-    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel));
-    std::fprintf(stderr, "[kbmod_hip] %s: %d blocks/CU, %d VGPRs, %zu B static LDS, %zu B scratch, dyn LDS %zu\n", name,
-                 blocks, attr.numRegs, attr.sharedSizeBytes, attr.localSizeBytes, lds);
-}
-
-// which: 0 = kb_search_direct, 1 = kb_search_lds on an encoded padded copy, 2 = kb_search_lds on canonical floats
-template <int KS, int NB, bool SIGMAG>
-static void launch_variant(const SearchArgs& a, int which, hipStream_t stream) {
-    debug_occupancy("kb_search_lds", kb_search_lds<KS, CHUNK, NB, true, SIGMAG>, 2 * LDS_GROUP_BYTES, LDS_BLOCK);
-    debug_occupancy("kb_search_direct", kb_search_direct<KS, CHUNK, NB, SIGMAG>, 0);
-    const dim3 grid(a.n_tiles), block(256), lds_block(LDS_BLOCK);
-    if (which == 2) {
-        hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, NB, true, SIGMAG>), grid, lds_block, 2 * LDS_GROUP_BYTES, stream,
-                           a);
-    } else if (which == 1) {
-        if constexpr (NB != 4) {
-            hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, NB, false, SIGMAG>), grid, lds_block, 2 * LDS_GROUP_BYTES,
-                               stream, a);
-        }
-    } else {
-        hipLaunchKernelGGL((kb_search_direct<KS, CHUNK, NB, SIGMAG>), grid, block, 0, stream, a);
-    }
-}
-
-template <int KS, int NB>
-static void launch_sigmag(const SearchArgs& a, bool sigmag, int which, hipStream_t stream) {
-    if (sigmag) {
-        // the emitting instances keep no list: one set (KS = 8) serves every K
-        if constexpr (KS == 8) launch_variant<8, NB, true>(a, which, stream);
-    } else {
-        launch_variant<KS, NB, false>(a, which, stream);
-    }
-}
-
-// Format code of the array for the templates: 4 = float, 2 / 1 = encoded with the reference's
+// Format code of the array for the kernel templates: 4 = float, 2 / 1 = encoded with the reference's
 // double-precision decode, 20 / 10 = encoded with the verified single-FMA decode.
-static int format_code(const SearchArgs& a) {
-    if (a.meta.num_bytes == 1) return a.fast_decode ? 10 : 1;
-    if (a.meta.num_bytes == 2) return a.fast_decode ? 20 : 2;
+static int format_code(int num_bytes, int fast_decode) {
+    if (num_bytes == 1) return fast_decode ? 10 : 1;
+    if (num_bytes == 2) return fast_decode ? 20 : 2;
     return 4;
 }
 
-template <int KS>
-static void launch_search(const SearchArgs& a, bool sigmag, int which, hipStream_t stream) {
-    switch (format_code(a)) {
-        case 1:
-            launch_sigmag<KS, 1>(a, sigmag, which, stream);
-            break;
-        case 10:
-            launch_sigmag<KS, 10>(a, sigmag, which, stream);
-            break;
-        case 2:
-            launch_sigmag<KS, 2>(a, sigmag, which, stream);
-            break;
-        case 20:
-            launch_sigmag<KS, 20>(a, sigmag, which, stream);
-            break;
-        default:
-            launch_sigmag<KS, 4>(a, sigmag, which, stream);
-            break;
+// which: 0 = kb_search_direct, 1 = kb_search_lds on an encoded padded copy, 2 = kb_search_lds on canonical floats
+static void launch_search(const SearchArgs& a, int fmt, bool sigmag, int which, hipStream_t stream) {
+    if (which == 2) {
+        launch_search_lds_canon(a, sigmag, stream);
+    } else if (which == 1) {
+        (void)launch_search_lds_encoded(a, fmt, sigmag, stream);  // the host chose `which` knowing the instances
+    } else {
+        launch_search_direct(a, fmt, sigmag, stream);
     }
 }
 
 template <int NB>
-static void launch_pad_fmt(const SearchArgs& a, bool canon, void* padded, int* n_invalid, hipStream_t stream) {
-    const dim3 grid((unsigned)std::min<int64_t>(((int64_t)a.Wp + 255) / 256, 64), (unsigned)a.Hp, (unsigned)a.T);
+static void launch_pad_fmt(const SearchArgs& a, const SearchCold& cold, bool canon, void* padded, int* n_invalid,
+                           hipStream_t stream) {
+    const dim3 grid((unsigned)std::min<int64_t>(((int64_t)a.Wp + 255) / 256, 64), (unsigned)cold.Hp, (unsigned)a.T);
     if (canon)
-        hipLaunchKernelGGL((kb_pad_kernel<NB, true>), grid, dim3(256), 0, stream, a, padded, n_invalid);
+        hipLaunchKernelGGL((kb_pad_kernel<NB, true>), grid, dim3(256), 0, stream, a, cold.Hp, cold.px0, cold.py0, padded,
+                           n_invalid);
     else
-        hipLaunchKernelGGL((kb_pad_kernel<NB, false>), grid, dim3(256), 0, stream, a, padded, n_invalid);
+        hipLaunchKernelGGL((kb_pad_kernel<NB, false>), grid, dim3(256), 0, stream, a, cold.Hp, cold.px0, cold.py0, padded,
+                           n_invalid);
 }
 
-static void launch_pad(const SearchArgs& a, bool canon, void* padded, int* n_invalid, hipStream_t stream) {
-    switch (format_code(a)) {
+static void launch_pad(const SearchArgs& a, const SearchCold& cold, int fmt, bool canon, void* padded, int* n_invalid,
+                       hipStream_t stream) {
+    switch (fmt) {
         case 1:
-            launch_pad_fmt<1>(a, canon, padded, n_invalid, stream);
+            launch_pad_fmt<1>(a, cold, canon, padded, n_invalid, stream);
             break;
         case 10:
-            launch_pad_fmt<10>(a, canon, padded, n_invalid, stream);
+            launch_pad_fmt<10>(a, cold, canon, padded, n_invalid, stream);
             break;
         case 2:
-            launch_pad_fmt<2>(a, canon, padded, n_invalid, stream);
+            launch_pad_fmt<2>(a, cold, canon, padded, n_invalid, stream);
             break;
         case 20:
-            launch_pad_fmt<20>(a, canon, padded, n_invalid, stream);
+            launch_pad_fmt<20>(a, cold, canon, padded, n_invalid, stream);
             break;
         default:
-            launch_pad_fmt<4>(a, true, padded, n_invalid, stream);
+            launch_pad_fmt<4>(a, cold, true, padded, n_invalid, stream);
             break;
     }
 }
@@ -1150,13 +518,22 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         flags |= 1u;  // start coordinates outside the proven range of the shift table
     }
 
-    SearchArgs a;
+    SearchArgs a{};
+    SearchCold cold{};
     a.psi_phi = psi_phi_dev;
-    a.times = times_dev;
-    a.cands = cands_dev;
-    a.results = sink;
-    a.meta = *meta;
-    a.params = params;
+    cold.times = times_dev;
+    cold.cands = cands_dev;
+    cold.results = sink;
+    cold.meta = *meta;
+    cold.params = params;
+    a.x_start_min = params.x_start_min;
+    a.y_start_min = params.y_start_min;
+    a.min_obs = params.min_observations;
+    a.min_lh = params.min_lh;
+    a.psi_scale = meta->psi_scale;
+    a.psi_min_val = meta->psi_min_val;
+    a.phi_scale = meta->phi_scale;
+    a.phi_min_val = meta->phi_min_val;
     a.T = (int)meta->num_times;
     a.W = (int)meta->width;
     a.H = (int)meta->height;
@@ -1169,24 +546,14 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     a.n_tiles = a.tiles_x * a.tiles_y;
     a.K = (int)params.results_per_pixel;
     a.force_exact = (flags & 1u) ? 1 : 0;
-    a.fast_decode = 0;
+    cold.fast_decode = 0;
     if (meta->num_bytes != 4 && (flags & 8u) == 0) {  // bit 3: force the double-precision decode
-        a.fast_decode = (verify_fast_decode(meta->psi_scale, meta->psi_min_val, meta->num_bytes) &&
+        cold.fast_decode = (verify_fast_decode(meta->psi_scale, meta->psi_min_val, meta->num_bytes) &&
                          verify_fast_decode(meta->phi_scale, meta->phi_min_val, meta->num_bytes))
                                 ? 1
                                 : 0;
     }
-    a.sg_scratch = nullptr;
-    a.table = nullptr;
-    a.chunks = nullptr;
-    a.boxes = nullptr;
-    a.lds_off = nullptr;
-    a.global_box = nullptr;
-    a.origins = nullptr;
-    a.padded = nullptr;
-    a.Wp = a.Hp = a.px0 = a.py0 = 0;
-    a.n_invalid = nullptr;
-    a.all_staged = 0;
+    const int fmt = format_code(meta->num_bytes, cold.fast_decode);
 
     EventTimer table_timer(stream, stats_out != nullptr);
     EventTimer search_timer(stream, stats_out != nullptr);
@@ -1200,12 +567,12 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     // load), the staged kernel reads each slab once per workgroup and sums out of LDS.
     int which = 0;
     const bool want_lds = (flags & 2u) == 0 && (flags & 1u) == 0 && a.K <= 32 &&
-                          (a.n_chunks >= 4 || (flags & 4u) != 0);
+                          (n_cands >= 32 || (flags & 4u) != 0);
     if (n_cands > 0) {
         const size_t table_bytes = (size_t)a.n_chunks * a.T * CHUNK * sizeof(int2);
         const size_t off_bytes = ((size_t)a.n_chunks * a.T * CHUNK + 4 * CHUNK) * sizeof(int);  // + prefetch slack
         const size_t box_bytes = (size_t)a.n_chunks * a.T * sizeof(EpochBox);
-        const size_t org_bytes = ((size_t)a.n_chunks * a.T + 8) * sizeof(int64_t);  // + prefetch slack
+        const size_t org_bytes = ((size_t)a.n_chunks * a.T + SLAB_REF_SLACK) * sizeof(SlabRef);
         const size_t chunk_bytes = (size_t)a.n_chunks * sizeof(ChunkInfo);
         // NO_DATA pixel counter [1], unstaged (chunk, epoch) counter [1], staged shift box + tallest slab [5],
         // per-lane (chunk, epoch) counter [1]
@@ -1215,11 +582,11 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         char* wsc = reinterpret_cast<char*>(ws);
         a.table = reinterpret_cast<const int2*>(wsc);
         a.lds_off = reinterpret_cast<const int*>(wsc + table_bytes);
-        a.boxes = reinterpret_cast<const EpochBox*>(wsc + table_bytes + off_bytes);
+        cold.boxes = reinterpret_cast<const EpochBox*>(wsc + table_bytes + off_bytes);
         a.chunks = reinterpret_cast<const ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes);
         int* inv = reinterpret_cast<int*>(wsc + table_bytes + off_bytes + box_bytes + chunk_bytes);
-        int64_t* origins = reinterpret_cast<int64_t*>(wsc + table_bytes + off_bytes + box_bytes + chunk_bytes + inv_bytes);
-        a.origins = origins;
+        SlabRef* slab_refs = reinterpret_cast<SlabRef*>(wsc + table_bytes + off_bytes + box_bytes + chunk_bytes + inv_bytes);
+        a.slabs = slab_refs;
         int* n_invalid = inv;
         int* n_not_lds = inv + 1;
         int* gbox = inv + 2;
@@ -1257,8 +624,16 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 const int64_t x_lo = (int64_t)params.x_start_min + back[1];
                 const int64_t x_hi = (int64_t)params.x_start_min + (int64_t)WAVE * (a.tiles_x - 1) + back[2] + LDS_COLS;
                 const int64_t y_lo = (int64_t)params.y_start_min + back[3];
+                // rows a slab's staging rounds can touch (whole rounds are loaded, see load_slab), for either
+                // staged format
+                auto rows_touched = [&](uint64_t pair_b) {
+                    const uint64_t row_b = (uint64_t)LDS_COLS * pair_b;
+                    const uint64_t rounds = ((uint64_t)back[5] * row_b + STAGE_ROUND - 1) / STAGE_ROUND;
+                    return (int64_t)((rounds * STAGE_ROUND + row_b - 1) / row_b);
+                };
+                const int64_t rows_cap = std::max(rows_touched(8), rows_touched(2ull * (uint64_t)meta->block_size));
                 const int64_t y_hi =
-                        (int64_t)params.y_start_min + (int64_t)TILE_ROWS * (a.tiles_y - 1) + back[4] + back[5];
+                        (int64_t)params.y_start_min + (int64_t)TILE_ROWS * (a.tiles_y - 1) + back[4] + rows_cap;
                 int64_t px0 = std::max<int64_t>(0, -x_lo), py0 = std::max<int64_t>(0, -y_lo);
                 // slab alignment (kb_shift_table_kernel): x_start_min + px0 is a multiple of LDS_ALIGN_PX,
                 // the row pitch a multiple of 16 pixels
@@ -1269,30 +644,33 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 const uint64_t image = (uint64_t)a.T * (uint64_t)a.H * (uint64_t)a.W;
                 // Canonical floats unless the caller keeps the array encoded or HBM is short.
                 bool canon = meta->num_bytes == 4 || (flags & 16u) == 0;
-                if (canon && meta->num_bytes != 4) {
-                    size_t free_b = 0, total_b = 0;
-                    KB_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-                    const uint64_t have = g_ws[2].ptr != nullptr ? g_ws[2].bytes : 0;
-                    if (frame * 8ull + 64 > have && frame * 8ull + (2ull << 30) > (uint64_t)free_b + have) canon = false;
-                }
+                const bool encoded_instance = params.do_sigmag_filter != 0 || a.K <= 8;  // search_lds_encoded.hip
+                size_t free_b = 0, total_b = 0;
+                KB_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+                const uint64_t have = g_ws[2].ptr != nullptr ? g_ws[2].bytes : 0;
+                auto room_for = [&](uint64_t bytes) { return bytes <= have || bytes + (2ull << 30) <= (uint64_t)free_b + have; };
+                if (canon && meta->num_bytes != 4 && !room_for(frame * 8ull + 64)) canon = false;
                 const uint64_t pair_bytes = canon ? 8ull : 2ull * (uint64_t)meta->block_size;
                 const uint64_t padded_bytes = frame * pair_bytes + 64;
-                // Per-lane DMA offsets are 32-bit; an apron that outweighs the image 3:1 is not worth staging.
-                if ((uint64_t)back[5] * (uint64_t)Wp * pair_bytes <= 0x7fffffffull && frame <= 4ull * image + (8ull << 20)) {
-                    void* padded = nullptr;
-                    if (ensure_workspace(2, padded_bytes, &padded)) return 1;
+                // Per-lane offsets are 32-bit; an apron that outweighs the image 3:1 is not worth staging; and
+                // without room for the copy in HBM (or if its allocation fails) the search reads the array itself
+                // (kb_search_direct), which needs no workspace beyond the tables.
+                void* padded = nullptr;
+                if ((canon || encoded_instance) && (uint64_t)rows_cap * (uint64_t)Wp * pair_bytes <= 0x7fffffffull &&
+                    frame <= 4ull * image + (8ull << 20) && room_for(padded_bytes) && try_workspace(2, padded_bytes, &padded)) {
                     a.padded = padded;
                     a.Wp = (int)Wp;
-                    a.Hp = (int)Hp;
-                    a.px0 = (int)px0;
-                    a.py0 = (int)py0;
+                    cold.Hp = (int)Hp;
+                    cold.px0 = (int)px0;
+                    cold.py0 = (int)py0;
                     // bit 5 (debug): never take the count-free specialisation
-                    a.all_staged = (back[0] == 0 && back[6] == 0 && (flags & 32u) == 0) ? 1 : 0;
-                    launch_pad(a, canon, padded, n_invalid, stream);
+                    a.all_staged = (back[0] == 0 && (flags & 32u) == 0) ? 1 : 0;
+                    launch_pad(a, cold, fmt, canon, padded, n_invalid, stream);
                     KB_HIP_TRY(hipGetLastError());
                     const int64_t n_org = (int64_t)a.n_chunks * a.T;
-                    hipLaunchKernelGGL(kb_slab_origin_kernel, dim3((unsigned)((n_org + 255) / 256)), dim3(256), 0, stream,
-                                       a.boxes, n_org, a.T, a.Hp, a.Wp, a.px0, a.py0, (int)pair_bytes, origins);
+                    hipLaunchKernelGGL(kb_slab_ref_kernel, dim3((unsigned)((n_org + SLAB_REF_SLACK + 255) / 256)), dim3(256), 0, stream,
+                                       cold.boxes, a.chunks, n_org, a.T, cold.Hp, a.Wp, cold.px0, cold.py0, (int)pair_bytes,
+                                       slab_refs);
                     KB_HIP_TRY(hipGetLastError());
                     which = canon ? 2 : 1;
                 }
@@ -1304,7 +682,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     const bool sigmag = params.do_sigmag_filter != 0;
     a.chunk_lo = 0;
     a.chunk_hi = a.n_chunks;
-    a.sg = SigmaGWork{};
+    cold.sg = SigmaGWork{};
 
     // Sigma-G: the search launch emits work items, two more launches resolve them (sigmag_kernels.hip).
     // Work items are bounded by rows x candidates; the candidate list is cut into batches of whole
@@ -1322,7 +700,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         resolve_waves = std::max(cus, 1) * 8 * TILE_ROWS;
         void* sg = nullptr;
         if (ensure_workspace(1, (size_t)resolve_waves * scratch_words_per_wave(a.T) * sizeof(float), &sg)) return 1;
-        a.sg_scratch = reinterpret_cast<float*>(sg);
+        cold.sg_scratch = reinterpret_cast<float*>(sg);
     }
     if (sigmag && a.K <= 32) {
         uint64_t cap_limit = 4ull << 20;
@@ -1337,15 +715,15 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         void* w = nullptr;
         if (ensure_workspace(3, slot_bytes + 256 + entry_bytes + 3 * out_bytes, &w)) return 1;
         char* wc = reinterpret_cast<char*>(w);
-        a.sg.slots = reinterpret_cast<uint32_t*>(wc);
-        a.sg.n_entries = reinterpret_cast<int*>(wc + slot_bytes);
-        a.sg.totals = reinterpret_cast<unsigned long long*>(wc + slot_bytes + 64);
-        KB_HIP_TRY(hipMemsetAsync(a.sg.totals, 0, 2 * sizeof(unsigned long long), stream));
-        a.sg.entries = reinterpret_cast<SgEntry*>(wc + slot_bytes + 256);
-        a.sg.lh = reinterpret_cast<float*>(wc + slot_bytes + 256 + entry_bytes);
-        a.sg.flux = reinterpret_cast<float*>(wc + slot_bytes + 256 + entry_bytes + out_bytes);
-        a.sg.obs = reinterpret_cast<int*>(wc + slot_bytes + 256 + entry_bytes + 2 * out_bytes);
-        a.sg.batch_cands = batch_chunks * CHUNK;
+        cold.sg.slots = reinterpret_cast<uint32_t*>(wc);
+        cold.sg.n_entries = reinterpret_cast<int*>(wc + slot_bytes);
+        cold.sg.totals = reinterpret_cast<unsigned long long*>(wc + slot_bytes + 64);
+        KB_HIP_TRY(hipMemsetAsync(cold.sg.totals, 0, 2 * sizeof(unsigned long long), stream));
+        cold.sg.entries = reinterpret_cast<SgEntry*>(wc + slot_bytes + 256);
+        cold.sg.lh = reinterpret_cast<float*>(wc + slot_bytes + 256 + entry_bytes);
+        cold.sg.flux = reinterpret_cast<float*>(wc + slot_bytes + 256 + entry_bytes + out_bytes);
+        cold.sg.obs = reinterpret_cast<int*>(wc + slot_bytes + 256 + entry_bytes + 2 * out_bytes);
+        cold.sg.batch_cands = batch_chunks * CHUNK;
         if (n_batches > 1) {
             void* pp = nullptr;
             if (ensure_workspace(4, (size_t)expected * sizeof(kb_trajectory), &pp)) return 1;
@@ -1353,15 +731,21 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         }
     }
 
+    // the cold block of the kernel arguments (search_common.h) lives in device memory
+    void* cold_dev = nullptr;
+    if (ensure_workspace(5, sizeof(SearchCold), &cold_dev)) return 1;
+    a.cold = reinterpret_cast<const SearchCold*>(cold_dev);
+    KB_HIP_TRY(hipMemcpyAsync(cold_dev, &cold, sizeof(SearchCold), hipMemcpyHostToDevice, stream));
+
     search_timer.begin();
     int variant;
     if (a.K > 32) {
         if (sink.compact != nullptr) return fail("compact results support results_per_pixel <= 32");
         if (sigmag) {
             const int blocks = std::max(1, std::min(a.n_tiles, resolve_waves / TILE_ROWS));
-            hipLaunchKernelGGL((kb_search_large_k<true>), dim3(blocks), dim3(256), 0, stream, a);
+            launch_search_large_k(a, true, blocks, stream);
         } else {
-            hipLaunchKernelGGL((kb_search_large_k<false>), dim3(a.n_tiles), dim3(256), 0, stream, a);
+            launch_search_large_k(a, false, a.n_tiles, stream);
         }
         variant = 99;
     } else if (sigmag) {
@@ -1377,25 +761,18 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         for (int b = 0; b < n_batches; ++b) {
             a.chunk_lo = b * batch_chunks;
             a.chunk_hi = std::min(a.n_chunks, a.chunk_lo + batch_chunks);
-            a.sg.cand_lo = a.chunk_lo * CHUNK;
-            KB_HIP_TRY(hipMemsetAsync(a.sg.slots, 0, (size_t)n_rows * a.sg.batch_cands * sizeof(uint32_t), stream));
-            KB_HIP_TRY(hipMemsetAsync(a.sg.n_entries, 0, sizeof(int), stream));
-            if (a.chunk_lo < a.chunk_hi) launch_search<8>(a, true, which, stream);  // the emitting instances keep no list
+            KB_HIP_TRY(hipMemsetAsync(cold.sg.slots, 0, (size_t)n_rows * cold.sg.batch_cands * sizeof(uint32_t), stream));
+            KB_HIP_TRY(hipMemsetAsync(cold.sg.n_entries, 0, sizeof(int), stream));
+            if (a.chunk_lo < a.chunk_hi) launch_search(a, fmt, true, which, stream);  // the emitting instances keep no list
             KB_HIP_TRY(hipGetLastError());
             const ResultSink* next = &bufs[(n_batches - 1 - b) % 2];
-            if (launch_sigmag_resolve(a, prev, *next, resolve_waves, stream)) return 1;
+            if (launch_sigmag_resolve(a, cold, prev, *next, resolve_waves, stream)) return 1;
             prev = next;
         }
         variant = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
-    } else if (a.K <= 8) {
-        launch_search<8>(a, false, which, stream);
-        variant = 8;
-    } else if (a.K <= 16) {
-        launch_search<16>(a, false, which, stream);
-        variant = 16;
     } else {
-        launch_search<32>(a, false, which, stream);
-        variant = 32;
+        launch_search(a, fmt, false, which, stream);
+        variant = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
     }
     KB_HIP_TRY(hipGetLastError());
     search_ms = search_timer.end();
@@ -1404,7 +781,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         KB_HIP_TRY(hipMemcpyAsync(&bad, a.n_invalid, sizeof(int), hipMemcpyDeviceToHost, stream));
         KB_HIP_TRY(hipStreamSynchronize(stream));
         std::fprintf(stderr, "[kbmod_hip] padded frame %d x %d (image at %d, %d), NO_DATA pixels %d, all_staged %d\n", a.Wp,
-                     a.Hp, a.px0, a.py0, bad, a.all_staged);
+                     cold.Hp, cold.px0, cold.py0, bad, a.all_staged);
     }
 
     if (stats_out != nullptr) {
@@ -1420,9 +797,9 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                                                : (which == 1 ? stats_out->num_evals * 2ull * (uint64_t)meta->block_size : 0ull);
         stats_out->sigmag_work_items = 0;
         stats_out->sigmag_trajectories = 0;
-        if (a.sg.totals != nullptr) {
+        if (cold.sg.totals != nullptr) {
             unsigned long long totals[2] = {0, 0};
-            KB_HIP_TRY(hipMemcpyAsync(totals, a.sg.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
+            KB_HIP_TRY(hipMemcpyAsync(totals, cold.sg.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
             KB_HIP_TRY(hipStreamSynchronize(stream));
             stats_out->sigmag_work_items = totals[0];
             stats_out->sigmag_trajectories = totals[1];
@@ -1539,3 +916,4 @@ void kb_sigmag_filtered_indices(const float* values, int num_values, float sgl0,
 }
 
 }  // extern "C"
+

@@ -299,16 +299,16 @@ __global__ __launch_bounds__(256) void kb_sigmag_select_kernel(const ResolveArgs
     }
 }
 
-int launch_sigmag_resolve(const SearchArgs& s, const ResultSink* prev, const ResultSink& next, int scratch_waves,
-                          hipStream_t stream) {
+int launch_sigmag_resolve(const SearchArgs& s, const SearchCold& cold, const ResultSink* prev, const ResultSink& next,
+                          int scratch_waves, hipStream_t stream) {
     ResolveArgs a;
-    a.meta = s.meta;
-    a.params = s.params;
+    a.meta = cold.meta;
+    a.params = cold.params;
     a.psi_phi = s.psi_phi;
-    a.times = s.times;
-    a.cands = s.cands;
-    a.sg = s.sg;
-    a.sg_scratch = s.sg_scratch;
+    a.times = cold.times;
+    a.cands = cold.cands;
+    a.sg = cold.sg;
+    a.sg_scratch = cold.sg_scratch;
     a.prev = (prev != nullptr) ? *prev : ResultSink{nullptr, nullptr, 0};
     a.next = next;
     a.T = s.T;

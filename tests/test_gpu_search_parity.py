@@ -87,7 +87,10 @@ def test_lds_kernel(kb, orc, stack, lds_cands, cfg, num_bytes, staging):
     if staging == "lds_encoded" and num_bytes == -1:
         pytest.skip("float arrays are always staged as canonical floats")
     got, exp, s = util.run_both(kb, orc, stack, *lds_cands, cfg, num_bytes=num_bytes, flags=KERNELS[staging])
-    _check_kernel(s, staging, num_bytes)
+    if staging == "lds_encoded" and cfg.get("K", 8) > 8 and "sigmag" not in cfg:
+        assert _variant(s) == 0  # encoded staging is built for lists up to 8 only: longer ones read the array itself
+    else:
+        _check_kernel(s, staging, num_bytes)
     _check(got, exp)
 
 

@@ -2,6 +2,7 @@
 """Register / spill / scratch figures of every kernel of libkbmod_hip.so (from the code-object notes).
 
     python tools/kernel_resources.py [substring ...]
+    KB_OBJ_DIR=/tmp/objs python tools/kernel_resources.py ...   (objects of a variant build)
 """
 import os
 import re
@@ -10,7 +11,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OBJ = os.path.join(ROOT, "kbmod_amd", "_obj")
+OBJ = os.environ.get("KB_OBJ_DIR", os.path.join(ROOT, "kbmod_amd", "_obj"))
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
