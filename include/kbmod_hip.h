@@ -126,7 +126,9 @@ int kb_generate_psi_phi_host(const float* sci_host, const float* var_host, int w
  *      when K > 32, or when the apron of the padded copy would outweigh the image;
  *   8  always decode uint8/uint16 samples in double (skip the verified fp32-FMA form);
  *  16  keep an encoded array encoded in the padded copy (default: canonical floats when HBM
- *      has room, which makes the search as fast as on a float array).
+ *      has room, which makes the search as fast as on a float array);
+ *  64 / 128  kb_search_lds with 64 x 16 / 64 x 8 start-pixel tiles whatever the search area (default:
+ *      64 x 16 for lists of up to 8 results per pixel when that still gives >= 128 tiles).
  * The library keeps its workspaces (shift tables, sigma-G scratch, padded copy) between
  * calls; kb_release_workspaces() returns them. */
 int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,

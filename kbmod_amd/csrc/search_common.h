@@ -12,43 +12,47 @@
 namespace kb {
 
 constexpr int SHIFT_UNSAFE = INT32_MIN;  // dx marker: no uniform shift proven for this (candidate, epoch)
-// Tile geometry of the search kernels (compile-time; tools/build_variants.sh overrides them to time
-// other shapes).  A workgroup owns 64 x TILE_ROWS start pixels, one wavefront per row, and accumulates
-// CHUNK candidates at a time.
-#ifndef KB_TILE_ROWS
-#define KB_TILE_ROWS 8
-#endif
+// Tile geometry of the search kernels.  A workgroup owns 64 x ROWS start pixels, one wavefront per row
+// (ROWS is a template parameter of the kernels, a runtime value in the tables built for them), and
+// accumulates CHUNK candidates at a time.  kb_search_lds runs 64 x 16 tiles (one 16-wave workgroup per
+// CU: the taller the tile, the less of each staged slab is apron) for lists of up to 8 results per pixel
+// and 64 x 8 tiles (register budget of 2 waves per SIMD) for longer ones; the direct kernels, which
+// share nothing between their waves, keep 64 x 4.
 #ifndef KB_CHUNK
 #define KB_CHUNK 8
 #endif
-constexpr int TILE_ROWS = KB_TILE_ROWS;          // waves (rows) per workgroup
-constexpr int CHUNK = KB_CHUNK;                  // candidates accumulated together per wave
-constexpr int SEARCH_BLOCK = TILE_ROWS * WAVE;   // threads per workgroup of the search kernels
-constexpr int STAGE_ROUND = SEARCH_BLOCK * 16;   // bytes one staging round of the workgroup moves (16 per thread)
+constexpr int CHUNK = KB_CHUNK;    // candidates accumulated together per wave
+constexpr int DIRECT_ROWS = 4;     // kb_search_direct / kb_search_large_k
+constexpr int LDS_ROWS_TALL = 16;  // kb_search_lds, K <= 8 (and the sigma-G emit)
+constexpr int LDS_ROWS_WIDE_K = 8; // kb_search_lds, 8 < K <= 32; also small search areas
+__host__ __device__ constexpr int block_threads(int rows) { return rows * WAVE; }
+__host__ __device__ constexpr int stage_round(int rows) { return rows * WAVE * 16; }  // bytes one staging round moves
+__host__ __device__ constexpr int lds_group_bytes(int rows) { return 5120 * rows; }   // one of the two group buffers
 
 // LDS staging (kb_search_lds): per (chunk, epoch) the workgroup stages a slab of
-// rows_max(chunk) x LDS_COLS raw pairs -- the union footprint of its 64 x TILE_ROWS tile
+// rows_max(chunk) x LDS_COLS raw pairs -- the union footprint of its 64 x ROWS tile
 // under the chunk's shifts -- from a padded HBM copy of the array into a ring of slab slots in LDS.
 constexpr int LDS_COLS = 88;          // slab pitch in pixels: 64 start columns + up to 24 of dx spread
                                       // (88 * {8,4,2} bytes are multiples of the 16-byte DMA granule)
 constexpr int LDS_ALIGN_PX = 8;         // slab origins are multiples of 8 columns of the padded frame
-constexpr int LDS_GROUP_BYTES = 5120 * TILE_ROWS;  // one group buffer; two per workgroup: 160 KiB hold 16 waves per CU
-constexpr int LDS_SLAB_MAX = LDS_GROUP_BYTES;      // largest slab that is staged
-constexpr int LDS_SLOTS = 3;            // 16-byte pieces a thread holds in registers at once; slabs beyond
-                                        // 3 rounds are copied in further, non-overlapped rounds
+#ifndef KB_LDS_SLOTS
+#define KB_LDS_SLOTS 2
+#endif
+constexpr int LDS_SLOTS = KB_LDS_SLOTS;  // 16-byte pieces a thread holds in registers at once; slabs beyond that many
+                                         // rounds are copied in further, non-overlapped rounds
 constexpr int SLAB_REF_SLACK = 8;       // valid slab references behind the table's last entry (prefetched, never used)
 
 struct ChunkInfo {
     int dx_min, dx_max, dy_min, dy_max;  // bounding box of the chunk's shifts over all epochs
     int unsafe;                          // any entry flagged SHIFT_UNSAFE
     int lds_ok;                          // every epoch's footprint fits one LDS slab
-    int rows_max;                        // TILE_ROWS + largest dy spread of any epoch (slab height)
+    int rows_max;                        // tile rows + largest dy spread of any epoch (slab height)
     int pad;
 };
 
 // Per (chunk, epoch) footprint, packed for one 8-byte scalar load:
 //   x = (dy_min << 16) | (dx_min & 0xffff)   origin of the staged region relative to the tile
-//   y = (rows   << 16) | cols                64 + dx spread, TILE_ROWS + dy spread
+//   y = (rows   << 16) | cols                64 + dx spread, tile rows + dy spread
 using EpochBox = int2;
 constexpr int BOX_NOT_STAGED = (int)0x80008000u;  // word 0 of an epoch that kb_search_lds does not stage
 constexpr int LDS_OFF_UNSTAGED = -1;
@@ -257,6 +261,7 @@ struct TileCoords {
     bool row_active;
 };
 
+template <int ROWS>
 __device__ __forceinline__ TileCoords tile_coords(const SearchArgs& a, int b) {
     // XCD-aware tile order: workgroup b runs on XCD (b % 8); give each XCD a
     // contiguous band of tiles so that its private L2 sees one image region.
@@ -268,12 +273,12 @@ __device__ __forceinline__ TileCoords tile_coords(const SearchArgs& a, int b) {
     c.tx = tile - c.ty * a.tiles_x;
     c.lane = threadIdx.x & (WAVE - 1);
     c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    c.y_i = c.ty * TILE_ROWS + c.wv;
+    c.y_i = c.ty * ROWS + c.wv;
     c.x_i = c.tx * WAVE + c.lane;
     c.x = c.x_i + a.x_start_min;
     c.y = c.y_i + a.y_start_min;
     c.tile_x0 = c.tx * WAVE + a.x_start_min;
-    c.tile_y0 = c.ty * TILE_ROWS + a.y_start_min;
+    c.tile_y0 = c.ty * ROWS + a.y_start_min;
     c.row_active = c.y_i < a.sh;
     return c;
 }
@@ -321,7 +326,10 @@ __device__ __forceinline__ SigmaGScratch<WAVE> make_scratch(float* sg_scratch, i
     return s;
 }
 
-__device__ __forceinline__ TileCoords tile_coords(const SearchArgs& a) { return tile_coords(a, (int)blockIdx.x); }
+template <int ROWS>
+__device__ __forceinline__ TileCoords tile_coords(const SearchArgs& a) {
+    return tile_coords<ROWS>(a, (int)blockIdx.x);
+}
 
 // Words of a scratch slot.
 __host__ __device__ constexpr size_t scratch_words_per_wave(int T) { return (size_t)(4 * T) * WAVE; }
@@ -333,8 +341,8 @@ __host__ __device__ constexpr size_t scratch_words_per_wave(int T) { return (siz
 // 2 / 1 = encoded with the reference's double-precision decode, 20 / 10 = encoded with the verified single-FMA decode.
 void launch_search_direct(const SearchArgs& a, int fmt, bool sigmag, hipStream_t stream);
 void launch_search_large_k(const SearchArgs& a, bool sigmag, int blocks, hipStream_t stream);
-void launch_search_lds_canon(const SearchArgs& a, bool sigmag, hipStream_t stream);
-bool launch_search_lds_encoded(const SearchArgs& a, int fmt, bool sigmag, hipStream_t stream);  // false: no such instance
+void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, hipStream_t stream);
+void launch_search_lds_encoded(const SearchArgs& a, int rows, int fmt, bool sigmag, hipStream_t stream);
 
 int launch_sigmag_resolve(const SearchArgs& a, const SearchCold& cold, const ResultSink* prev, const ResultSink& next,
                           int scratch_waves, hipStream_t stream);

@@ -31,24 +31,25 @@ template <int KS, int C, bool SIGMAG>
 __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoords& tc, int chunk,
                                              const float (&ps)[C], const float (&ph)[C], const int (&cnt)[C],
                                              TopK<KS>& top) {
-    float lh[C];
-    bool take[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        lh[c] = lh_from_sums(ps[c], ph[c]);
-        take[c] = !(cnt[c] < a.min_obs);
-    }
+    // The candidates are finished strictly one after the other: each likelihood (a correctly rounded
+    // sqrt and divide, a dozen temporaries) is tied by an empty asm to the state the previous candidate
+    // left, so that the compiler cannot run the C of them side by side and charge the kernel's main
+    // loop with their registers.
     if constexpr (SIGMAG) {
         const bool live = tc.x_i < a.sw;  // lanes past the right edge of the search area own no pixel
         // two passes over the candidates (count, then write): the ballots are cheap to form again and C
         // 64-bit masks kept alive would cost the surrounding loop its scalar registers
-        bool pass[C];
+        uint32_t pass_bits = 0;
         int n_items = 0;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
+            float p = ps[c], f = ph[c];
+            asm volatile("" : "+v"(p), "+v"(f), "+v"(pass_bits));
+            const float lh = lh_from_sums(p, f);
             const bool real = (chunk * C + c) < a.n_cands;  // uniform
-            pass[c] = real && live && take[c] && !(lh[c] < a.min_lh);
-            n_items += (__ballot(pass[c]) != 0) ? 1 : 0;
+            const bool pass = real && live && !(cnt[c] < a.min_obs) && !(lh < a.min_lh);
+            pass_bits |= pass ? (1u << c) : 0u;
+            n_items += (__ballot(pass) != 0) ? 1 : 0;
         }
         if (n_items == 0) return;  // uniform
         const SigmaGWork& sg = a.cold->sg;
@@ -60,7 +61,7 @@ __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoor
         SgEntry* entries = sg.entries;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const uint64_t need = __ballot(pass[c]);
+            const uint64_t need = __ballot(((pass_bits >> c) & 1u) != 0u);
             if (need != 0) {  // uniform
                 if (tc.lane == 0) {
                     SgEntry e;
@@ -78,7 +79,10 @@ __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoor
         for (int c = 0; c < C; ++c) {
             const int cand = chunk * C + c;
             if (cand >= a.n_cands) break;  // uniform
-            if (take[c]) top.insert(lh[c], cand);
+            float p = ps[c], f = ph[c];
+            asm volatile("" : "+v"(p), "+v"(f), "+v"(top.lh[KS - 1]));
+            const float lh = lh_from_sums(p, f);
+            if (!(cnt[c] < a.min_obs)) top.insert(lh, cand);
         }
     }
 }

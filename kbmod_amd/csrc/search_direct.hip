@@ -8,8 +8,9 @@
 namespace kb {
 
 template <int KS, int C, int NB, bool SIGMAG>
-__global__ __launch_bounds__(SEARCH_BLOCK, 2) void kb_search_direct(const SearchArgs a) {
-    const TileCoords tc = tile_coords(a);
+// second launch bound = waves per SIMD: 4 / 3 / 2 four-wave workgroups per CU for K <= 8 / 16 / 32
+__global__ __launch_bounds__(DIRECT_ROWS * WAVE, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_search_direct(const SearchArgs a) {
+    const TileCoords tc = tile_coords<DIRECT_ROWS>(a);
     if (!tc.row_active) return;  // whole wave (no barriers in this kernel)
     const int pix0 = tc.y * a.W + tc.x;
     TopK<KS> top;
@@ -49,16 +50,16 @@ __global__ __launch_bounds__(SEARCH_BLOCK, 2) void kb_search_direct(const Search
 // reference kernel's own structure; it is only used where the register top-K
 // cannot hold the list (few start pixels x many results in practice).
 template <bool SIGMAG>
-__global__ __launch_bounds__(SEARCH_BLOCK) void kb_search_large_k(const SearchArgs a) {
+__global__ __launch_bounds__(DIRECT_ROWS * WAVE) void kb_search_large_k(const SearchArgs a) {
     // A bounded grid walks the tiles (workgroup b takes tiles b, b + gridDim.x, ...), so that the
     // sigma-G scratch is sized by the waves of the launch and not by the search area.
     SigmaGScratch<WAVE> scratch = {};
     if constexpr (SIGMAG) {
-        scratch = make_scratch(a.cold->sg_scratch, a.T, (size_t)blockIdx.x * TILE_ROWS + (threadIdx.x >> 6),
+        scratch = make_scratch(a.cold->sg_scratch, a.T, (size_t)blockIdx.x * DIRECT_ROWS + (threadIdx.x >> 6),
                                threadIdx.x & (WAVE - 1));
     }
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const TileCoords tc = tile_coords(a, tile);
+        const TileCoords tc = tile_coords<DIRECT_ROWS>(a, tile);
         if (!tc.row_active || tc.x_i >= a.sw) continue;
         kb_trajectory* slots = a.cold->results.full + ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
         for (int s = 0; s < a.K; ++s) slots[s] = placeholder_result(tc.x, tc.y);  // kernels.cu:293-301
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(SEARCH_BLOCK) void kb_search_large_k(const SearchAr
 // ---------------------------------------------------------------------------
 template <int KS, int NB>
 static void launch_direct_fmt(const SearchArgs& a, bool sigmag, hipStream_t stream) {
-    const dim3 grid(a.n_tiles), block(SEARCH_BLOCK);
+    const dim3 grid(a.n_tiles), block(DIRECT_ROWS * WAVE);
     if (sigmag) {
         // the emitting instances keep no list: one set (KS = 8) serves every K
         if constexpr (KS == 8) hipLaunchKernelGGL((kb_search_direct<8, CHUNK, NB, true>), grid, block, 0, stream, a);
@@ -131,9 +132,9 @@ void launch_search_direct(const SearchArgs& a, int fmt, bool sigmag, hipStream_t
 
 void launch_search_large_k(const SearchArgs& a, bool sigmag, int blocks, hipStream_t stream) {
     if (sigmag) {
-        hipLaunchKernelGGL((kb_search_large_k<true>), dim3(blocks), dim3(SEARCH_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((kb_search_large_k<true>), dim3(blocks), dim3(DIRECT_ROWS * WAVE), 0, stream, a);
     } else {
-        hipLaunchKernelGGL((kb_search_large_k<false>), dim3(blocks), dim3(SEARCH_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((kb_search_large_k<false>), dim3(blocks), dim3(DIRECT_ROWS * WAVE), 0, stream, a);
     }
 }
 

@@ -69,12 +69,12 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
                                                              EpochBox* __restrict__ boxes,
                                                              int* __restrict__ lds_off,
                                                              int* __restrict__ n_not_lds,
-                                                             int* __restrict__ global_box) {
+                                                             int* __restrict__ global_box, int tile_rows) {
     // One workgroup per chunk, one thread per epoch (strided): the thread owns the
     // C shifts of its epoch, their bounding box and the LDS offsets derived from it.
     const int chunk = blockIdx.x;
     int dx_min = INT32_MAX, dx_max = INT32_MIN, dy_min = INT32_MAX, dy_max = INT32_MIN, any_unsafe = 0, lds_bad = 0;
-    int rows_max = TILE_ROWS;
+    int rows_max = tile_rows;
     int sx_min = INT32_MAX, sx_max = INT32_MIN, sy_min = INT32_MAX, sy_max = INT32_MIN;  // staged epochs only
     int n_per_lane = 0;
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
@@ -118,15 +118,15 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
         // before and after); it is kept because it costs nothing and removes one variable, not because
         // the memory pipe was shown to need it.
         if (ex0 <= ex1) ex0 -= ((ex0 % LDS_ALIGN_PX) + LDS_ALIGN_PX) % LDS_ALIGN_PX;
-        // A slab of (TILE_ROWS + dy spread) x LDS_COLS 8-byte pairs must fit one group buffer.
+        // A slab of (tile rows + dy spread) x LDS_COLS 8-byte pairs must fit one group buffer.
         const bool fits = !epoch_wild && ex0 <= ex1 && (ex1 - ex0) <= (LDS_COLS - WAVE) &&
-                          (TILE_ROWS + ey1 - ey0) * LDS_COLS * 8 <= LDS_SLAB_MAX && ex0 > -30000 && ex1 < 30000 &&
+                          (tile_rows + ey1 - ey0) * LDS_COLS * 8 <= lds_group_bytes(tile_rows) && ex0 > -30000 && ex1 < 30000 &&
                           ey0 > -30000 && ey1 < 30000;
-        EpochBox box = make_int2(0, (TILE_ROWS << 16) | WAVE);
+        EpochBox box = make_int2(0, (tile_rows << 16) | WAVE);
         if (fits) {
             box.x = (ey0 << 16) | (ex0 & 0xffff);
-            box.y = ((TILE_ROWS + ey1 - ey0) << 16) | (WAVE + ex1 - ex0);
-            rows_max = max(rows_max, TILE_ROWS + ey1 - ey0);
+            box.y = ((tile_rows + ey1 - ey0) << 16) | (WAVE + ex1 - ex0);
+            rows_max = max(rows_max, tile_rows + ey1 - ey0);
             sx_min = min(sx_min, ex0);
             sx_max = max(sx_max, ex1);
             sy_min = min(sy_min, ey0);
@@ -426,14 +426,21 @@ static int format_code(int num_bytes, int fast_decode) {
     return 4;
 }
 
+// The tile grid of a launch: rows per tile differ between the kernels.
+static SearchArgs with_tile_rows(SearchArgs a, int rows) {
+    a.tiles_y = (a.sh + rows - 1) / rows;
+    a.n_tiles = a.tiles_x * a.tiles_y;
+    return a;
+}
+
 // which: 0 = kb_search_direct, 1 = kb_search_lds on an encoded padded copy, 2 = kb_search_lds on canonical floats
-static void launch_search(const SearchArgs& a, int fmt, bool sigmag, int which, hipStream_t stream) {
+static void launch_search(const SearchArgs& a, int fmt, bool sigmag, int which, int lds_rows, hipStream_t stream) {
     if (which == 2) {
-        launch_search_lds_canon(a, sigmag, stream);
+        launch_search_lds_canon(with_tile_rows(a, lds_rows), lds_rows, sigmag, stream);
     } else if (which == 1) {
-        (void)launch_search_lds_encoded(a, fmt, sigmag, stream);  // the host chose `which` knowing the instances
+        launch_search_lds_encoded(with_tile_rows(a, lds_rows), lds_rows, fmt, sigmag, stream);
     } else {
-        launch_search_direct(a, fmt, sigmag, stream);
+        launch_search_direct(with_tile_rows(a, DIRECT_ROWS), fmt, sigmag, stream);
     }
 }
 
@@ -542,7 +549,19 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     a.sw = (int)sw;
     a.sh = (int)sh;
     a.tiles_x = (a.sw + WAVE - 1) / WAVE;
-    a.tiles_y = (a.sh + TILE_ROWS - 1) / TILE_ROWS;
+    // Tile height of kb_search_lds: 64 x 16 for lists of up to 8 (and the sigma-G emit) when the search area
+    // gives every CU a tile of that size, 64 x 8 otherwise; flags bits 6 / 7 force one or the other (tests).
+    // Encoded staging is built for 64 x 8 only.
+    int lds_rows = LDS_ROWS_WIDE_K;
+    {
+        const bool list_fits = params.do_sigmag_filter != 0 || params.results_per_pixel <= 8;
+        const int64_t tall_tiles = (int64_t)a.tiles_x * ((sh + LDS_ROWS_TALL - 1) / LDS_ROWS_TALL);
+        const bool keep_encoded = meta->num_bytes != 4 && (flags & 16u) != 0;
+        if (list_fits && !keep_encoded && ((tall_tiles >= 128 && (flags & 128u) == 0) || (flags & 64u) != 0)) {
+            lds_rows = LDS_ROWS_TALL;
+        }
+    }
+    a.tiles_y = (a.sh + lds_rows - 1) / lds_rows;
     a.n_tiles = a.tiles_x * a.tiles_y;
     a.K = (int)params.results_per_pixel;
     a.force_exact = (flags & 1u) ? 1 : 0;
@@ -599,7 +618,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                            times_dev, a.n_cands, a.T, reinterpret_cast<int2*>(wsc),
                            reinterpret_cast<ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes),
                            reinterpret_cast<EpochBox*>(wsc + table_bytes + off_bytes),
-                           reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox);
+                           reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox, lds_rows);
         KB_HIP_TRY(hipGetLastError());
         if (want_lds) {
             // The choice and the apron of the padded copy need six ints back.
@@ -628,12 +647,13 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 // staged format
                 auto rows_touched = [&](uint64_t pair_b) {
                     const uint64_t row_b = (uint64_t)LDS_COLS * pair_b;
-                    const uint64_t rounds = ((uint64_t)back[5] * row_b + STAGE_ROUND - 1) / STAGE_ROUND;
-                    return (int64_t)((rounds * STAGE_ROUND + row_b - 1) / row_b);
+                    const uint64_t round_b = (uint64_t)stage_round(lds_rows);
+                    const uint64_t rounds = ((uint64_t)back[5] * row_b + round_b - 1) / round_b;
+                    return (int64_t)((rounds * round_b + row_b - 1) / row_b);
                 };
                 const int64_t rows_cap = std::max(rows_touched(8), rows_touched(2ull * (uint64_t)meta->block_size));
                 const int64_t y_hi =
-                        (int64_t)params.y_start_min + (int64_t)TILE_ROWS * (a.tiles_y - 1) + back[4] + rows_cap;
+                        (int64_t)params.y_start_min + (int64_t)lds_rows * (a.tiles_y - 1) + back[4] + rows_cap;
                 int64_t px0 = std::max<int64_t>(0, -x_lo), py0 = std::max<int64_t>(0, -y_lo);
                 // slab alignment (kb_shift_table_kernel): x_start_min + px0 is a multiple of LDS_ALIGN_PX,
                 // the row pitch a multiple of 16 pixels
@@ -644,7 +664,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 const uint64_t image = (uint64_t)a.T * (uint64_t)a.H * (uint64_t)a.W;
                 // Canonical floats unless the caller keeps the array encoded or HBM is short.
                 bool canon = meta->num_bytes == 4 || (flags & 16u) == 0;
-                const bool encoded_instance = params.do_sigmag_filter != 0 || a.K <= 8;  // search_lds_encoded.hip
+                const bool encoded_instance = (params.do_sigmag_filter != 0 || a.K <= 8) && lds_rows == LDS_ROWS_WIDE_K;  // search_lds_encoded.hip
                 size_t free_b = 0, total_b = 0;
                 KB_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
                 const uint64_t have = g_ws[2].ptr != nullptr ? g_ws[2].bytes : 0;
@@ -697,7 +717,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         // literal-clip scratch: one slot per wave of the resolve launch (8 workgroups per CU), or per wave of
         // the bounded kb_search_large_k grid
-        resolve_waves = std::max(cus, 1) * 8 * TILE_ROWS;
+        resolve_waves = std::max(cus, 1) * 32;
         void* sg = nullptr;
         if (ensure_workspace(1, (size_t)resolve_waves * scratch_words_per_wave(a.T) * sizeof(float), &sg)) return 1;
         cold.sg_scratch = reinterpret_cast<float*>(sg);
@@ -742,10 +762,11 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     if (a.K > 32) {
         if (sink.compact != nullptr) return fail("compact results support results_per_pixel <= 32");
         if (sigmag) {
-            const int blocks = std::max(1, std::min(a.n_tiles, resolve_waves / TILE_ROWS));
-            launch_search_large_k(a, true, blocks, stream);
+            const SearchArgs ad = with_tile_rows(a, DIRECT_ROWS);
+            launch_search_large_k(ad, true, std::max(1, std::min(ad.n_tiles, resolve_waves / DIRECT_ROWS)), stream);
         } else {
-            launch_search_large_k(a, false, a.n_tiles, stream);
+            const SearchArgs ad = with_tile_rows(a, DIRECT_ROWS);
+            launch_search_large_k(ad, false, ad.n_tiles, stream);
         }
         variant = 99;
     } else if (sigmag) {
@@ -763,7 +784,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
             a.chunk_hi = std::min(a.n_chunks, a.chunk_lo + batch_chunks);
             KB_HIP_TRY(hipMemsetAsync(cold.sg.slots, 0, (size_t)n_rows * cold.sg.batch_cands * sizeof(uint32_t), stream));
             KB_HIP_TRY(hipMemsetAsync(cold.sg.n_entries, 0, sizeof(int), stream));
-            if (a.chunk_lo < a.chunk_hi) launch_search(a, fmt, true, which, stream);  // the emitting instances keep no list
+            if (a.chunk_lo < a.chunk_hi) launch_search(a, fmt, true, which, lds_rows, stream);  // the emitting instances keep no list
             KB_HIP_TRY(hipGetLastError());
             const ResultSink* next = &bufs[(n_batches - 1 - b) % 2];
             if (launch_sigmag_resolve(a, cold, prev, *next, resolve_waves, stream)) return 1;
@@ -771,7 +792,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         }
         variant = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
     } else {
-        launch_search(a, fmt, false, which, stream);
+        launch_search(a, fmt, false, which, lds_rows, stream);
         variant = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
     }
     KB_HIP_TRY(hipGetLastError());

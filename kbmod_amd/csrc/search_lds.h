@@ -29,11 +29,12 @@ struct SlabRegs {
 };
 
 // Offsets of a thread for slabs of slab_bytes: 0 (re-read the slab's first bytes) past the slab's end.
+template <int ROWS>
 __device__ __forceinline__ StageLane clip_lane(const StageLane& sl, int slab_bytes) {
     StageLane out;
 #pragma unroll
     for (int j = 0; j < LDS_SLOTS; ++j) {
-        out.goff[j] = (16 * ((int)threadIdx.x + SEARCH_BLOCK * j) < slab_bytes) ? sl.goff[j] : 0u;
+        out.goff[j] = (16 * ((int)threadIdx.x + (ROWS * WAVE) * j) < slab_bytes) ? sl.goff[j] : 0u;
     }
     return out;
 }
@@ -42,7 +43,7 @@ __device__ __forceinline__ StageLane clip_lane(const StageLane& sl, int slab_byt
 // loads are issued whatever the slab size (no branch, no exec mask -- the compiler would serialise
 // masked loads with vmcnt(0)): threads past the end of the slab re-read its first bytes and do not
 // write them to LDS.
-template <int BYTES>
+template <int BYTES, int ROWS>
 __device__ __forceinline__ void load_slab(const SearchArgs& a, const StageLane& sl, const char* base, int slab_bytes,
                                           SlabRegs& regs, int j0 = 0) {
     const int tid = threadIdx.x;
@@ -50,99 +51,95 @@ __device__ __forceinline__ void load_slab(const SearchArgs& a, const StageLane& 
     for (int j = 0; j < LDS_SLOTS; ++j) {
         uint32_t goff = sl.goff[j];
         if (j0 != 0) {  // uniform, rare: rounds after the first compute their map on the fly
-            const int p = 16 * (tid + SEARCH_BLOCK * (j0 + j)) / BYTES;
+            const int p = 16 * (tid + (ROWS * WAVE) * (j0 + j)) / BYTES;
             const int r = p / LDS_COLS, c = p - r * LDS_COLS;
             goff = (uint32_t)(r * a.Wp + c) * (uint32_t)BYTES;
         }
         // (round 0: sl already holds 0 for threads past the end of this chunk's slabs, see clip_lane)
-        const uint32_t off = (j0 == 0 || 16 * (tid + SEARCH_BLOCK * (j0 + j)) < slab_bytes) ? goff : 0u;
+        uint32_t off = (j0 == 0 || 16 * (tid + (ROWS * WAVE) * (j0 + j)) < slab_bytes) ? goff : 0u;
+        // the offset stays a 32-bit register across the loop (uniform base + 32-bit lane offset is an addressing mode;
+        // hoisted as a 64-bit value it costs an add per load and a register more)
+        asm volatile("" : "+v"(off));
         // only BYTES-aligned: the hardware takes unaligned 16-byte global loads
         const PieceMem<(BYTES < 4 ? BYTES : 4)>* src = reinterpret_cast<const PieceMem<(BYTES < 4 ? BYTES : 4)>*>(base + off);
         regs.v[j] = Piece{src->w[0], src->w[1], src->w[2], src->w[3]};
     }
 }
 
+template <int ROWS>
 __device__ __forceinline__ void write_slab(char* dst, int slab_bytes, const SlabRegs& regs, int j0 = 0) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < LDS_SLOTS; ++j) {
-        if (STAGE_ROUND * (j0 + j) < slab_bytes) {  // uniform
-            const int o = 16 * (tid + SEARCH_BLOCK * (j0 + j));
+        if (stage_round(ROWS) * (j0 + j) < slab_bytes) {  // uniform
+            const int o = 16 * (tid + (ROWS * WAVE) * (j0 + j));
             if (o < slab_bytes) *reinterpret_cast<Piece*>(dst + o) = regs.v[j];
         }
     }
 }
 
 // Rounds after the first of a slab larger than LDS_SLOTS x 4 KiB (load, then write, no overlap).
-template <int BYTES>
+template <int BYTES, int ROWS>
 __device__ __forceinline__ void copy_slab_tail(const SearchArgs& a, const StageLane& sl, const char* base, int slab_bytes,
                                                char* dst, SlabRegs& regs) {
-    for (int j0 = LDS_SLOTS; STAGE_ROUND * j0 < slab_bytes; j0 += LDS_SLOTS) {
-        load_slab<BYTES>(a, sl, base, slab_bytes, regs, j0);
-        write_slab(dst, slab_bytes, regs, j0);
+    for (int j0 = LDS_SLOTS; stage_round(ROWS) * j0 < slab_bytes; j0 += LDS_SLOTS) {
+        load_slab<BYTES, ROWS>(a, sl, base, slab_bytes, regs, j0);
+        write_slab<ROWS>(dst, slab_bytes, regs, j0);
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
 }
 
 typedef float PairF __attribute__((ext_vector_type(2)));
 
-// One epoch that is not staged (a footprint larger than a slab, a velocity beyond the table's proven
-// range): every lane predicts its own pixel exactly and reads the array itself, like
-// kb_search_direct's exact mode.  Rare; decodes through the meta data (any array format), so that the
-// canonical-float instances of the kernel do not depend on the array's encoding.
-template <int C>
-__device__ __forceinline__ void unstaged_epoch(const SearchArgs& a, int x, int y, int chunk, int t, PairF (&acc)[C],
-                                               int (&cnt)[C]) {
-    const SearchCold* cold = a.cold;
-    const double tm = cold->times[t];
-    const kb_trajectory* cands = cold->cands;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const int ci = min(chunk * C + c, a.n_cands - 1);
-        int cx, cy;
-        bool in = predict_index(x, cands[ci].vx, tm, &cx);
-        in = predict_index(y, cands[ci].vy, tm, &cy) && in;
-        float psi = NAN, phi = NAN;
-        if (in) read_psi_phi(cold->meta, a.psi_phi, (uint64_t)t, cy, cx, &psi, &phi);  // NaN outside the image
-        float s0 = acc[c].x, s1 = acc[c].y;
-        accumulate(psi, phi, true, s0, s1, cnt[c]);
-        acc[c] = PairF{s0, s1};
-    }
-}
-
-// One staged epoch in which some candidate's shift is known only to +-1 pixel (v*t + 0.5 on a
-// rounding boundary): every lane predicts its own pixel with the reference's arithmetic and reads
-// it from the slab, which was sized with that slack.  No global memory traffic.
+// One epoch whose samples cannot be read at lane base + scalar offset: either staged with slack because
+// some candidate's shift sits on a rounding boundary (every lane predicts its own pixel with the
+// reference's arithmetic and reads it from the slab), or not staged at all (a footprint larger than a
+// slab, a velocity beyond the table's proven range: the lane reads the array itself, like
+// kb_search_direct's exact mode).  Rare, and deliberately compact: the candidates are walked by a real
+// loop and routed to their accumulators by a select chain, so that the
+// kernel's register budget is set by its main loop and not by this path.
 template <int C, int SF, bool CANON>
-__device__ __forceinline__ void per_lane_epoch(const SearchArgs& a, const TileCoords& tc, int chunk, int t, int box_word,
-                                               int slab_bytes, const char* slab, PairF (&acc)[C], int (&cnt)[C]) {
+__device__ __forceinline__ void special_epoch(const SearchArgs& a, const TileCoords& tc, int chunk, int t, bool in_slab,
+                                              const char* slab, PairF (&acc)[C], int (&cnt)[C]) {
     using R = RawPair<SF>;
     constexpr int BYTES = 2 * fmt_bytes(SF);
     typedef const __attribute__((address_space(4))) double* ConstDoublePtr;
-    const double tm = ((ConstDoublePtr)(uintptr_t)a.cold->times)[t];
+    const SearchCold* cold = a.cold;
+    const double tm = ((ConstDoublePtr)(uintptr_t)cold->times)[t];
+    const int box_word = as_const_ints(cold->boxes + (size_t)chunk * a.T + t)[0];
     const EpochBox box = make_int2(box_word, 0);
     const int ox = tc.tile_x0 + box_dx(box), oy = tc.tile_y0 + box_dy(box);  // image coordinates of slab pixel (0, 0)
-    const int rows = slab_bytes / (LDS_COLS * BYTES);
-#pragma unroll
+    const int rows = as_const_ints(&a.chunks[chunk])[6];                     // rows_max: the slab's height
+    const kb_trajectory* cands = cold->cands;
+#pragma nounroll
     for (int c = 0; c < C; ++c) {
         const int ci = min(chunk * C + c, a.n_cands - 1);
-        const ConstIntPtr cw = as_const_ints(a.cold->cands + ci);  // {vx, vy, ...}
+        const ConstIntPtr cw = as_const_ints(cands + ci);  // {vx, vy, ...}
         int cx, cy;
         bool in = predict_index(tc.x, __int_as_float(cw[0]), tm, &cx);
         in = predict_index(tc.y, __int_as_float(cw[1]), tm, &cy) && in;
-        const int rx = cx - ox, ry = cy - oy;
-        const bool ok = in && ((unsigned)rx < (unsigned)LDS_COLS) && ((unsigned)ry < (unsigned)rows);
-        const int off = ok ? (ry * LDS_COLS + rx) * BYTES : 0;
-        const typename R::type raw = *reinterpret_cast<const typename R::type*>(slab + off);
-        float psi, phi;
-        R::decode(raw, a, &psi, &phi);
-        if (CANON) {
-            acc[c] += ok ? PairF{psi, phi} : PairF{0.0f, 0.0f};
-            cnt[c] += (ok && __float_as_uint(phi) != 0x80000000u) ? 1 : 0;
-        } else {
-            float s0 = acc[c].x, s1 = acc[c].y;
-            accumulate(psi, phi, ok, s0, s1, cnt[c]);
-            acc[c] = PairF{s0, s1};
+        float psi = NAN, phi = NAN;
+        if (in_slab) {  // uniform
+            const int rx = cx - ox, ry = cy - oy;
+            const bool ok = in && ((unsigned)rx < (unsigned)LDS_COLS) && ((unsigned)ry < (unsigned)rows);
+            const int off = ok ? (ry * LDS_COLS + rx) * BYTES : 0;
+            const typename R::type raw = *reinterpret_cast<const typename R::type*>(slab + off);
+            float p0, p1;
+            R::decode(raw, a, &p0, &p1);
+            if (CANON && __float_as_uint(p1) == 0x80000000u) p1 = NAN;  // the NO_DATA marker of the canonical copy
+            psi = ok ? p0 : NAN;
+            phi = ok ? p1 : NAN;
+        } else if (in) {
+            read_psi_phi(cold->meta, a.psi_phi, (uint64_t)t, cy, cx, &psi, &phi);  // NaN outside the image
+        }
+        const bool valid = __builtin_isfinite(psi) && __builtin_isfinite(phi);
+        const PairF add = valid ? PairF{psi, phi} : PairF{0.0f, 0.0f};
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+            if (cc == c) {  // uniform
+                acc[cc] += add;
+                cnt[cc] += valid ? 1 : 0;
+            }
         }
     }
 }
@@ -153,12 +150,12 @@ struct ChunkPlan {
     int E;           // epochs per group
     int clean;       // every epoch is staged with uniform shifts: the summing loop needs no per-epoch test
 };
-template <int BYTES>
+template <int BYTES, int ROWS>
 __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) {
     ChunkPlan p;
     const ConstIntPtr ci = as_const_ints(&a.chunks[chunk]);  // {dx_min, dx_max, dy_min, dy_max, unsafe, lds_ok, rows_max}
     p.slab_bytes = ci[6] * LDS_COLS * BYTES;
-    p.E = max(1, min(a.T, LDS_GROUP_BYTES / p.slab_bytes));
+    p.E = max(1, min(a.T, lds_group_bytes(ROWS) / p.slab_bytes));
     p.clean = (ci[4] == 0 && ci[5] != 0) ? 1 : 0;
     return p;
 }
@@ -169,7 +166,7 @@ __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) 
 // the epoch's sums and written to LDS after them.
 // FAST: no sample of this tile can be NO_DATA (the tile stays inside the image under
 // every shift, the array has no NO_DATA pixel, every epoch is staged): obs_count is T.
-template <int KS, int C, int NB, bool CANON, bool SIGMAG, bool FAST>
+template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, bool FAST>
 __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileCoords& tc, char* smem,
                                                 const StageLane& sl, TopK<KS>& top) {
     constexpr int SF = CANON ? 4 : NB;  // staged format
@@ -187,23 +184,23 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     }
 
     int chunk = a.chunk_lo, t0 = 0, buf = 0;
-    ChunkPlan plan = chunk_plan<BYTES>(a, chunk);
+    ChunkPlan plan = chunk_plan<BYTES, ROWS>(a, chunk);
     SlabRegs regs;
     typedef int Int4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) Int4* ConstSlabPtr;  // a SlabRef as four dwords
     auto origin_of = [](Int4 r) { return (int64_t)(((uint64_t)(uint32_t)r.y << 32) | (uint64_t)(uint32_t)r.x); };
     // this tile's own pixel inside the padded copy
     const char* tile_base = reinterpret_cast<const char*>(a.padded) + ((int64_t)tc.tile_y0 * a.Wp + tc.tile_x0) * BYTES;
-    StageLane n_sl = clip_lane(sl, plan.slab_bytes);  // staging map of the group being copied
+    StageLane n_sl = clip_lane<ROWS>(sl, plan.slab_bytes);  // staging map of the group being copied
     {
         const ConstSlabPtr org = (ConstSlabPtr)(uintptr_t)(a.slabs + (size_t)chunk * T);
         const int n = min(plan.E, T);
         for (int e = 0; e < n; ++e) {
             const int64_t o = origin_of(org[e]);
-            load_slab<BYTES>(a, n_sl, tile_base + o, plan.slab_bytes, regs);
-            write_slab(smem + e * plan.slab_bytes, plan.slab_bytes, regs);
+            load_slab<BYTES, ROWS>(a, n_sl, tile_base + o, plan.slab_bytes, regs);
+            write_slab<ROWS>(smem + e * plan.slab_bytes, plan.slab_bytes, regs);
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            copy_slab_tail<BYTES>(a, sl, tile_base + o, plan.slab_bytes, smem + e * plan.slab_bytes, regs);
+            copy_slab_tail<BYTES, ROWS>(a, sl, tile_base + o, plan.slab_bytes, smem + e * plan.slab_bytes, regs);
         }
     }
     __syncthreads();
@@ -216,56 +213,62 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             n_chunk = chunk + 1;
             n_t0 = 0;
             if (n_chunk < a.chunk_hi) {
-                n_plan = chunk_plan<BYTES>(a, n_chunk);
-                n_sl = clip_lane(sl, n_plan.slab_bytes);
+                n_plan = chunk_plan<BYTES, ROWS>(a, n_chunk);
+                n_sl = clip_lane<ROWS>(sl, n_plan.slab_bytes);
             }
         }
         const int n_next = (n_chunk < a.chunk_hi) ? min(n_plan.E, T - n_t0) : 0;
         const ConstSlabPtr n_org = (ConstSlabPtr)(uintptr_t)(a.slabs + (size_t)min(n_chunk, a.chunk_hi - 1) * T + n_t0);
-        char* nb = smem + (1 - buf) * LDS_GROUP_BYTES;
+        char* nb = smem + (1 - buf) * lds_group_bytes(ROWS);
         // slab e of the next group: loads issued before, LDS writes after the sums of epoch e
         const char* n_base = tile_base;
         auto next_load = [&](int e) -> bool {
             if (e >= n_next) return false;
             n_base = tile_base + origin_of(n_org[e]);
-            load_slab<BYTES>(a, n_sl, n_base, n_plan.slab_bytes, regs);
+            load_slab<BYTES, ROWS>(a, n_sl, n_base, n_plan.slab_bytes, regs);
             return true;
         };
         auto next_write = [&](int e) {
-            write_slab(nb + e * n_plan.slab_bytes, n_plan.slab_bytes, regs);
-            if (n_plan.slab_bytes > LDS_SLOTS * STAGE_ROUND) {  // uniform, rare
+            write_slab<ROWS>(nb + e * n_plan.slab_bytes, n_plan.slab_bytes, regs);
+            if (n_plan.slab_bytes > LDS_SLOTS * stage_round(ROWS)) {  // uniform, rare
                 __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-                copy_slab_tail<BYTES>(a, sl, n_base, n_plan.slab_bytes, nb + e * n_plan.slab_bytes, regs);
+                copy_slab_tail<BYTES, ROWS>(a, sl, n_base, n_plan.slab_bytes, nb + e * n_plan.slab_bytes, regs);
             }
         };
 
         const ConstIntPtr offs = as_const_ints(a.lds_off + ((size_t)chunk * T + t0) * C);  // offsets for 8-byte pairs
-        const char* cb = smem + buf * LDS_GROUP_BYTES + lane_b;
+        const char* cb = smem + buf * lds_group_bytes(ROWS) + lane_b;
         const int n_cur = min(plan.E, T - t0);
         // C samples of one staged epoch with uniform shifts: slab offsets o[] (scalars) -> LDS reads -> sums
         auto sum_epoch = [&](const int (&o)[C], int e) {
-            typename R::type raw[C];
+            // eight reads in flight at a time (a chunk of 16 goes in two halves: the registers of the samples
+            // are the ones this kernel is short of)
+            constexpr int HALF = 8;
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int off = (BYTES == 8) ? o[c] : (o[c] >> 3) * BYTES;
-                raw[c] = *reinterpret_cast<const typename R::type*>(cb + e * plan.slab_bytes + off);
-            }
-            // one wait for the C reads instead of the compiler's one per read (instruction issue is the bound)
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            for (int c0 = 0; c0 < C; c0 += HALF) {
+                typename R::type raw[HALF];
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                if constexpr (CANON) {
-                    acc[c] += PairF{raw[c].x, raw[c].y};
-                    if (!FAST) cnt[c] += (__float_as_uint(raw[c].y) != 0x80000000u) ? 1 : 0;
-                } else {
-                    float psi, phi;
-                    R::decode(raw[c], a, &psi, &phi);
-                    if (FAST) {
-                        acc[c] += PairF{psi, phi};
+                for (int c = 0; c < HALF; ++c) {
+                    const int off = (BYTES == 8) ? o[c0 + c] : (o[c0 + c] >> 3) * BYTES;
+                    raw[c] = *reinterpret_cast<const typename R::type*>(cb + e * plan.slab_bytes + off);
+                }
+                // one wait for the reads instead of the compiler's one per read (instruction issue is the bound)
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+#pragma unroll
+                for (int c = 0; c < HALF; ++c) {
+                    if constexpr (CANON) {
+                        acc[c0 + c] += PairF{raw[c].x, raw[c].y};
+                        if (!FAST) cnt[c0 + c] += (__float_as_uint(raw[c].y) != 0x80000000u) ? 1 : 0;
                     } else {
-                        float s0 = acc[c].x, s1 = acc[c].y;
-                        accumulate(psi, phi, true, s0, s1, cnt[c]);
-                        acc[c] = PairF{s0, s1};
+                        float psi, phi;
+                        R::decode(raw[c], a, &psi, &phi);
+                        if (FAST) {
+                            acc[c0 + c] += PairF{psi, phi};
+                        } else {
+                            float s0 = acc[c0 + c].x, s1 = acc[c0 + c].y;
+                            accumulate(psi, phi, true, s0, s1, cnt[c0 + c]);
+                            acc[c0 + c] = PairF{s0, s1};
+                        }
                     }
                 }
             }
@@ -273,13 +276,8 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
         // Keeps the epoch's sums in front of the LDS writes of the staged slab: left alone the compiler
         // sinks the adds behind the writes, whose vmcnt(0) then waits out the loads with nothing to overlap.
         auto pin_sums = [&]() {
-            static_assert(C == 8, "operand list below");
-            asm volatile(""
-                         : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
-                           "+v"(acc[7]), "+v"(cnt[0]), "+v"(cnt[1]), "+v"(cnt[2]), "+v"(cnt[3]), "+v"(cnt[4]), "+v"(cnt[5]),
-                           "+v"(cnt[6]), "+v"(cnt[7])
-                         :
-                         : "memory");
+#pragma unroll
+            for (int c = 0; c < C; ++c) asm volatile("" : "+v"(acc[c]), "+v"(cnt[c])::"memory");
         };
         if (plan.clean) {
             // A block alone on its CU is bound by the chain scalar table fetch -> LDS read -> adds -> slab
@@ -296,7 +294,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 const bool staging = e < n_next;
                 if (staging) {
                     n_base = tile_base + org_cur;
-                    load_slab<BYTES>(a, n_sl, n_base, n_plan.slab_bytes, regs);
+                    load_slab<BYTES, ROWS>(a, n_sl, n_base, n_plan.slab_bytes, regs);
                 }
                 sum_epoch(o_cur, e);
                 pin_sums();
@@ -317,12 +315,9 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 for (int c = 0; c < C; ++c) o[c] = offs[e * C + c];
                 if (o[0] >= 0) {
                     sum_epoch(o, e);
-                } else if (o[0] == LDS_OFF_UNSTAGED) {
-                    unstaged_epoch<C>(a, tc.x, tc.y, chunk, t0 + e, acc, cnt);
                 } else {
-                    const int bw = as_const_ints(a.cold->boxes + (size_t)chunk * T + t0 + e)[0];
-                    per_lane_epoch<C, SF, CANON>(a, tc, chunk, t0 + e, bw, plan.slab_bytes,
-                                                 smem + buf * LDS_GROUP_BYTES + e * plan.slab_bytes, acc, cnt);
+                    special_epoch<C, SF, CANON>(a, tc, chunk, t0 + e, o[0] == LDS_OFF_PER_LANE,
+                                                smem + buf * lds_group_bytes(ROWS) + e * plan.slab_bytes, acc, cnt);
                 }
                 pin_sums();
                 if (staging) next_write(e);
@@ -360,19 +355,20 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 }
 
 
-template <int KS, int C, int NB, bool CANON, bool SIGMAG>
-// second launch bound = waves per SIMD: two eight-wave workgroups per CU for K <= 8, one beyond
-__global__ __launch_bounds__(SEARCH_BLOCK, (KS <= 8 ? 4 : 2)) void kb_search_lds(const SearchArgs a) {
+template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG>
+// second launch bound = waves per SIMD: 16 waves per CU (one 64 x 16 or two 64 x 8 workgroups) for K <= 8,
+// one 64 x 8 workgroup with twice the registers beyond
+__global__ __launch_bounds__(ROWS * WAVE, (KS <= 8 ? 4 : 2)) void kb_search_lds(const SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // two group buffers
     constexpr int BYTES = 2 * fmt_bytes(CANON ? 4 : NB);
-    const TileCoords tc = tile_coords(a);  // rows past the search area stay alive (barriers)
+    const TileCoords tc = tile_coords<ROWS>(a);  // rows past the search area stay alive (barriers)
     TopK<KS> top;
     top.init();
 
     StageLane sl;
 #pragma unroll
     for (int j = 0; j < LDS_SLOTS; ++j) {
-        const int p = 16 * ((int)threadIdx.x + SEARCH_BLOCK * j) / BYTES;  // first pixel of this thread's 16 bytes
+        const int p = 16 * ((int)threadIdx.x + (ROWS * WAVE) * j) / BYTES;  // first pixel of this thread's 16 bytes
         const int r = p / LDS_COLS, c = p - r * LDS_COLS;
         sl.goff[j] = (uint32_t)(r * a.Wp + c) * (uint32_t)BYTES;
     }
@@ -381,23 +377,23 @@ __global__ __launch_bounds__(SEARCH_BLOCK, (KS <= 8 ? 4 : 2)) void kb_search_lds
     const ConstIntPtr gb = as_const_ints(a.global_box);
     const bool fast = a.all_staged && as_const_ints(a.n_invalid)[0] == 0 && (tc.tile_x0 + gb[0] >= 0) &&
                       (tc.tile_x0 + WAVE + gb[1] <= a.W) && (tc.tile_y0 + gb[2] >= 0) &&
-                      (tc.tile_y0 + TILE_ROWS + gb[3] <= a.H);
+                      (tc.tile_y0 + ROWS + gb[3] <= a.H);
     if (fast) {
-        lds_search_tile<KS, C, NB, CANON, SIGMAG, true>(a, tc, smem, sl, top);
+        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, true>(a, tc, smem, sl, top);
     } else {
-        lds_search_tile<KS, C, NB, CANON, SIGMAG, false>(a, tc, smem, sl, top);
+        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, false>(a, tc, smem, sl, top);
     }
     if constexpr (!SIGMAG) write_results<KS>(a, tc, top);
 }
 
 // Launch of one instance (two group buffers beyond the default 64 KiB of dynamic LDS need the attribute raised).
-template <int KS, int NB, bool CANON, bool SIGMAG>
+template <int KS, int ROWS, int NB, bool CANON, bool SIGMAG>
 static void launch_lds(const SearchArgs& a, hipStream_t stream) {
-    constexpr size_t lds_bytes = 2 * LDS_GROUP_BYTES;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb_search_lds<KS, CHUNK, NB, CANON, SIGMAG>),
+    constexpr size_t lds_bytes = 2 * lds_group_bytes(ROWS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb_search_lds<KS, CHUNK, ROWS, NB, CANON, SIGMAG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, NB, CANON, SIGMAG>), dim3(a.n_tiles), dim3(SEARCH_BLOCK), lds_bytes, stream,
-                       a);
+    hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, ROWS, NB, CANON, SIGMAG>), dim3(a.n_tiles), dim3(ROWS * WAVE), lds_bytes,
+                       stream, a);
 }
 
 }  // namespace kb

@@ -5,15 +5,24 @@
 
 namespace kb {
 
-void launch_search_lds_canon(const SearchArgs& a, bool sigmag, hipStream_t stream) {
-    if (sigmag) {
-        launch_lds<8, 4, true, true>(a, stream);  // the emitting instance keeps no list: KS is irrelevant
+void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, hipStream_t stream) {
+    const bool tall = rows == LDS_ROWS_TALL;
+    if (sigmag) {  // the emitting instances keep no list: KS is irrelevant
+        if (tall) {
+            launch_lds<8, LDS_ROWS_TALL, 4, true, true>(a, stream);
+        } else {
+            launch_lds<8, LDS_ROWS_WIDE_K, 4, true, true>(a, stream);
+        }
     } else if (a.K <= 8) {
-        launch_lds<8, 4, true, false>(a, stream);
+        if (tall) {
+            launch_lds<8, LDS_ROWS_TALL, 4, true, false>(a, stream);
+        } else {
+            launch_lds<8, LDS_ROWS_WIDE_K, 4, true, false>(a, stream);
+        }
     } else if (a.K <= 16) {
-        launch_lds<16, 4, true, false>(a, stream);
+        launch_lds<16, LDS_ROWS_WIDE_K, 4, true, false>(a, stream);
     } else {
-        launch_lds<32, 4, true, false>(a, stream);
+        launch_lds<32, LDS_ROWS_WIDE_K, 4, true, false>(a, stream);
     }
 }
 

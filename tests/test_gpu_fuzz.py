@@ -9,7 +9,7 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
-DIRECT, LDS, ENCODED_STAGING = 2, 4, 16
+DIRECT, LDS, ENCODED_STAGING, TALL_TILES, WIDE_TILES = 2, 4, 16, 64, 128
 
 
 def _config(seed):
@@ -48,9 +48,11 @@ def _config(seed):
 def test_random_configuration(kb, orc, seed):
     stack, vx, vy, cfg, num_bytes = _config(seed)
     a, exp, s1 = util.run_both(kb, orc, stack, vx, vy, cfg, num_bytes=num_bytes, flags=DIRECT)
-    b, _, s2 = util.run_both(kb, orc, stack, vx, vy, cfg, num_bytes=num_bytes, flags=LDS)
+    b, _, s2 = util.run_both(kb, orc, stack, vx, vy, cfg, num_bytes=num_bytes, flags=LDS | WIDE_TILES)
     assert a.shape == exp.shape and np.array_equal(a, exp), f"direct kernel differs from the oracle (seed {seed})"
     assert np.array_equal(b, exp), f"kernel variant {s2.last_search_stats()['kernel_variant']} differs (seed {seed})"
+    t, _, _ = util.run_both(kb, orc, stack, vx, vy, cfg, num_bytes=num_bytes, flags=LDS | TALL_TILES)
+    assert np.array_equal(t, exp), f"64 x 16 tiles differ (seed {seed})"
     if num_bytes != -1:
         c, _, _ = util.run_both(kb, orc, stack, vx, vy, cfg, num_bytes=num_bytes, flags=LDS | ENCODED_STAGING)
         assert np.array_equal(c, exp)

@@ -39,11 +39,13 @@ def lds_cands():
 
 
 # kb_device_search_filter flags (include/kbmod_hip.h)
-EXACT, DIRECT, LDS, DOUBLE_DECODE, ENCODED_STAGING = 1, 2, 4, 8, 16
-KERNELS = {"direct": DIRECT, "lds": LDS, "lds_encoded": LDS | ENCODED_STAGING}
+EXACT, DIRECT, LDS, DOUBLE_DECODE, ENCODED_STAGING, TALL_TILES, WIDE_TILES = 1, 2, 4, 8, 16, 64, 128
+# "lds": 64 x 8 start-pixel tiles (what the small search areas of these tests get by default), "lds_tall": 64 x 16
+KERNELS = {"direct": DIRECT, "lds": LDS | WIDE_TILES, "lds_tall": LDS | TALL_TILES,
+           "lds_encoded": LDS | ENCODED_STAGING}
 
 
-@pytest.fixture(params=["direct", "lds"])
+@pytest.fixture(params=["direct", "lds", "lds_tall"])
 def kern(request):
     return request.param
 
@@ -53,7 +55,7 @@ def _variant(search):
 
 
 def _check_kernel(search, kern, num_bytes=-1):
-    want = {"direct": 0, "lds": 2, "lds_encoded": 2 if num_bytes in (-1, 4) else 1}[kern]
+    want = {"direct": 0, "lds": 2, "lds_tall": 2, "lds_encoded": 2 if num_bytes in (-1, 4) else 1}[kern]
     assert _variant(search) == want, search.last_search_stats()
 
 
