@@ -52,6 +52,35 @@ def check(lib, rc):
         raise RuntimeError(lib.kb_last_error().decode())
 
 
+def synthetic_stack(torch, dev, T, H, W, mask_fraction=0.0):
+    """The benchmark's synthetic image stack, generated on the device: the distributions of
+    fake_data.make_fake_image_stack (sci ~ N(0, 2^2), var = 4, Gaussian PSF sigma = 1, epochs i / T days) with ten
+    injected movers.  Seeded: identical on every rank (psi/phi is replicated) and in the tests that re-create it."""
+    from kbmod_amd import fake_data as fd
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    sci = torch.randn((T, H, W), generator=gen, device=dev, dtype=torch.float32) * 2.0
+    var = torch.full((T, H, W), 4.0, device=dev, dtype=torch.float32)
+    times = torch.arange(T, dtype=torch.float64, device=dev) / T
+    psf = fd.make_gaussian_kernel(1.0)
+    # ~10 injected movers (x, y, vx, vy, flux)
+    obj_rng = np.random.default_rng(99)
+    tcpu = times.cpu().numpy()
+    for _ in range(10):
+        x0, y0 = obj_rng.integers(20, W - 60), obj_rng.integers(20, H - 60)
+        v, ang = obj_rng.uniform(8, 35), obj_rng.uniform(0.1, 1.3)
+        for t in range(T):
+            px = int(x0 + v * np.cos(ang) * tcpu[t] + 0.5)
+            py = int(y0 + v * np.sin(ang) * tcpu[t] + 0.5)
+            r = psf.shape[0] // 2
+            if r <= px < W - r and r <= py < H - r:
+                sci[t, py - r:py + r + 1, px - r:px + r + 1] += torch.from_numpy(300.0 * psf).to(dev)
+    if mask_fraction > 0.0:
+        sci[torch.rand((T, H, W), generator=gen, device=dev) < mask_fraction] = float("nan")
+    return sci, var, times, psf
+
+
 def self_launch(args_list, n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the
     same command the driver would issue) and pass their output through."""
@@ -125,29 +154,8 @@ def main():
     T, H, W = args.frames, args.size, args.size
     K = 8
 
-    # ---- synthetic stack, generated on the device (same distributions as
-    # fake_data.make_fake_image_stack: sci ~ N(0, 2^2), var = 4, Gaussian PSF sigma = 1) ----
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234)  # identical stack on every rank (psi/phi replicated)
-    sci = torch.randn((T, H, W), generator=gen, device=dev, dtype=torch.float32) * 2.0
-    var = torch.full((T, H, W), 4.0, device=dev, dtype=torch.float32)
-    times = torch.arange(T, dtype=torch.float64, device=dev) / T
-    psf = fd.make_gaussian_kernel(1.0)
-    # ~10 injected movers (x, y, vx, vy, flux)
-    obj_rng = np.random.default_rng(99)
+    sci, var, times, psf = synthetic_stack(torch, dev, T, H, W, args.mask_fraction)
     tcpu = times.cpu().numpy()
-    for _ in range(10):
-        x0, y0 = obj_rng.integers(20, W - 60), obj_rng.integers(20, H - 60)
-        v, ang = obj_rng.uniform(8, 35), obj_rng.uniform(0.1, 1.3)
-        for t in range(T):
-            px = int(x0 + v * np.cos(ang) * tcpu[t] + 0.5)
-            py = int(y0 + v * np.sin(ang) * tcpu[t] + 0.5)
-            r = psf.shape[0] // 2
-            if r <= px < W - r and r <= py < H - r:
-                sci[t, py - r:py + r + 1, px - r:px + r + 1] += torch.from_numpy(300.0 * psf).to(dev)
-
-    if args.mask_fraction > 0.0:
-        sci[torch.rand((T, H, W), generator=gen, device=dev) < args.mask_fraction] = float("nan")
 
     psf_all = np.ascontiguousarray(np.tile(psf.ravel(), T), dtype=np.float32)
     psf_dims = np.full(T, psf.shape[0], dtype=np.int32)

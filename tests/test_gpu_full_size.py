@@ -43,3 +43,122 @@ def test_full_size_properties(name):
     assert proc.returncode == 0
     assert out["roofline"]["kernel"] == "kb_search_lds" and v["other_kernel"] == "kb_search_direct"
     assert out["value"] > 1e9  # north star floor, evals/s
+
+
+def _oracle_view(orc, lib, meta, arr, times):
+    """The device array copied to the host, wrapped for the oracle (the array itself was produced by the HIP
+    builder, whose bytes test_gpu_builder_and_api pins against the oracle's)."""
+    import numpy as np
+
+    host = np.empty(int(meta.num_entries), dtype={4: np.float32, 2: np.uint16, 1: np.uint8}[meta.num_bytes])
+    rc = lib.kb_copy_block_to_cpu(host.ctypes.data, arr, meta.total_array_size)
+    assert rc == 0
+    pp = orc.PsiPhi.__new__(orc.PsiPhi)
+    pp.meta = orc.Meta(meta.num_times, meta.width, meta.height, meta.num_bytes, meta.psi_min_val, meta.psi_max_val,
+                       meta.psi_scale, meta.phi_min_val, meta.phi_max_val, meta.phi_scale)
+    pp.array = host
+    pp.times = np.ascontiguousarray(times, dtype=np.float64)
+    pp.T, pp.H, pp.W, pp.nb = int(meta.num_times), int(meta.height), int(meta.width), int(meta.num_bytes)
+    return pp
+
+
+@pytest.mark.parametrize("num_bytes,sigmag", [(-1, False), (1, True)])
+def test_headline_search_windows_against_the_oracle(orc, num_bytes, sigmag):
+    """configs[1] / configs[2] at full size (64 x 512 x 512, 1024 candidates, the bench's own stack): windows of
+    the product's result buffer against the ORACLE on the same array -- the kernel-semantics search bit for bit
+    and, for configs[1] (min_obs 0, no sigma-G: the regime where the reference's CPU and GPU searches select the
+    same trajectories), the reference CPU StackSearch semantics as per-pixel likelihood lists."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    import bench
+    from kbmod_amd import capi
+    from kbmod_amd import fake_data as fd
+
+    lib = capi.load_lib()
+    dev = torch.device("cuda")
+    T, H, W, K = 64, 512, 512, 8
+    sci, var, times, psf = bench.synthetic_stack(torch, dev, T, H, W)
+    psf_all = np.ascontiguousarray(np.tile(psf.ravel(), T), dtype=np.float32)
+    psf_dims = np.full(T, psf.shape[0], dtype=np.int32)
+    meta, arr = capi.Meta(), C.c_void_p()
+    stream = torch.cuda.current_stream().cuda_stream
+    capi.check(lib.kb_build_psi_phi_from_device(sci.data_ptr(), var.data_ptr(), psf_all.ctypes.data, psf_dims.ctypes.data,
+                                                T, H, W, num_bytes, C.byref(meta), C.byref(arr), stream))
+    torch.cuda.synchronize()
+    vx, vy = fd.kbmod_v1_candidates(32, 5.0, 40.0, 32, 0.0, 1.5)
+    cands_np = np.zeros((len(vx), 7), dtype=np.float32)
+    cands_np[:, 0], cands_np[:, 1] = vx, vy
+    cands = torch.from_numpy(cands_np).to(dev)
+    nb = -1 if num_bytes in (-1, 4) else num_bytes
+    if sigmag:
+        params = capi.Params(T // 2, 10.0, 1, 0.25, 0.75, 0.7413, nb, 0, W, 0, H, K, 0)
+    else:
+        params = capi.Params(0, 0.0, 0, 0.25, 0.75, -1.0, nb, 0, W, 0, H, K, 0)
+    results = torch.empty((H * W * K, 7), dtype=torch.float32, device=dev)
+    st = capi.Stats()
+    capi.check(lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), len(vx),
+                                           results.data_ptr(), H * W * K, 0, stream, C.byref(st)))
+    torch.cuda.synchronize()
+    assert st.kernel_variant // 10000 == 2  # kb_search_lds on the float copy
+    got = results.cpu().numpy().reshape(H, W, K, 7)
+
+    pp = _oracle_view(orc, lib, meta, arr, times.cpu().numpy())
+    ocands = orc.make_candidates(vx, vy)
+    # windows: an image corner (trajectories leave the image), the interior, and a mover's neighbourhood
+    obj_rng = np.random.default_rng(99)
+    mx, my = int(obj_rng.integers(20, W - 60)), int(obj_rng.integers(20, H - 60))
+    for (x0, y0, w, h) in [(0, 0, 48, 6), (230, 250, 40, 4), (max(0, mx - 8), max(0, my - 2), 24, 6), (W - 40, H - 5, 40, 5)]:
+        kw = dict(x_start_min=x0, x_start_max=x0 + w, y_start_min=y0, y_start_max=y0 + h, results_per_pixel=K)
+        if sigmag:
+            kw.update(do_sigmag_filter=1, sgl_L=0.25, sgl_H=0.75, sigmag_coeff=0.7413, min_lh=10.0, min_observations=T // 2)
+        p = pp.default_params(**kw)
+        exp = pp.search_kernel_semantics(ocands, p).reshape(h, w, K)
+        win = got[y0:y0 + h, x0:x0 + w]
+        for i, name in enumerate(("vx", "vy", "lh", "flux", "x", "y", "obs_count")):
+            col = win[..., i]
+            if name in ("x", "y", "obs_count"):
+                col = col.view(np.int32)
+            assert np.array_equal(col, exp[name]), (name, (x0, y0))
+        if not sigmag:
+            cpu = pp.search_cpu(ocands, p).reshape(h, w, K)
+            assert np.array_equal(win[..., 2], cpu["lh"]), ("cpu semantics lh", (x0, y0))
+            # pixels whose K + 1 best likelihoods are distinct: the selection is unique there
+            kw1 = dict(kw, results_per_pixel=K + 1)
+            lh = pp.search_cpu(ocands, pp.default_params(**kw1)).reshape(h, w, K + 1)["lh"]
+            untied = ~(lh[..., :-1] == lh[..., 1:]).any(axis=-1)
+            assert untied.any()
+            for i, name in ((0, "vx"), (1, "vy"), (3, "flux")):
+                assert np.array_equal(win[..., i][untied], cpu[name][untied]), ("cpu semantics", name, (x0, y0))
+    lib.kb_free_gpu_block(arr)
+
+
+def test_readme_configuration_at_full_size(kb, orc):
+    """BASELINE configs[0] as stated: 10 x 512 x 512 float32, 25 candidates of KBMODV1Search(5, 0, 4, 5, -0.1, 0.1),
+    min_obs 7 -- psi/phi from the HIP builder, then the CPU StackSearch (on_gpu=False) against the oracle's
+    restatement of the reference CPU search, and the GPU search against the kernel-semantics oracle."""
+    import numpy as np
+
+    from kbmod_amd import fake_data as fd
+    from tests import util
+
+    times = fd.create_fake_times(10, 57130.2)
+    st = fd.make_fake_image_stack(512, 512, times, noise_level=2.0, psf_val=0.5, rng=np.random.default_rng(1))
+    fd.add_fake_object(st, 2, 0, 10.7, 15.3, flux=275.0)
+    vx, vy = fd.kbmod_v1_candidates(5, 0, 4, 5, -0.1, 0.1)
+    assert len(vx) == 25
+    pp = orc.PsiPhi.from_images(st.sci, st.var, st.psfs, st.zeroed_times)
+    ocands = orc.make_candidates(vx, vy)
+    for on_gpu in (False, True):
+        s = kb.StackSearch(st.sci, st.var, st.psfs, st.zeroed_times)
+        assert s.get_psi_phi_array().device_resident
+        s.set_min_obs(7)
+        s.search_all(util.trajectories(kb, vx, vy), on_gpu)
+        got = s.results_to_numpy()
+        p = pp.default_params(min_observations=7)
+        raw = pp.search_kernel_semantics(ocands, p) if on_gpu else pp.search_cpu(ocands, p)
+        exp = util.as_table(orc.filter_sort(raw, 0.0, 7))
+        assert got.shape == exp.shape and np.array_equal(got, exp), on_gpu
+        assert len(got) > 1000
