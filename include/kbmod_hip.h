@@ -79,6 +79,13 @@ int kb_free_gpu_block(void* ptr_dev);                                           
 int kb_copy_block_to_gpu(const void* src_host, void* dst_dev, uint64_t memory_size); /* :112 */
 int kb_copy_block_to_cpu(void* dst_host, const void* src_dev, uint64_t memory_size); /* :124 */
 int kb_device_synchronize(void);
+/* new (multi-GPU fan-out inside one process): the calling thread's current device, and a copy between two devices'
+ * HBM (over xGMI where the devices are peers).  Every entry point acts on the calling thread's current device; the
+ * library keeps its workspaces per device. */
+int kb_get_device(void);           /* -1 without a device */
+int kb_set_device(int32_t device);
+int kb_copy_block_between_gpus(void* dst_dev, int32_t dst_device, const void* src_dev, int32_t src_device,
+                               uint64_t memory_size);
 /* new: streaming device-to-device copy of `bytes`, `iters` timed passes; *gbps_out = (read + written bytes) / time.
  * The measured HBM peak of the roofline report (bench.py). */
 int kb_measure_copy_bandwidth(uint64_t bytes, int32_t iters, void* stream, double* gbps_out);
@@ -102,7 +109,27 @@ int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, con
                                  const int32_t* psf_dims, int32_t num_times, int32_t height, int32_t width,
                                  int32_t num_bytes, kb_psi_phi_meta* meta_out, void** psi_phi_dev_out,
                                  void* stream);
-/* Same, from host images (sci_host[t] / var_host[t] are H*W float32 each). */
+/* The same build with options (new).  build_flags:
+ *   KB_BUILD_SEPARABLE      rank-1 PSF kernels (every Gaussian: core/psf.py:49-74) are correlated as a row pass and
+ *                           a column pass over the masked image and the mask (kb_conv_sep_kernel).  Agrees with the
+ *                           default 2-D kernel to rounding (1e-4 relative), not bit for bit; a stack with any kernel
+ *                           that does not factor takes the 2-D kernel;
+ *   KB_BUILD_EMPTY_IS_ZERO  a valid centre whose PSF footprint holds no valid pixel gives 0.0, as the reference's own
+ *                           device builder does (image_kernels.cu:61); default NaN, the reference CPU value
+ *                           (image_utils_cpp.cpp:60-61), which the CPU StackSearch and the parity tests assume. */
+enum { KB_BUILD_SEPARABLE = 1, KB_BUILD_EMPTY_IS_ZERO = 2 };
+int kb_build_psi_phi_from_device_ex(const float* sci_dev, const float* var_dev, const float* psf_host,
+                                    const int32_t* psf_dims, int32_t num_times, int32_t height, int32_t width,
+                                    int32_t num_bytes, uint32_t build_flags, kb_psi_phi_meta* meta_out,
+                                    void** psi_phi_dev_out, void* stream);
+/* From contiguous host stacks sci_host / var_host = [T][H][W] float32 (new; the ingest path, SURVEY 8(f4): what
+ * WorkUnit.from_fits leaves in memory, work_unit.py:489-608): uploaded in chunks of epochs through pinned staging
+ * buffers on a copy stream, each chunk correlated behind its arrival. */
+int kb_build_psi_phi_from_host_stack(const float* sci_host, const float* var_host, const float* psf_host,
+                                     const int32_t* psf_dims, int32_t num_times, int32_t height, int32_t width,
+                                     int32_t num_bytes, uint32_t build_flags, kb_psi_phi_meta* meta_out,
+                                     void** psi_phi_dev_out);
+/* Same as kb_build_psi_phi_from_device, from separate host images (sci_host[t] / var_host[t] are H*W float32 each). */
 int kb_build_psi_phi_from_host(const float* const* sci_host, const float* const* var_host,
                                const float* psf_host, const int32_t* psf_dims, int32_t num_times,
                                int32_t height, int32_t width, int32_t num_bytes, kb_psi_phi_meta* meta_out,

@@ -140,6 +140,31 @@ int kb_measure_copy_bandwidth(uint64_t bytes, int32_t iters, void* stream_v, dou
     return 0;
 }
 
+int kb_get_device(void) {
+    if (kb_device_count() == 0) return -1;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev;
+}
+
+int kb_set_device(int32_t device) {
+    if (device < 0 || device >= kb_device_count()) return kb::fail("Invalid device " + std::to_string(device));
+    KB_HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+
+int kb_copy_block_between_gpus(void* dst_dev, int32_t dst_device, const void* src_dev, int32_t src_device,
+                               uint64_t memory_size) {
+    if (dst_dev == nullptr || src_dev == nullptr) return kb::fail("Invalid GPU pointer");
+    if (memory_size == 0) return 0;
+    if (dst_device == src_device) {
+        KB_HIP_TRY(hipMemcpy(dst_dev, src_dev, memory_size, hipMemcpyDeviceToDevice));
+    } else {
+        KB_HIP_TRY(hipMemcpyPeer(dst_dev, dst_device, src_dev, src_device, memory_size));
+    }
+    return 0;
+}
+
 int kb_device_synchronize(void) {
     KB_HIP_TRY(hipDeviceSynchronize());
     return 0;

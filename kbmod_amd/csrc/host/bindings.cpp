@@ -398,6 +398,32 @@ PYBIND11_MODULE(search, m) {
                  }),
                  py::arg("sci_imgs"), py::arg("var_imgs"), py::arg("psf_kernels"), py::arg("zeroed_times"),
                  py::arg("num_bytes") = -1)
+            // the ingest form: contiguous [T][H][W] float32 stacks straight to the device builder
+            .def_static(
+                    "from_image_stacks",
+                    [](py::array_t<float, py::array::c_style | py::array::forcecast> sci,
+                       py::array_t<float, py::array::c_style | py::array::forcecast> var,
+                       const std::vector<conv_array>& psfs, std::vector<double> times, int num_bytes, bool separable_psf,
+                       bool empty_footprint_is_zero) {
+                        if (sci.ndim() != 3 || var.ndim() != 3) {
+                            throw std::runtime_error("from_image_stacks expects [T][H][W] arrays");
+                        }
+                        for (int d = 0; d < 3; ++d) {
+                            if (sci.shape(d) != var.shape(d)) {
+                                throw std::runtime_error("The science and variance stacks differ in shape.");
+                            }
+                        }
+                        std::vector<Image> p = to_images(psfs);
+                        const uint32_t flags = (separable_psf ? (uint32_t)KB_BUILD_SEPARABLE : 0u) |
+                                               (empty_footprint_is_zero ? (uint32_t)KB_BUILD_EMPTY_IS_ZERO : 0u);
+                        return std::unique_ptr<StackSearch>(new StackSearch(sci.data(), var.data(), (unsigned)sci.shape(0),
+                                                                            (unsigned)sci.shape(1), (unsigned)sci.shape(2), p,
+                                                                            times, num_bytes, flags));
+                    },
+                    py::arg("sci_stack"), py::arg("var_stack"), py::arg("psf_kernels"), py::arg("zeroed_times"),
+                    py::arg("num_bytes") = -1, py::arg("separable_psf") = false, py::arg("empty_footprint_is_zero") = false)
+            .def("set_search_devices", &StackSearch::set_search_devices)
+            .def("get_search_devices", &StackSearch::get_search_devices)
             .def_property_readonly("num_images", &StackSearch::num_images)
             .def_property_readonly("height", &StackSearch::get_image_height)
             .def_property_readonly("width", &StackSearch::get_image_width)

@@ -1,15 +1,29 @@
-// StackSearch and the explicit CPU search of kbmod_amd.search.
+// StackSearch of kbmod_amd.search: the object behind the reference's `kbmod.search.StackSearch`
+// (stack_search.{h,cpp}:18-338; CPU search cpu_search_algorithms.cpp:20-124) with the same Python-visible
+// methods, validation rules, error messages and log / timer labels.
 //
-// Mirrors stack_search.{h,cpp}:18-338 and cpu_search_algorithms.cpp:20-124 of
-// the reference: same methods, validation, error messages and log/timer labels.
-// on_gpu=True dispatches to libkbmod_hip.so (kb_device_search_filter) and NEVER
-// falls back to the host: without a device it raises, as the reference does
-// (stack_search.cpp:240).  on_gpu=False is the reference's explicit CPU search.
+// How it is put together here:
+//  * every trajectory evaluation on the host -- the explicit CPU search (on_gpu=False), the
+//    single-trajectory calls -- goes through kb::evaluate_trajectory_full of search_math.h, the one
+//    evaluator the device kernels' epilogue also uses;
+//  * on_gpu=True runs kb_device_search_filter of libkbmod_hip.so and filters / sorts in HBM; it never
+//    falls back to the host: without a device it raises, as the reference does (stack_search.cpp:240);
+//  * with more than one search device (set_search_devices) the candidate list is cut into contiguous
+//    slices, one host thread per device searches its slice against its own replica of psi/phi
+//    (kb_device_search_compact, 16-byte records), the records are copied to the first device and merged
+//    there (kb_merge_compact) -- SURVEY 8(e): the fan-out lives behind search_all, the Python surface
+//    does not change;
+//  * psi/phi is built on the device, from a list of images (the reference's constructor) or from
+//    contiguous [T][H][W] stacks without any per-image conversion (the ingest path).
 #ifndef KBH_STACK_SEARCH_H_
 #define KBH_STACK_SEARCH_H_
 
+#include <algorithm>
+#include <cstring>
 #include <sstream>
+#include <thread>
 
+#include "../search_math.h"
 #include "common.h"
 #include "image_utils.h"
 #include "psi_phi_array.h"
@@ -17,98 +31,100 @@
 
 namespace search {
 
-// cpu_search_algorithms.cpp:20-50
+namespace detail {
+
+inline void require(bool ok, const std::string& message) {
+    if (!ok) throw std::runtime_error(message);
+}
+
+inline std::string bounds_text(const char* axis, int lo, int hi) {
+    return std::string("Invalid search bounds for the ") + axis + " pixel [" + std::to_string(lo) + ", " +
+           std::to_string(hi) + "]";
+}
+
+// A device block that is released when it goes out of scope.
+struct DeviceBlock {
+    void* ptr = nullptr;
+    DeviceBlock() = default;
+    explicit DeviceBlock(uint64_t bytes) { check_status(kb_allocate_gpu_block(std::max<uint64_t>(bytes, 1), &ptr)); }
+    DeviceBlock(const DeviceBlock&) = delete;
+    DeviceBlock& operator=(const DeviceBlock&) = delete;
+    ~DeviceBlock() {
+        if (ptr != nullptr) (void)kb_free_gpu_block(ptr);
+    }
+    template <typename T>
+    T* as() const {
+        return reinterpret_cast<T*>(ptr);
+    }
+};
+
+}  // namespace detail
+
+// cpu_search_algorithms.cpp:20-50: summed psi / phi, likelihood and flux of one trajectory on the host
+// array -- kb::evaluate_trajectory_full with the sigma-G clip off (the CPU search has none).
 inline void evaluate_trajectory_cpu(PsiPhiArray& psi_phi, Trajectory& candidate) {
-    const unsigned int num_times = psi_phi.get_num_times();
-    float psi_sum = 0.0;
-    float phi_sum = 0.0;
-    candidate.obs_count = 0;
-    candidate.lh = -1.0;
-    candidate.flux = -1.0;
-    int num_seen = 0;
-    for (unsigned int i = 0; i < num_times; ++i) {
-        double curr_time = psi_phi.read_time(i);
-        int current_x = (int)(floor(candidate.x + candidate.vx * curr_time + 0.5f));
-        int current_y = (int)(floor(candidate.y + candidate.vy * curr_time + 0.5f));
-        PsiPhi pixel_vals = psi_phi.read_psi_phi(i, current_y, current_x);
-        if (std::isfinite(pixel_vals.psi) && std::isfinite(pixel_vals.phi)) {
-            psi_sum += pixel_vals.psi;
-            phi_sum += pixel_vals.phi;
-            num_seen += 1;
-        }
-    }
-    candidate.obs_count = num_seen;
-    candidate.lh = (phi_sum > 0) ? (psi_sum / std::sqrt(phi_sum)) : -1.0;
-    candidate.flux = (phi_sum > 0) ? (psi_sum / phi_sum) : -1.0;
+    kb_search_params plain{};
+    plain.do_sigmag_filter = 0;
+    plain.min_observations = 0;
+    kb_trajectory t;
+    std::memcpy(&t, &candidate, sizeof(t));
+    kb::evaluate_trajectory_full<1>(psi_phi.get_meta_data(), psi_phi.host_ptr(), psi_phi.get_cpu_time_array_ptr(), plain, &t,
+                                    static_cast<const kb::SigmaGScratch<1>*>(nullptr));
+    std::memcpy(&candidate, &t, sizeof(t));
 }
 
-// cpu_search_algorithms.cpp:57-86: evaluate every candidate at (y, x), sort
-// descending by lh, keep the first num_results (ties keep candidate order).
-inline void evaluate_single_pixel(int y, int x, PsiPhiArray& psi_phi, const std::vector<Trajectory>& cands,
-                                  int num_results, std::vector<Trajectory>& scratch, Trajectory* out) {
-    const uint64_t num_candidates = cands.size();
-    if ((uint64_t)num_results > num_candidates) {
-        throw std::runtime_error("evaluate_single_pixel requesting more results than candidates.");
-    }
-    scratch.resize(num_candidates);
-    for (uint64_t trj_idx = 0; trj_idx < num_candidates; ++trj_idx) {
-        Trajectory& curr_trj = scratch[trj_idx];
-        curr_trj.x = x;
-        curr_trj.y = y;
-        curr_trj.vx = cands[trj_idx].vx;
-        curr_trj.vy = cands[trj_idx].vy;
-        curr_trj.flux = 0.0;
-        curr_trj.obs_count = 0;
-        evaluate_trajectory_cpu(psi_phi, curr_trj);
-    }
-    std::stable_sort(scratch.begin(), scratch.end(),
-                     [](const Trajectory& a, const Trajectory& b) { return b.lh < a.lh; });
-    for (int i = 0; i < num_results; ++i) out[i] = scratch[i];
-}
-
-// cpu_search_algorithms.cpp:93-124
+// cpu_search_algorithms.cpp:57-124: per start pixel every candidate is evaluated, the list ordered by
+// falling likelihood (candidates of equal likelihood stay in list order) and its head kept.
 inline void search_cpu_only(PsiPhiArray& psi_phi_array, SearchParameters params, TrajectoryList& trj_to_search,
                             TrajectoryList& results) {
-    const int64_t search_height = (int64_t)params.y_start_max - params.y_start_min;
-    const int64_t search_width = (int64_t)params.x_start_max - params.x_start_min;
-    if (search_height <= 0 || search_width <= 0) throw std::runtime_error("Invalid search bounds.");
-    const uint64_t num_candidates = trj_to_search.get_size();
-    const uint64_t results_per_test =
-            (num_candidates < params.results_per_pixel) ? num_candidates : params.results_per_pixel;
-    const uint64_t total_results = results_per_test * (uint64_t)search_height * (uint64_t)search_width;
-    results.resize(total_results);
-    results.reset_all();
-    if (total_results == 0) return;
-    psi_phi_array.ensure_host();  // once, outside the parallel region
-
+    const int64_t rows = (int64_t)params.y_start_max - params.y_start_min;
+    const int64_t cols = (int64_t)params.x_start_max - params.x_start_min;
+    detail::require(rows > 0 && cols > 0, "Invalid search bounds.");
     const std::vector<Trajectory>& cands = trj_to_search.get_list();
+    const uint64_t keep = std::min<uint64_t>(cands.size(), params.results_per_pixel);
+    results.resize(keep * (uint64_t)rows * (uint64_t)cols);
+    results.reset_all();
+    if (results.get_size() == 0) return;
+
+    const kb_psi_phi_meta meta = psi_phi_array.get_meta_data();
+    const void* array = psi_phi_array.host_ptr();  // brings the array to the host once, before the threads start
+    const double* times = psi_phi_array.get_cpu_time_array_ptr();
+    kb_search_params plain{};
     std::vector<Trajectory>& out = results.get_list();
 #pragma omp parallel
     {
-        std::vector<Trajectory> scratch;
-#pragma omp for collapse(2) schedule(dynamic, 16)
-        for (int64_t y_i = 0; y_i < search_height; ++y_i) {
-            for (int64_t x_i = 0; x_i < search_width; ++x_i) {
-                // Each pixel owns its slots, so no critical section is needed (cf. :115).
-                const uint64_t start_ind = ((uint64_t)y_i * (uint64_t)search_width + (uint64_t)x_i) * results_per_test;
-                evaluate_single_pixel((int)(y_i + params.y_start_min), (int)(x_i + params.x_start_min), psi_phi_array,
-                                      cands, (int)results_per_test, scratch, &out[start_ind]);
+        std::vector<Trajectory> column(cands.size());
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t pixel = 0; pixel < rows * cols; ++pixel) {
+            const int y = (int)(pixel / cols + params.y_start_min), x = (int)(pixel % cols + params.x_start_min);
+            for (size_t c = 0; c < cands.size(); ++c) {
+                kb_trajectory t{};
+                t.x = x;
+                t.y = y;
+                t.vx = cands[c].vx;
+                t.vy = cands[c].vy;
+                kb::evaluate_trajectory_full<1>(meta, array, times, plain, &t,
+                                                static_cast<const kb::SigmaGScratch<1>*>(nullptr));
+                std::memcpy(&column[c], &t, sizeof(t));
             }
+            std::stable_sort(column.begin(), column.end(),
+                             [](const Trajectory& a, const Trajectory& b) { return b.lh < a.lh; });
+            std::copy_n(column.begin(), keep, out.begin() + pixel * keep);  // every pixel owns its slots (cf. :115)
         }
     }
 }
 
-// stack_search.cpp:22-39
+// stack_search.cpp:22-39: psi in [0, T), phi in [T, 2T), invalid samples left at 0.
 inline std::vector<float> extract_joint_psi_phi_curve(PsiPhiArray& psi_phi, const Trajectory& trj) {
-    const unsigned int num_times = psi_phi.get_num_times();
-    std::vector<float> result(2 * num_times, 0.0);
-    for (unsigned int i = 0; i < num_times; ++i) {
-        double time = psi_phi.read_time(i);
-        PsiPhi v = psi_phi.read_psi_phi(i, trj.get_y_index(time), trj.get_x_index(time));
-        if (pixel_value_valid(v.psi)) result[i] = v.psi;
-        if (pixel_value_valid(v.phi)) result[i + num_times] = v.phi;
+    const unsigned int T = psi_phi.get_num_times();
+    std::vector<float> curve(2 * T, 0.0f);
+    for (unsigned int i = 0; i < T; ++i) {
+        const double when = psi_phi.read_time(i);
+        const PsiPhi sample = psi_phi.read_psi_phi(i, trj.get_y_index(when), trj.get_x_index(when));
+        if (pixel_value_valid(sample.psi)) curve[i] = sample.psi;
+        if (pixel_value_valid(sample.phi)) curve[i + T] = sample.phi;
     }
-    return result;
+    return curve;
 }
 
 class StackSearch {
@@ -119,32 +135,56 @@ public:
             : zeroed_times(zeroed_times_in), results(0) {
         rs_logger = logging::getLogger("kbmod.search.run_search");
         num_imgs = sci_imgs.size();
-        if (num_imgs == 0) throw std::runtime_error("No images in the to process.");
-        if (sci_imgs.size() != var_imgs.size()) {
-            throw std::runtime_error("The number of science and variance images do not match. Science: " +
-                                     std::to_string(sci_imgs.size()) + ", Variance: " +
-                                     std::to_string(var_imgs.size()));
-        }
-        if (sci_imgs.size() != psf_kernels.size()) {
-            throw std::runtime_error("The number of science and PSF kernel images do not match. Science: " +
-                                     std::to_string(sci_imgs.size()) + ", PSF Kernels: " +
-                                     std::to_string(psf_kernels.size()));
-        }
-        if (sci_imgs.size() != zeroed_times.size()) {
-            throw std::runtime_error("The number of science images and zeroed times do not match. Science: " +
-                                     std::to_string(sci_imgs.size()) + ", Zeroed Times: " +
-                                     std::to_string(zeroed_times.size()));
-        }
+        detail::require(num_imgs != 0, "No images in the to process.");
+        check_count("variance", "Variance", var_imgs.size());
+        check_count("PSF kernel", "PSF Kernels", psf_kernels.size());
+        check_count_times(zeroed_times.size());
         width = sci_imgs[0].cols;
         height = sci_imgs[0].rows;
         set_default_parameters(num_bytes);
         DebugTimer timer = DebugTimer("preparing Psi and Phi images", rs_logger);
-        fill_psi_phi_array_from_image_arrays(psi_phi_array, num_bytes, sci_imgs, var_imgs, psf_kernels,
-                                             zeroed_times);
+        fill_psi_phi_array_from_image_arrays(psi_phi_array, num_bytes, sci_imgs, var_imgs, psf_kernels, zeroed_times);
         psi_phi_preloaded = false;
         timer.stop();
     }
-    virtual ~StackSearch() { psi_phi_array.clear(); }
+
+    // The ingest form (work_unit.py:489-608 leaves the layers as arrays): contiguous
+    // [T][H][W] float32 stacks go to the device builder as they are -- no per-image conversion, chunked
+    // upload through pinned buffers overlapped with the correlation (kb_build_psi_phi_from_host_stack).
+    StackSearch(const float* sci_stack, const float* var_stack, unsigned int T, unsigned int H, unsigned int W,
+                std::vector<Image>& psf_kernels, std::vector<double>& zeroed_times_in, int num_bytes, uint32_t build_flags)
+            : zeroed_times(zeroed_times_in), results(0) {
+        rs_logger = logging::getLogger("kbmod.search.run_search");
+        num_imgs = T;
+        detail::require(num_imgs != 0 && H != 0 && W != 0, "No images in the to process.");
+        check_count("PSF kernel", "PSF Kernels", psf_kernels.size());
+        check_count_times(zeroed_times.size());
+        detail::require(has_gpu(), "GPU is not available for the psi/phi build.");
+        width = W;
+        height = H;
+        set_default_parameters(num_bytes);
+        DebugTimer timer = DebugTimer("preparing Psi and Phi images", rs_logger);
+        std::vector<int32_t> dims(T);
+        std::vector<float> psf_packed;
+        for (unsigned int i = 0; i < T; ++i) {
+            detail::require(psf_kernels[i].rows == psf_kernels[i].cols, "PSF kernel must be square.");
+            dims[i] = (int32_t)psf_kernels[i].rows;
+            psf_packed.insert(psf_packed.end(), psf_kernels[i].data.begin(), psf_kernels[i].data.end());
+        }
+        kb_psi_phi_meta meta;
+        void* dev = nullptr;
+        check_status(kb_build_psi_phi_from_host_stack(sci_stack, var_stack, psf_packed.data(), dims.data(), (int32_t)T,
+                                                      (int32_t)H, (int32_t)W, num_bytes, build_flags, &meta, &dev));
+        psi_phi_array.adopt_device_array(meta, dev);
+        psi_phi_array.set_time_array(zeroed_times);
+        psi_phi_preloaded = false;
+        timer.stop();
+    }
+
+    virtual ~StackSearch() {
+        drop_replicas();
+        psi_phi_array.clear();
+    }
 
     unsigned int num_images() const { return num_imgs; }
     unsigned int get_image_width() const { return width; }
@@ -156,123 +196,113 @@ public:
 
     // stack_search.cpp:89-117
     void set_default_parameters(int num_bytes = -1) {
+        detail::require(num_bytes == -1 || num_bytes == 1 || num_bytes == 2 || num_bytes == 4,
+                        "Invalid encoding size. Must be -1, 1, 2 or 4. Got " + std::to_string(num_bytes));
+        params = SearchParameters{};
         params.min_observations = 0;
         params.min_lh = 0.0;
         params.do_sigmag_filter = false;
         params.sgl_L = 0.25;
         params.sgl_H = 0.75;
         params.sigmag_coeff = -1.0;
-        if (num_bytes == 1 || num_bytes == 2) {
-            params.encode_num_bytes = num_bytes;
-        } else if (num_bytes == -1 || num_bytes == 4) {
-            params.encode_num_bytes = -1;
-        } else {
-            throw std::runtime_error("Invalid encoding size. Must be -1, 1, 2 or 4. Got " +
-                                     std::to_string(num_bytes));
-        }
+        params.encode_num_bytes = (num_bytes == 1 || num_bytes == 2) ? num_bytes : -1;
         params.results_per_pixel = 8;
         params.x_start_min = 0;
         params.x_start_max = width;
         params.y_start_min = 0;
         params.y_start_max = height;
     }
+
     // stack_search.cpp:119-172
     void set_min_obs(int new_value) {
-        if (new_value < 0) throw std::runtime_error("min_obs must be >= 0. Got " + std::to_string(new_value));
-        if ((unsigned int)new_value > num_imgs)
-            throw std::runtime_error("min_obs cannot be greater than the number of images. min_obs = " +
-                                     std::to_string(new_value) + ", num_imgs = " + std::to_string(num_imgs) + ".");
+        detail::require(new_value >= 0, "min_obs must be >= 0. Got " + std::to_string(new_value));
+        detail::require((unsigned int)new_value <= num_imgs,
+                        "min_obs cannot be greater than the number of images. min_obs = " + std::to_string(new_value) +
+                                ", num_imgs = " + std::to_string(num_imgs) + ".");
         params.min_observations = new_value;
     }
     void set_min_lh(float new_value) { params.min_lh = new_value; }
     void set_results_per_pixel(int new_value) {
-        if (new_value <= 0) throw std::runtime_error("Invalid results per pixel. Got " + std::to_string(new_value));
+        detail::require(new_value > 0, "Invalid results per pixel. Got " + std::to_string(new_value));
         params.results_per_pixel = new_value;
     }
     void enable_gpu_sigmag_filter(std::vector<float> percentiles, float sigmag_coeff, float min_lh) {
-        if (percentiles.size() != 2) {
-            throw std::runtime_error("Invalid percentiles for sigma G filtering. Expected 2 values, got " +
-                                     std::to_string(percentiles.size()) + ".");
-        }
-        if ((percentiles[0] >= percentiles[1]) || (percentiles[0] <= 0.0) || (percentiles[1] >= 1.0)) {
-            throw std::runtime_error("Invalid percentiles for sigma G filtering. Got [" +
-                                     std::to_string(percentiles[0]) + ", " + std::to_string(percentiles[1]) + "].");
-        }
-        if (sigmag_coeff <= 0.0) {
-            throw std::runtime_error("Invalid coefficient for sigma G filtering. Got " +
-                                     std::to_string(sigmag_coeff) + ".");
-        }
+        detail::require(percentiles.size() == 2, "Invalid percentiles for sigma G filtering. Expected 2 values, got " +
+                                                         std::to_string(percentiles.size()) + ".");
+        const float lo = percentiles[0], hi = percentiles[1];
+        detail::require(lo < hi && lo > 0.0 && hi < 1.0, "Invalid percentiles for sigma G filtering. Got [" +
+                                                                 std::to_string(lo) + ", " + std::to_string(hi) + "].");
+        detail::require(sigmag_coeff > 0.0,
+                        "Invalid coefficient for sigma G filtering. Got " + std::to_string(sigmag_coeff) + ".");
         params.do_sigmag_filter = true;
-        params.sgl_L = percentiles[0];
-        params.sgl_H = percentiles[1];
+        params.sgl_L = lo;
+        params.sgl_H = hi;
         params.sigmag_coeff = sigmag_coeff;
         params.min_lh = min_lh;
     }
     void disable_gpu_sigmag_filter() { params.do_sigmag_filter = false; }
     void set_start_bounds_x(int x_min, int x_max) {
-        if (x_min >= x_max) {
-            throw std::runtime_error("Invalid search bounds for the x pixel [" + std::to_string(x_min) + ", " +
-                                     std::to_string(x_max) + "]");
-        }
+        detail::require(x_min < x_max, detail::bounds_text("x", x_min, x_max));
         params.x_start_min = x_min;
         params.x_start_max = x_max;
     }
     void set_start_bounds_y(int y_min, int y_max) {
-        if (y_min >= y_max) {
-            throw std::runtime_error("Invalid search bounds for the y pixel [" + std::to_string(y_min) + ", " +
-                                     std::to_string(y_max) + "]");
-        }
+        detail::require(y_min < y_max, detail::bounds_text("y", y_min, y_max));
         params.y_start_min = y_min;
         params.y_start_max = y_max;
     }
 
     // stack_search.cpp:174-186
     void preload_psi_phi_array() {
-        if (!psi_phi_array.on_gpu()) {
-            psi_phi_array.move_to_gpu();
-            psi_phi_preloaded = true;
-        }
+        if (psi_phi_array.on_gpu()) return;
+        psi_phi_array.move_to_gpu();
+        psi_phi_preloaded = true;
     }
     void unload_psi_phi_array() {
-        if (psi_phi_array.on_gpu()) {
-            psi_phi_array.clear_from_gpu();
-            psi_phi_preloaded = false;
-        }
+        if (!psi_phi_array.on_gpu()) return;
+        psi_phi_array.clear_from_gpu();
+        psi_phi_preloaded = false;
     }
     bool psi_phi_array_on_gpu() const { return psi_phi_array.on_gpu(); }
 
-    // stack_search.cpp:193-207
+    // stack_search.cpp:193-219
     void evaluate_single_trajectory(Trajectory& trj, bool use_kernel) {
         if (!use_kernel) {
             evaluate_trajectory_cpu(psi_phi_array, trj);
-        } else {
-            if (!has_gpu()) throw std::runtime_error("GPU is not available for kernel evaluation.");
-            if (psi_phi_array.get_num_times() > MAX_NUM_IMAGES) {
-                throw std::runtime_error("Too many images to evaluate on GPU. Max = " +
-                                         std::to_string(MAX_NUM_IMAGES));
-            }
-            kb_trajectory t;
-            std::memcpy(&t, &trj, sizeof(t));
-            check_status(kb_evaluate_trajectory_host(&psi_phi_array.get_meta_data(), psi_phi_array.host_ptr(),
-                                                     psi_phi_array.get_cpu_time_array_ptr(), params, &t));
-            std::memcpy(&trj, &t, sizeof(t));
+            return;
         }
+        detail::require(has_gpu(), "GPU is not available for kernel evaluation.");
+        detail::require(psi_phi_array.get_num_times() <= MAX_NUM_IMAGES,
+                        "Too many images to evaluate on GPU. Max = " + std::to_string(MAX_NUM_IMAGES));
+        kb_trajectory t;
+        std::memcpy(&t, &trj, sizeof(t));
+        check_status(kb_evaluate_trajectory_host(&psi_phi_array.get_meta_data(), psi_phi_array.host_ptr(),
+                                                 psi_phi_array.get_cpu_time_array_ptr(), params, &t));
+        std::memcpy(&trj, &t, sizeof(t));
     }
-    // stack_search.cpp:209-219
     Trajectory search_linear_trajectory(int x, int y, float vx, float vy, bool use_kernel) {
-        Trajectory result;
-        result.x = x;
-        result.y = y;
-        result.vx = vx;
-        result.vy = vy;
-        evaluate_single_trajectory(result, use_kernel);
-        return result;
+        Trajectory trj = Trajectory::make_trajectory(x, y, vx, vy, 0.0f, 0.0f, 0);
+        evaluate_single_trajectory(trj, use_kernel);
+        return trj;
     }
+
+    // Devices the GPU search fans out over (default: the current device alone).  Entries may repeat
+    // (two slices on one device run one after the other): the tests exercise the fan-out that way on a
+    // single GPU.
+    void set_search_devices(const std::vector<int>& devices) {
+        const int n = kb_device_count();
+        for (int d : devices) {
+            detail::require(d >= 0 && d < std::max(n, 1), "Invalid search device " + std::to_string(d));
+        }
+        drop_replicas();
+        search_devices = devices;
+    }
+    const std::vector<int>& get_search_devices() const { return search_devices; }
 
     // stack_search.cpp:221-284
     void search_all(std::vector<Trajectory>& search_list, bool on_gpu) {
         TrajectoryList candidate_list(search_list);
-        uint64_t max_results = compute_max_results();
+        const uint64_t max_results = compute_max_results();
         DebugTimer core_timer = DebugTimer("Running batch search", rs_logger);
         std::stringstream logmsg;
         logmsg << "Searching X=[" << params.x_start_min << ", " << params.x_start_max << "] "
@@ -282,129 +312,98 @@ public:
 
         DebugTimer search_timer = DebugTimer("Running search", rs_logger);
         if (on_gpu) {
-            if (!has_gpu()) throw std::runtime_error("GPU is not available for search.");
-            if (psi_phi_array.get_num_times() > MAX_NUM_IMAGES) {
-                throw std::runtime_error("Number of images exceeds GPU maximum " + std::to_string(MAX_NUM_IMAGES));
-            }
+            detail::require(has_gpu(), "GPU is not available for search.");
+            detail::require(psi_phi_array.get_num_times() <= MAX_NUM_IMAGES,
+                            "Number of images exceeds GPU maximum " + std::to_string(MAX_NUM_IMAGES));
             rs_logger->info("Moving all data to GPU.");
             if (!psi_phi_preloaded) psi_phi_array.move_to_gpu();
-            candidate_list.move_to_gpu();
-            // The result slots are initialised by the kernel itself; nothing is
-            // uploaded (the reference uploads S*K*28 bytes of zeros here).
-            void* results_dev = nullptr;
-            void* sorted_dev = nullptr;
-            const uint64_t n_alloc = std::max<uint64_t>(max_results, 1) * sizeof(Trajectory);
-            check_status(kb_allocate_gpu_block(n_alloc, &results_dev));
-            try {
-                check_status(kb_allocate_gpu_block(n_alloc, &sorted_dev));
+            struct ReleaseArray {  // the array leaves "in use on the device" however the search ends
+                StackSearch* self;
+                ~ReleaseArray() {
+                    if (!self->psi_phi_preloaded) self->psi_phi_array.end_device_use();
+                }
+            } release{this};
+
+            // The result slots are written by the kernels themselves; nothing is uploaded (the reference
+            // uploads S*K*28 bytes of zeros here).
+            detail::DeviceBlock raw(max_results * sizeof(Trajectory)), kept(max_results * sizeof(Trajectory));
+            const bool fan_out = search_devices.size() > 1 && params.results_per_pixel <= 32 && !search_list.empty();
+            if (fan_out) {
+                search_on_devices(candidate_list, raw.as<kb_trajectory>(), max_results);
+            } else {
+                candidate_list.move_to_gpu();
                 check_status(kb_device_search_filter(
                         &psi_phi_array.get_meta_data(), psi_phi_array.get_gpu_array_ptr(),
                         psi_phi_array.get_gpu_time_array_ptr(), params,
-                        reinterpret_cast<const kb_trajectory*>(candidate_list.get_gpu_list_ptr()),
-                        candidate_list.get_size(), reinterpret_cast<kb_trajectory*>(results_dev), max_results,
-                        search_flags, nullptr, &last_stats));
-                search_timer.stop();
-                // stack_search.cpp:266-277 (filter by lh, filter by obs_count, sort by lh) done in HBM:
-                // only the survivors cross PCIe.
-                DebugTimer filter_timer = DebugTimer("Filtering results by LH and min_obs", rs_logger);
-                uint64_t kept = 0;
-                check_status(kb_filter_sort_results(reinterpret_cast<const kb_trajectory*>(results_dev), max_results,
-                                                    params.min_lh, params.min_observations,
-                                                    reinterpret_cast<kb_trajectory*>(sorted_dev), &kept, nullptr));
-                rs_logger->debug("Core search returned " + std::to_string(max_results) + " results.\n");
-                rs_logger->debug("After filtering by LH and min_obs " + std::to_string(kept) + " results (" +
-                                 std::to_string(max_results - kept) + " removed).\n");
-                filter_timer.stop();
-                rs_logger->info("Clearing all data from GPU.");
-                results.resize(0);
-                results.resize(kept);
-                if (kept > 0) {
-                    check_status(kb_copy_block_to_cpu(results.get_list().data(), sorted_dev, kept * sizeof(Trajectory)));
-                }
-            } catch (...) {
-                (void)kb_free_gpu_block(results_dev);
-                if (sorted_dev != nullptr) (void)kb_free_gpu_block(sorted_dev);
-                if (!psi_phi_preloaded) psi_phi_array.end_device_use();
-                throw;
+                        reinterpret_cast<const kb_trajectory*>(candidate_list.get_gpu_list_ptr()), candidate_list.get_size(),
+                        raw.as<kb_trajectory>(), max_results, search_flags, nullptr, &last_stats));
+                candidate_list.move_to_cpu();
             }
-            (void)kb_free_gpu_block(results_dev);
-            (void)kb_free_gpu_block(sorted_dev);
-            candidate_list.move_to_cpu();
-            if (!psi_phi_preloaded) psi_phi_array.end_device_use();
-            results.assert_valid();  // trajectory_list.cpp:152 / stack_search.cpp:280
-            core_timer.stop();
-            return;
+            search_timer.stop();
+            // stack_search.cpp:266-277 (filter by lh, filter by obs_count, sort by lh) in HBM: only the
+            // survivors cross PCIe.
+            DebugTimer filter_timer = DebugTimer("Filtering results by LH and min_obs", rs_logger);
+            uint64_t n_kept = 0;
+            check_status(kb_filter_sort_results(raw.as<kb_trajectory>(), max_results, params.min_lh, params.min_observations,
+                                                kept.as<kb_trajectory>(), &n_kept, nullptr));
+            report_filtering(max_results, n_kept);
+            filter_timer.stop();
+            rs_logger->info("Clearing all data from GPU.");
+            results.resize(0);
+            results.resize(n_kept);
+            if (n_kept > 0) {
+                check_status(kb_copy_block_to_cpu(results.get_list().data(), kept.ptr, n_kept * sizeof(Trajectory)));
+            }
         } else {
             rs_logger->info("Running search on CPU.");
             results.resize(0);
             search_cpu_only(psi_phi_array, params, candidate_list, results);
+            search_timer.stop();
+            const uint64_t before = results.get_size();
+            DebugTimer filter_timer = DebugTimer("Filtering results by LH and min_obs", rs_logger);
+            results.filter_by_likelihood(params.min_lh);
+            results.filter_by_obs_count(params.min_observations);
+            report_filtering(before, results.get_size());
+            filter_timer.stop();
+            DebugTimer sort_timer = DebugTimer("Sorting results", rs_logger);
+            results.sort_by_likelihood();
+            sort_timer.stop();
         }
-        search_timer.stop();
-
-        uint64_t num_results = results.get_size();
-        rs_logger->debug("Core search returned " + std::to_string(num_results) + " results.\n");
-        DebugTimer filter_timer = DebugTimer("Filtering results by LH and min_obs", rs_logger);
-        results.filter_by_likelihood(params.min_lh);
-        results.filter_by_obs_count(params.min_observations);
-        uint64_t new_num_results = results.get_size();
-        rs_logger->debug("After filtering by LH and min_obs " + std::to_string(new_num_results) + " results (" +
-                         std::to_string(num_results - new_num_results) + " removed).\n");
-        filter_timer.stop();
-        DebugTimer sort_timer = DebugTimer("Sorting results", rs_logger);
-        results.sort_by_likelihood();
-        sort_timer.stop();
-        results.assert_valid();
+        results.assert_valid();  // trajectory_list.cpp:152 / stack_search.cpp:280
         core_timer.stop();
     }
 
     // stack_search.cpp:286-300
     uint64_t compute_max_results() {
-        if (params.x_start_min >= params.x_start_max)
-            throw std::runtime_error("Invalid search bounds for the x pixel [" +
-                                     std::to_string(params.x_start_min) + ", " +
-                                     std::to_string(params.x_start_max) + "]");
-        if (params.y_start_min >= params.y_start_max)
-            throw std::runtime_error("Invalid search bounds for the y pixel [" +
-                                     std::to_string(params.y_start_min) + ", " +
-                                     std::to_string(params.y_start_max) + "]");
-        uint64_t search_width = params.x_start_max - params.x_start_min;
-        uint64_t search_height = params.y_start_max - params.y_start_min;
-        return search_width * search_height * params.results_per_pixel;
+        detail::require(params.x_start_min < params.x_start_max,
+                        detail::bounds_text("x", params.x_start_min, params.x_start_max));
+        detail::require(params.y_start_min < params.y_start_max,
+                        detail::bounds_text("y", params.y_start_min, params.y_start_max));
+        return (uint64_t)(params.x_start_max - params.x_start_min) * (uint64_t)(params.y_start_max - params.y_start_min) *
+               params.results_per_pixel;
     }
 
     // stack_search.cpp:302-318: (num_trj, 2*num_times) row-major.  With the array resident in HBM the
-    // gather runs on the device (kb_psi_phi_curves); otherwise the reference's host loop.
+    // gather runs on the device (kb_psi_phi_curves); otherwise on the host threads.
     Image get_all_psi_phi_curves(const std::vector<Trajectory>& trajectories) {
         const int64_t num_trj = trajectories.size();
         Image out(num_trj, 2 * (int64_t)num_imgs);
         if (num_trj == 0) return out;
         if (has_gpu() && psi_phi_array.device_resident()) {
             psi_phi_array.ensure_device();  // times too
-            void* trj_dev = nullptr;
-            void* out_dev = nullptr;
-            check_status(kb_allocate_gpu_block((uint64_t)num_trj * sizeof(Trajectory), &trj_dev));
-            try {
-                check_status(kb_allocate_gpu_block(out.data.size() * sizeof(float), &out_dev));
-                check_status(kb_copy_block_to_gpu(trajectories.data(), trj_dev, (uint64_t)num_trj * sizeof(Trajectory)));
-                check_status(kb_psi_phi_curves(&psi_phi_array.get_meta_data(), psi_phi_array.get_gpu_array_ptr(),
-                                               psi_phi_array.get_gpu_time_array_ptr(),
-                                               reinterpret_cast<const kb_trajectory*>(trj_dev), (uint64_t)num_trj,
-                                               reinterpret_cast<float*>(out_dev), nullptr));
-                check_status(kb_copy_block_to_cpu(out.data.data(), out_dev, out.data.size() * sizeof(float)));
-            } catch (...) {
-                (void)kb_free_gpu_block(trj_dev);
-                if (out_dev != nullptr) (void)kb_free_gpu_block(out_dev);
-                throw;
-            }
-            (void)kb_free_gpu_block(trj_dev);
-            (void)kb_free_gpu_block(out_dev);
+            detail::DeviceBlock trj_dev((uint64_t)num_trj * sizeof(Trajectory)), out_dev(out.data.size() * sizeof(float));
+            check_status(kb_copy_block_to_gpu(trajectories.data(), trj_dev.ptr, (uint64_t)num_trj * sizeof(Trajectory)));
+            check_status(kb_psi_phi_curves(&psi_phi_array.get_meta_data(), psi_phi_array.get_gpu_array_ptr(),
+                                           psi_phi_array.get_gpu_time_array_ptr(), trj_dev.as<const kb_trajectory>(),
+                                           (uint64_t)num_trj, out_dev.as<float>(), nullptr));
+            check_status(kb_copy_block_to_cpu(out.data.data(), out_dev.ptr, out.data.size() * sizeof(float)));
             return out;
         }
         psi_phi_array.ensure_host();
 #pragma omp parallel for schedule(dynamic, 64)
         for (int64_t i = 0; i < num_trj; ++i) {
-            std::vector<float> curve = extract_joint_psi_phi_curve(psi_phi_array, trajectories[i]);
-            std::memcpy(&out.data[(size_t)i * 2 * num_imgs], curve.data(), curve.size() * sizeof(float));
+            const std::vector<float> curve = extract_joint_psi_phi_curve(psi_phi_array, trajectories[i]);
+            std::copy(curve.begin(), curve.end(), out.data.begin() + (size_t)i * 2 * num_imgs);
         }
         return out;
     }
@@ -420,10 +419,119 @@ public:
         if (results.on_gpu()) results.move_to_cpu();
         results.resize(0);
     }
-    // Debug/self-check hook: bit 0 forces the per-lane exact-position path.
+    // kb_device_search_filter flags (include/kbmod_hip.h): kernel choice, self-check paths.
     void set_search_flags(uint32_t f) { search_flags = f; }
 
 protected:
+    void check_count(const char* what, const char* label, size_t n) const {
+        detail::require(n == num_imgs, std::string("The number of science and ") + what + " images do not match. Science: " +
+                                               std::to_string(num_imgs) + ", " + label + ": " + std::to_string(n));
+    }
+    void check_count_times(size_t n) const {
+        detail::require(n == num_imgs, "The number of science images and zeroed times do not match. Science: " +
+                                               std::to_string(num_imgs) + ", Zeroed Times: " + std::to_string(n));
+    }
+    void report_filtering(uint64_t before, uint64_t after) {
+        rs_logger->debug("Core search returned " + std::to_string(before) + " results.\n");
+        rs_logger->debug("After filtering by LH and min_obs " + std::to_string(after) + " results (" +
+                         std::to_string(before - after) + " removed).\n");
+    }
+
+    // A device's own copy of the array and the epoch times (the home device uses the array itself).
+    struct Replica {
+        int device = -1;
+        void* array = nullptr;
+        void* times = nullptr;
+    };
+    void drop_replicas() {
+        int prev = kb_get_device();
+        for (Replica& r : replicas) {
+            if (r.device < 0) continue;
+            (void)kb_set_device(r.device);
+            if (r.array != nullptr) (void)kb_free_gpu_block(r.array);
+            if (r.times != nullptr) (void)kb_free_gpu_block(r.times);
+        }
+        replicas.clear();
+        if (prev >= 0) (void)kb_set_device(prev);
+    }
+    const Replica& replica_on(int device, int home) {
+        for (const Replica& r : replicas) {
+            if (r.device == device) return r;
+        }
+        Replica r;
+        r.device = device;
+        const uint64_t bytes = psi_phi_array.get_total_array_size(), tbytes = (uint64_t)num_imgs * sizeof(double);
+        check_status(kb_set_device(device));
+        check_status(kb_allocate_gpu_block(bytes, &r.array));
+        check_status(kb_allocate_gpu_block(tbytes, &r.times));
+        check_status(kb_copy_block_between_gpus(r.array, device, psi_phi_array.get_gpu_array_ptr(), home, bytes));
+        check_status(kb_copy_block_between_gpus(r.times, device, psi_phi_array.get_gpu_time_array_ptr(), home, tbytes));
+        replicas.push_back(r);
+        return replicas.back();
+    }
+
+    // contiguous candidate slices, one host thread per slice on its device, 16-byte records
+    // copied to the home device, per-pixel merge there.  `merged` (home device) receives the per-pixel lists.
+    void search_on_devices(TrajectoryList& candidates, kb_trajectory* merged, uint64_t max_results) {
+        const int home = kb_get_device();
+        const int n_parts = (int)search_devices.size();
+        const std::vector<Trajectory>& cands = candidates.get_list();
+        const uint64_t n = cands.size();
+        for (int d : search_devices) {  // replicas are made here, one after the other, before the threads start
+            if (d != home) (void)replica_on(d, home);
+        }
+        check_status(kb_set_device(home));
+        detail::DeviceBlock gathered((uint64_t)n_parts * max_results * sizeof(kb_compact_result));
+        detail::DeviceBlock all_cands(n * sizeof(Trajectory));
+        check_status(kb_copy_block_to_gpu(cands.data(), all_cands.ptr, n * sizeof(Trajectory)));
+
+        std::vector<std::string> errors(n_parts);
+        std::vector<kb_search_stats> part_stats(n_parts);
+        auto run_part = [&](int part) {
+            try {
+                const int device = search_devices[part];
+                check_status(kb_set_device(device));
+                const uint64_t lo = n * part / n_parts, hi = n * (part + 1) / n_parts;
+                const void* array = psi_phi_array.get_gpu_array_ptr();
+                const double* times = psi_phi_array.get_gpu_time_array_ptr();
+                if (device != home) {
+                    for (const Replica& r : replicas) {
+                        if (r.device == device) {
+                            array = r.array;
+                            times = reinterpret_cast<const double*>(r.times);
+                        }
+                    }
+                }
+                detail::DeviceBlock slice((hi - lo) * sizeof(Trajectory)), records(max_results * sizeof(kb_compact_result));
+                if (hi > lo) check_status(kb_copy_block_to_gpu(cands.data() + lo, slice.ptr, (hi - lo) * sizeof(Trajectory)));
+                check_status(kb_device_search_compact(&psi_phi_array.get_meta_data(), array, times, params,
+                                                      slice.as<const kb_trajectory>(), hi - lo, (int32_t)lo,
+                                                      records.as<kb_compact_result>(), max_results, search_flags, nullptr,
+                                                      &part_stats[part]));
+                check_status(kb_copy_block_between_gpus(gathered.as<kb_compact_result>() + (uint64_t)part * max_results, home,
+                                                        records.ptr, device, max_results * sizeof(kb_compact_result)));
+            } catch (const std::exception& e) {
+                errors[part] = e.what();
+            }
+        };
+        std::vector<std::thread> workers;
+        for (int part = 1; part < n_parts; ++part) workers.emplace_back(run_part, part);
+        run_part(0);
+        for (std::thread& w : workers) w.join();
+        check_status(kb_set_device(home));
+        for (const std::string& e : errors) detail::require(e.empty(), e);
+        check_status(kb_merge_compact(gathered.as<const kb_compact_result>(), n_parts, params,
+                                      all_cands.as<const kb_trajectory>(), n, merged, nullptr));
+        check_status(kb_device_synchronize());
+        last_stats = part_stats[0];
+        for (int part = 1; part < n_parts; ++part) {
+            last_stats.num_evals += part_stats[part].num_evals;
+            last_stats.algorithmic_bytes += part_stats[part].algorithmic_bytes;
+            last_stats.search_kernel_ms = std::max(last_stats.search_kernel_ms, part_stats[part].search_kernel_ms);
+            last_stats.num_search_launches += part_stats[part].num_search_launches;
+        }
+    }
+
     SearchParameters params;
     unsigned int height;
     unsigned int width;
@@ -435,6 +543,8 @@ protected:
     logging::Logger* rs_logger;
     kb_search_stats last_stats{};
     uint32_t search_flags = 0;
+    std::vector<int> search_devices;
+    std::vector<Replica> replicas;
 };
 
 }  // namespace search

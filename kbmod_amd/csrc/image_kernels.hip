@@ -17,6 +17,8 @@
 #include <cfloat>
 #include <cstring>
 #include <cmath>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "kb_common.h"
@@ -39,9 +41,13 @@ struct ConvArgs {
     const float* psf_tot;  // [T] sum of kernel t ; MODE 1: [T..2T) sums of the squared kernels
     int sq_base;           // MODE 1: offset of the squared kernels inside psf
     int W, H, T;
+    int t0;                // first epoch of this launch (blockIdx.z counts from it): the host-stack build
+                           // launches chunk by chunk behind the uploads
     int max_radius;
     int empty_is_nan;
     unsigned* minmax;  // MODE 1, encoded output: {psi_min, psi_max, phi_min, phi_max} as ordered keys, or null
+    const float* sep;  // separable build: per epoch the column factor u and the row factor w of the kernel
+                       // (K[j][i] = u[j] * w[i]), each padded to 2 * max_radius + 1 values: [T][2][dim_max]
 };
 
 // Order-preserving map float -> unsigned (finite values only are ever inserted).
@@ -54,6 +60,33 @@ static inline float key_float(unsigned k) {
     float f;
     std::memcpy(&f, &b, 4);
     return f;
+}
+
+// psi_phi_array.cpp:223-232: min/max over the finite values of every image, as ordered keys.
+__device__ __forceinline__ void reduce_value_range(unsigned* minmax, bool inside, float psi, float phi) {
+    unsigned kmin0 = 0xffffffffu, kmax0 = 0u, kmin1 = 0xffffffffu, kmax1 = 0u;
+    if (inside && __builtin_isfinite(psi)) kmin0 = kmax0 = float_key(psi);
+    if (inside && __builtin_isfinite(phi)) kmin1 = kmax1 = float_key(phi);
+    for (int o = 32; o > 0; o >>= 1) {
+        kmin0 = min(kmin0, (unsigned)__shfl_xor((int)kmin0, o));
+        kmax0 = max(kmax0, (unsigned)__shfl_xor((int)kmax0, o));
+        kmin1 = min(kmin1, (unsigned)__shfl_xor((int)kmin1, o));
+        kmax1 = max(kmax1, (unsigned)__shfl_xor((int)kmax1, o));
+    }
+    // One lane per wave, and only when the wave's extremum can still move the
+    // global value (plain pre-read: the atomic itself stays the arbiter).  Without
+    // the pre-read ~10^6 same-address atomics serialise into milliseconds.
+    if ((threadIdx.x & 63) == 0) {
+        volatile unsigned* mm = minmax;
+        if (kmin0 != 0xffffffffu) {
+            if (kmin0 < mm[0]) atomicMin(&minmax[0], kmin0);
+            if (kmax0 > mm[1]) atomicMax(&minmax[1], kmax0);
+        }
+        if (kmin1 != 0xffffffffu) {
+            if (kmin1 < mm[2]) atomicMin(&minmax[2], kmin1);
+            if (kmax1 > mm[3]) atomicMax(&minmax[3], kmax1);
+        }
+    }
 }
 
 // One masked correlation at LDS tile position (lx, ly) (tile pitch = pitch).
@@ -82,7 +115,7 @@ __device__ __forceinline__ float masked_correlate(const float* __restrict__ tile
 template <int MODE>
 __global__ __launch_bounds__(256) void kb_conv_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int t = blockIdx.z;
+    const int t = blockIdx.z + a.t0;
     const int dim = a.psf_dim[t];
     const int rad = (dim - 1) / 2;
     const int R = a.max_radius;
@@ -137,32 +170,110 @@ __global__ __launch_bounds__(256) void kb_conv_kernel(const ConvArgs a) {
         }
     }
 
-    if (MODE == 1 && a.minmax != nullptr) {
-        // psi_phi_array.cpp:223-232: min/max over finite values of every image.
-        unsigned kmin0 = 0xffffffffu, kmax0 = 0u, kmin1 = 0xffffffffu, kmax1 = 0u;
-        if (inside && __builtin_isfinite(psi)) kmin0 = kmax0 = float_key(psi);
-        if (inside && __builtin_isfinite(phi)) kmin1 = kmax1 = float_key(phi);
-        for (int o = 32; o > 0; o >>= 1) {
-            kmin0 = min(kmin0, (unsigned)__shfl_xor((int)kmin0, o));
-            kmax0 = max(kmax0, (unsigned)__shfl_xor((int)kmax0, o));
-            kmin1 = min(kmin1, (unsigned)__shfl_xor((int)kmin1, o));
-            kmax1 = max(kmax1, (unsigned)__shfl_xor((int)kmax1, o));
-        }
-        // One lane per wave, and only when the wave's extremum can still move the
-        // global value (plain pre-read: the atomic itself stays the arbiter).  Without
-        // the pre-read ~10^6 same-address atomics serialise into milliseconds.
-        if ((threadIdx.x & 63) == 0) {
-            volatile unsigned* mm = a.minmax;
-            if (kmin0 != 0xffffffffu) {
-                if (kmin0 < mm[0]) atomicMin(&a.minmax[0], kmin0);
-                if (kmax0 > mm[1]) atomicMax(&a.minmax[1], kmax0);
-            }
-            if (kmin1 != 0xffffffffu) {
-                if (kmin1 < mm[2]) atomicMin(&a.minmax[2], kmin1);
-                if (kmax1 > mm[3]) atomicMax(&a.minmax[3], kmax1);
-            }
-        }
+    if (MODE == 1 && a.minmax != nullptr) reduce_value_range(a.minmax, inside, psi, phi);
+}
+
+// Separable variant of the MODE 1 build for rank-1 kernels K[j][i] = u[j] * w[i] (every Gaussian PSF,
+// the reference default: core/psf.py:49-74).  The masked correlation (sum over valid taps of v * K) * sum(K)
+// / (sum over valid taps of K) splits into a row pass and a column pass over two planes per quantity,
+// the masked values m * v and the mask m itself: 4 * (2r + 1) multiply-adds per pixel and quantity
+// instead of 2 * (2r + 1)^2.  The summation order differs from the reference's row-major tap loop, so
+// the result agrees to rounding (tested to 1e-4 relative against the reference twin's vectors), not
+// bit for bit: opt-in (KB_BUILD_SEPARABLE), the 2-D kernel stays the default.
+__global__ __launch_bounds__(256) void kb_conv_sep_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = blockIdx.z + a.t0;
+    const int dim = a.psf_dim[t];
+    const int rad = (dim - 1) / 2;
+    const int R = a.max_radius;
+    const int DM = 2 * R + 1;
+    const int pitch = CONV_BX + 2 * R;
+    const int rows = CONV_BY + 2 * R;
+    // staged planes: masked psi0, its mask, masked phi0, its mask; then the four row-pass planes; then factors
+    float* in_pl = smem;                          // [4][rows][pitch]
+    float* row_pl = smem + 4 * pitch * rows;      // [4][rows][CONV_BX]
+    float* fac = row_pl + 4 * rows * CONV_BX;     // u, w, u^2, w^2: [4][DM]
+
+    const int x0 = blockIdx.x * CONV_BX, y0 = blockIdx.y * CONV_BY;
+    const size_t img = (size_t)t * a.W * a.H;
+    const float* sep_t = a.sep + (size_t)t * 2 * DM;
+    for (int e = threadIdx.x; e < 2 * DM; e += 256) {
+        const float f = sep_t[e];
+        fac[e] = f;
+        fac[2 * DM + e] = f * f;  // (u_j w_i)^2 = u_j^2 w_i^2: the squared kernel of phi (image_utils_cpp.cpp:110-120)
     }
+    for (int e = threadIdx.x; e < pitch * rows; e += 256) {
+        const int ly = e / pitch, lx = e - ly * pitch;
+        const int gx = x0 + lx - R, gy = y0 + ly - R;
+        float v0 = NAN, v1 = NAN;
+        if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) {
+            const size_t p = img + (size_t)gy * a.W + gx;
+            const float sci = a.in0[p];
+            const float var = a.in1[p];
+            const bool var_ok = __builtin_isfinite(var) && var != 0.0f;  // image_utils_cpp.cpp:142-149, :165-172
+            v0 = (var_ok && __builtin_isfinite(sci)) ? (sci / var) : NAN;
+            v1 = var_ok ? (float)__ddiv_rn(1.0, (double)var) : NAN;
+        }
+        const bool m0 = __builtin_isfinite(v0), m1 = __builtin_isfinite(v1);
+        in_pl[e] = m0 ? v0 : 0.0f;
+        in_pl[pitch * rows + e] = m0 ? 1.0f : 0.0f;
+        in_pl[2 * pitch * rows + e] = m1 ? v1 : 0.0f;
+        in_pl[3 * pitch * rows + e] = m1 ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    // row pass: every row of the tile and its halo, the tile's own columns
+    const float* w = fac + DM;
+    const float* w2 = fac + 3 * DM;
+    for (int e = threadIdx.x; e < rows * CONV_BX; e += 256) {
+        const int ly = e / CONV_BX, lx = e - ly * CONV_BX;
+        const float* r0 = in_pl + ly * pitch + lx + R;
+        float s0 = 0.0f, p0 = 0.0f, s1 = 0.0f, p1 = 0.0f;
+        for (int i = -rad; i <= rad; ++i) {
+            const float wi = w[i + rad], wi2 = w2[i + rad];
+            s0 += r0[i] * wi;
+            p0 += r0[pitch * rows + i] * wi;
+            s1 += r0[2 * pitch * rows + i] * wi2;
+            p1 += r0[3 * pitch * rows + i] * wi2;
+        }
+        row_pl[e] = s0;
+        row_pl[rows * CONV_BX + e] = p0;
+        row_pl[2 * rows * CONV_BX + e] = s1;
+        row_pl[3 * rows * CONV_BX + e] = p1;
+    }
+    __syncthreads();
+
+    const int lx = threadIdx.x % CONV_BX, ly = threadIdx.x / CONV_BX;
+    const int gx = x0 + lx, gy = y0 + ly;
+    const bool inside = gx < a.W && gy < a.H;
+    float psi = NAN, phi = NAN;
+    if (inside) {
+        const float* u = fac;
+        const float* u2 = fac + 2 * DM;
+        const float* c0 = row_pl + (ly + R) * CONV_BX + lx;
+        float s0 = 0.0f, p0 = 0.0f, s1 = 0.0f, p1 = 0.0f;
+        for (int j = -rad; j <= rad; ++j) {
+            const float uj = u[j + rad], uj2 = u2[j + rad];
+            s0 += c0[j * CONV_BX] * uj;
+            p0 += c0[rows * CONV_BX + j * CONV_BX] * uj;
+            s1 += c0[2 * rows * CONV_BX + j * CONV_BX] * uj2;
+            p1 += c0[3 * rows * CONV_BX + j * CONV_BX] * uj2;
+        }
+        const int ce = (ly + R) * pitch + lx + R;
+        const bool c_psi = in_pl[pitch * rows + ce] != 0.0f, c_phi = in_pl[3 * pitch * rows + ce] != 0.0f;
+        const float empty = a.empty_is_nan ? NAN : 0.0f;
+        psi = (p0 == 0.0f) ? empty : (s0 * a.psf_tot[t]) / p0;
+        phi = (p1 == 0.0f) ? empty : (s1 * a.psf_tot[a.T + t]) / p1;
+        if (!c_psi || !c_phi) {  // an invalid centre passes through unchanged (image_utils_cpp.cpp:41-44)
+            const size_t p = img + (size_t)gy * a.W + gx;
+            const float sci = a.in0[p];
+            const float var = a.in1[p];
+            const bool var_ok = __builtin_isfinite(var) && var != 0.0f;
+            if (!c_psi) psi = (var_ok && __builtin_isfinite(sci)) ? (sci / var) : NAN;
+            if (!c_phi) phi = var_ok ? (float)__ddiv_rn(1.0, (double)var) : NAN;
+        }
+        reinterpret_cast<float2*>(a.out_pairs)[img + (size_t)gy * a.W + gx] = make_float2(psi, phi);
+    }
+    if (a.minmax != nullptr) reduce_value_range(a.minmax, inside, psi, phi);
 }
 
 // psi_phi_array_ds.h:40-43 + psi_phi_array.cpp:284-285 (truncating cast).
@@ -267,12 +378,50 @@ static size_t conv_lds_bytes(int max_radius, bool two_tiles) {
 
 extern "C" {
 
-int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, const float* psf_host,
-                                 const int32_t* psf_dims, int32_t num_times, int32_t height, int32_t width,
-                                 int32_t num_bytes, kb_psi_phi_meta* meta_out, void** psi_phi_dev_out,
-                                 void* stream_v) {
-    using namespace kb;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+}  // extern "C"
+
+namespace kb {
+
+// Rank-1 factors of kernel t: K[j][i] = u[j] * w[i] to 1e-6 of the largest tap, or false.
+static bool factor_kernel(const float* k, int dim, float* u, float* w) {
+    int j0 = 0, i0 = 0;
+    double big = 0.0;
+    for (int j = 0; j < dim; ++j) {
+        for (int i = 0; i < dim; ++i) {
+            if (std::fabs((double)k[j * dim + i]) > big) {
+                big = std::fabs((double)k[j * dim + i]);
+                j0 = j;
+                i0 = i;
+            }
+        }
+    }
+    if (!(big > 0.0)) return false;
+    const double pivot = k[j0 * dim + i0];
+    for (int j = 0; j < dim; ++j) u[j] = k[j * dim + i0];
+    for (int i = 0; i < dim; ++i) w[i] = (float)((double)k[j0 * dim + i] / pivot);
+    for (int j = 0; j < dim; ++j) {
+        for (int i = 0; i < dim; ++i) {
+            if (std::fabs((double)u[j] * (double)w[i] - (double)k[j * dim + i]) > 1e-6 * big) return false;
+        }
+    }
+    return true;
+}
+
+// Pinned staging of the host-stack build: two buffers, kept between calls.
+struct PinnedStage {
+    void* p[2] = {nullptr, nullptr};
+    size_t bytes = 0;
+};
+static PinnedStage g_stage;
+static std::mutex g_stage_mutex;
+
+// The psi/phi build.  The image stacks are either resident (sci_dev / var_dev) or contiguous host
+// stacks (sci_host / var_host: [T][H][W]) that are uploaded chunk by chunk through pinned staging
+// buffers on a copy stream while the correlation kernel of the chunk before runs.
+static int build_psi_phi(const float* sci_dev, const float* var_dev, const float* sci_host, const float* var_host,
+                         const float* psf_host, const int32_t* psf_dims, int32_t num_times, int32_t height,
+                         int32_t width, int32_t num_bytes, uint32_t build_flags, kb_psi_phi_meta* meta_out,
+                         void** psi_phi_dev_out, hipStream_t stream) {
     if (meta_out == nullptr || psi_phi_dev_out == nullptr) return fail("build_psi_phi: null output pointer");
     *psi_phi_dev_out = nullptr;
     if (num_times <= 0) return fail("Trying to fill PsiPhi from empty vectors.");
@@ -281,23 +430,41 @@ int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, con
         return fail("Invalid setting of num_bytes. Must be (-1 [use default], 1, 2, or 4). Got " +
                     std::to_string(num_bytes));
     }
-    if (sci_dev == nullptr || var_dev == nullptr || psf_host == nullptr || psf_dims == nullptr) {
+    const bool from_host = sci_host != nullptr;
+    if ((!from_host && (sci_dev == nullptr || var_dev == nullptr)) || (from_host && var_host == nullptr) ||
+        psf_host == nullptr || psf_dims == nullptr) {
         return fail("build_psi_phi: null input pointer");
     }
     if (kb_device_count() == 0) return fail("GPU is not available for the psi/phi build.");
+    (void)hipGetLastError();
 
     fill_meta(meta_out, num_bytes, (uint64_t)num_times, (uint64_t)height, (uint64_t)width);
     const bool encoded = meta_out->num_bytes != 4;
-    const size_t n_pix = (size_t)num_times * height * width;
+    const size_t img = (size_t)height * width;
+    const size_t n_pix = (size_t)num_times * img;
 
     std::vector<float> packed, totals;
     std::vector<int> offs;
     int max_radius = 0, sq_base = 0;
     if (pack_psfs(psf_host, psf_dims, num_times, true, &packed, &offs, &totals, &max_radius, &sq_base)) return 1;
-    const size_t lds = conv_lds_bytes(max_radius, true);
+
+    // separable build: every kernel must factor
+    const int DM = 2 * max_radius + 1;
+    std::vector<float> factors;
+    bool separable = (build_flags & KB_BUILD_SEPARABLE) != 0;
+    if (separable) {
+        factors.assign((size_t)num_times * 2 * DM, 0.0f);
+        for (int t = 0; t < num_times && separable; ++t) {
+            separable = factor_kernel(psf_host + offs[t], psf_dims[t], &factors[(size_t)t * 2 * DM],
+                                      &factors[(size_t)t * 2 * DM + DM]);
+        }
+    }
+    const int pitch = CONV_BX + 2 * max_radius, rows = CONV_BY + 2 * max_radius;
+    const size_t lds = separable ? sizeof(float) * ((size_t)4 * pitch * rows + (size_t)4 * rows * CONV_BX + 4 * DM)
+                                 : conv_lds_bytes(max_radius, true);
     if (lds > 160 * 1024) return fail("PSF radius too large for the LDS-tiled convolution.");
 
-    DeviceBuffer d_psf, d_off, d_dim, d_tot, d_stage, d_minmax;
+    DeviceBuffer d_psf, d_off, d_dim, d_tot, d_stage, d_minmax, d_sep, d_sci, d_var;
     KB_HIP_TRY(hipMalloc(&d_psf.p, packed.size() * sizeof(float)));
     KB_HIP_TRY(hipMalloc(&d_off.p, offs.size() * sizeof(int)));
     KB_HIP_TRY(hipMalloc(&d_dim.p, (size_t)num_times * sizeof(int)));
@@ -306,6 +473,10 @@ int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, con
     KB_HIP_TRY(hipMemcpyAsync(d_off.p, offs.data(), offs.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     KB_HIP_TRY(hipMemcpyAsync(d_dim.p, psf_dims, (size_t)num_times * sizeof(int), hipMemcpyHostToDevice, stream));
     KB_HIP_TRY(hipMemcpyAsync(d_tot.p, totals.data(), totals.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    if (separable) {
+        KB_HIP_TRY(hipMalloc(&d_sep.p, factors.size() * sizeof(float)));
+        KB_HIP_TRY(hipMemcpyAsync(d_sep.p, factors.data(), factors.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    }
 
     void* final_arr = nullptr;
     KB_HIP_TRY(hipMalloc(&final_arr, meta_out->total_array_size));
@@ -319,6 +490,12 @@ int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, con
         KB_HIP_TRY(hipMalloc(&d_minmax.p, 4 * sizeof(unsigned)));
         const unsigned init[4] = {0xffffffffu, 0u, 0xffffffffu, 0u};
         KB_HIP_TRY(hipMemcpyAsync(d_minmax.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    }
+    if (from_host) {
+        KB_HIP_TRY(hipMalloc(&d_sci.p, n_pix * sizeof(float)));
+        KB_HIP_TRY(hipMalloc(&d_var.p, n_pix * sizeof(float)));
+        sci_dev = reinterpret_cast<const float*>(d_sci.p);
+        var_dev = reinterpret_cast<const float*>(d_var.p);
     }
 
     ConvArgs a;
@@ -334,17 +511,90 @@ int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, con
     a.W = width;
     a.H = height;
     a.T = num_times;
+    a.t0 = 0;
     a.max_radius = max_radius;
-    a.empty_is_nan = 1;  // the array is the CPU StackSearch's array (image_utils_cpp.cpp:60-61)
+    // The array is the CPU StackSearch's array: an empty PSF footprint gives NaN (image_utils_cpp.cpp:60-61).
+    // KB_BUILD_EMPTY_IS_ZERO reproduces the reference's own device builder instead (0.0, image_kernels.cu:61).
+    a.empty_is_nan = (build_flags & KB_BUILD_EMPTY_IS_ZERO) ? 0 : 1;
     a.minmax = reinterpret_cast<unsigned*>(d_minmax.p);
+    a.sep = reinterpret_cast<const float*>(d_sep.p);
 
     if (lds > 64 * 1024) {
-        KB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_conv_kernel<1>),
+        KB_HIP_TRY(hipFuncSetAttribute(separable ? reinterpret_cast<const void*>(&kb_conv_sep_kernel)
+                                                 : reinterpret_cast<const void*>(&kb_conv_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    const dim3 grid((width + CONV_BX - 1) / CONV_BX, (height + CONV_BY - 1) / CONV_BY, num_times);
-    hipLaunchKernelGGL((kb_conv_kernel<1>), grid, dim3(256), lds, stream, a);
-    KB_HIP_TRY(hipGetLastError());
+    auto launch_epochs = [&](int t0, int nt, hipStream_t s) {
+        ConvArgs c = a;
+        c.t0 = t0;
+        const dim3 grid((width + CONV_BX - 1) / CONV_BX, (height + CONV_BY - 1) / CONV_BY, nt);
+        if (separable) {
+            hipLaunchKernelGGL(kb_conv_sep_kernel, grid, dim3(256), lds, s, c);
+        } else {
+            hipLaunchKernelGGL((kb_conv_kernel<1>), grid, dim3(256), lds, s, c);
+        }
+    };
+
+    if (!from_host) {
+        launch_epochs(0, num_times, stream);
+        KB_HIP_TRY(hipGetLastError());
+    } else {
+        // chunks of whole epochs, at most ~16 MiB per stack and chunk; chunk c is copied into the pinned
+        // buffer c % 2 by this thread, sent by the copy engine, and correlated behind its arrival
+        std::lock_guard<std::mutex> lock(g_stage_mutex);
+        const int chunk_epochs = (int)std::max<size_t>(1, std::min<size_t>((size_t)num_times, (16u << 20) / (img * sizeof(float))));
+        const size_t chunk_bytes = (size_t)chunk_epochs * img * sizeof(float);
+        if (g_stage.bytes < 2 * chunk_bytes) {
+            for (void*& p : g_stage.p) {
+                if (p != nullptr) (void)hipHostFree(p);
+                p = nullptr;
+            }
+            g_stage.bytes = 0;
+            KB_HIP_TRY(hipHostMalloc(&g_stage.p[0], 2 * chunk_bytes, hipHostMallocDefault));
+            KB_HIP_TRY(hipHostMalloc(&g_stage.p[1], 2 * chunk_bytes, hipHostMallocDefault));
+            g_stage.bytes = 2 * chunk_bytes;
+        }
+        hipStream_t copy_stream = nullptr;
+        KB_HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        hipEvent_t arrived[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+        for (int i = 0; i < 2; ++i) {
+            (void)hipEventCreateWithFlags(&arrived[i], hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&consumed[i], hipEventDisableTiming);
+        }
+        int rc = 0;
+        int c = 0;
+        for (int t0 = 0; t0 < num_times && rc == 0; t0 += chunk_epochs, ++c) {
+            const int nt = std::min(chunk_epochs, num_times - t0);
+            const size_t nb = (size_t)nt * img * sizeof(float);
+            const int b = c & 1;
+            if (c >= 2 && hipEventSynchronize(consumed[b]) != hipSuccess) rc = 1;  // the copy two chunks ago has left the buffer
+            char* host_buf = reinterpret_cast<char*>(g_stage.p[b]);
+            std::memcpy(host_buf, sci_host + (size_t)t0 * img, nb);
+            std::memcpy(host_buf + chunk_bytes, var_host + (size_t)t0 * img, nb);
+            if (hipMemcpyAsync(reinterpret_cast<float*>(d_sci.p) + (size_t)t0 * img, host_buf, nb, hipMemcpyHostToDevice,
+                               copy_stream) != hipSuccess ||
+                hipMemcpyAsync(reinterpret_cast<float*>(d_var.p) + (size_t)t0 * img, host_buf + chunk_bytes, nb,
+                               hipMemcpyHostToDevice, copy_stream) != hipSuccess) {
+                rc = 1;
+                break;
+            }
+            (void)hipEventRecord(consumed[b], copy_stream);
+            (void)hipEventRecord(arrived[b], copy_stream);
+            (void)hipStreamWaitEvent(stream, arrived[b], 0);
+            launch_epochs(t0, nt, stream);
+        }
+        const hipError_t launch_err = hipGetLastError();
+        (void)hipStreamSynchronize(copy_stream);
+        for (int i = 0; i < 2; ++i) {
+            (void)hipEventDestroy(arrived[i]);
+            (void)hipEventDestroy(consumed[i]);
+        }
+        (void)hipStreamDestroy(copy_stream);
+        if (rc != 0 || launch_err != hipSuccess) {
+            (void)hipStreamSynchronize(stream);
+            return fail(std::string("build_psi_phi: upload failed: ") + hipGetErrorString(launch_err));
+        }
+    }
 
     if (encoded) {
         unsigned keys[4];
@@ -390,6 +640,35 @@ int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, con
     final_guard.p = nullptr;  // ownership passes to the caller
     *psi_phi_dev_out = final_arr;
     return 0;
+}
+
+}  // namespace kb
+
+extern "C" {
+
+int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, const float* psf_host,
+                                 const int32_t* psf_dims, int32_t num_times, int32_t height, int32_t width,
+                                 int32_t num_bytes, kb_psi_phi_meta* meta_out, void** psi_phi_dev_out,
+                                 void* stream_v) {
+    return kb::build_psi_phi(sci_dev, var_dev, nullptr, nullptr, psf_host, psf_dims, num_times, height, width, num_bytes,
+                             0, meta_out, psi_phi_dev_out, reinterpret_cast<hipStream_t>(stream_v));
+}
+
+int kb_build_psi_phi_from_device_ex(const float* sci_dev, const float* var_dev, const float* psf_host,
+                                    const int32_t* psf_dims, int32_t num_times, int32_t height, int32_t width,
+                                    int32_t num_bytes, uint32_t build_flags, kb_psi_phi_meta* meta_out,
+                                    void** psi_phi_dev_out, void* stream_v) {
+    return kb::build_psi_phi(sci_dev, var_dev, nullptr, nullptr, psf_host, psf_dims, num_times, height, width, num_bytes,
+                             build_flags, meta_out, psi_phi_dev_out, reinterpret_cast<hipStream_t>(stream_v));
+}
+
+int kb_build_psi_phi_from_host_stack(const float* sci_host, const float* var_host, const float* psf_host,
+                                     const int32_t* psf_dims, int32_t num_times, int32_t height, int32_t width,
+                                     int32_t num_bytes, uint32_t build_flags, kb_psi_phi_meta* meta_out,
+                                     void** psi_phi_dev_out) {
+    if (sci_host == nullptr || var_host == nullptr) return kb::fail("build_psi_phi: null input pointer");
+    return kb::build_psi_phi(nullptr, nullptr, sci_host, var_host, psf_host, psf_dims, num_times, height, width, num_bytes,
+                             build_flags, meta_out, psi_phi_dev_out, nullptr);
 }
 
 int kb_build_psi_phi_from_host(const float* const* sci_host, const float* const* var_host,
@@ -458,9 +737,11 @@ int kb_device_convolve(const float* src_host, float* dst_host, int width, int he
     a.W = width;
     a.H = height;
     a.T = 1;
+    a.t0 = 0;
     a.max_radius = max_radius;
     a.empty_is_nan = empty_is_nan;
     a.minmax = nullptr;
+    a.sep = nullptr;
     if (lds > 64 * 1024) {
         KB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_conv_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

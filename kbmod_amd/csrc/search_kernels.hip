@@ -375,16 +375,24 @@ struct Workspace {
     size_t bytes = 0;
     int device = -1;
 };
-static std::mutex g_ws_mutex;
-static Workspace g_ws[6];  // 0: shift table + chunk info, 1: literal sigma-G scratch, 2: padded array copy (LDS kernel),
+// One set of workspaces (and one lock) per device: searches on different devices run side by side from
+// different host threads (StackSearch's fan-out), searches on one device one after the other.
+constexpr int MAX_DEVICES = 64;
+static std::mutex g_ws_mutex[MAX_DEVICES];
+static Workspace g_ws_all[MAX_DEVICES][6];  // 0: shift table + chunk info, 1: literal sigma-G scratch, 2: padded array copy (LDS kernel),
                             // 3: sigma-G work items + clipped values, 4: second per-pixel list buffer (sigma-G batches),
                             // 5: cold block of the kernel arguments
 
-static int ensure_workspace(int which, size_t bytes, void** out) {
+static int current_device_slot() {
     int dev = 0;
-    KB_HIP_TRY(hipGetDevice(&dev));
-    Workspace& w = g_ws[which];
-    if (w.ptr != nullptr && (w.device != dev || w.bytes < bytes)) {
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return (dev >= 0 && dev < MAX_DEVICES) ? dev : 0;
+}
+
+static int ensure_workspace(int which, size_t bytes, void** out) {
+    const int dev = current_device_slot();
+    Workspace& w = g_ws_all[dev][which];
+    if (w.ptr != nullptr && w.bytes < bytes) {
         (void)hipFree(w.ptr);
         w.ptr = nullptr;
         w.bytes = 0;
@@ -576,7 +584,8 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
 
     EventTimer table_timer(stream, stats_out != nullptr);
     EventTimer search_timer(stream, stats_out != nullptr);
-    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    std::lock_guard<std::mutex> lock(g_ws_mutex[current_device_slot()]);
+    Workspace* g_ws = g_ws_all[current_device_slot()];
 
     float table_ms = 0.0f, search_ms = 0.0f;
     // Kernel choice.  kb_search_lds (LDS-DMA staging from a padded copy) is the default for K <= 32;
@@ -855,17 +864,19 @@ int kb_device_search_compact(const kb_psi_phi_meta* meta, const void* psi_phi_de
 
 int kb_release_workspaces(void) {
     using namespace kb;
-    std::lock_guard<std::mutex> lock(g_ws_mutex);
-    for (Workspace& w : g_ws) {
-        if (w.ptr != nullptr) {
-            int prev = 0;
-            KB_HIP_TRY(hipGetDevice(&prev));
-            KB_HIP_TRY(hipSetDevice(w.device));
-            KB_HIP_TRY(hipFree(w.ptr));
-            KB_HIP_TRY(hipSetDevice(prev));
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    for (int dev = 0; dev < MAX_DEVICES; ++dev) {
+        std::lock_guard<std::mutex> lock(g_ws_mutex[dev]);
+        for (Workspace& w : g_ws_all[dev]) {
+            if (w.ptr != nullptr) {
+                KB_HIP_TRY(hipSetDevice(w.device));
+                KB_HIP_TRY(hipFree(w.ptr));
+            }
+            w = Workspace();
         }
-        w = Workspace();
     }
+    if (have_prev) (void)hipSetDevice(prev);
     return 0;
 }
 

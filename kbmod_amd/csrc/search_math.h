@@ -12,7 +12,9 @@
 #ifndef KB_SEARCH_MATH_H_
 #define KB_SEARCH_MATH_H_
 
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#endif
 
 #include <cfloat>
 #include <cmath>
@@ -24,7 +26,12 @@
 
 namespace kb {
 
+// The header also serves the host module (g++): there the functions are plain inline host functions.
+#if defined(__HIPCC__)
 #define KB_HD __host__ __device__ __forceinline__
+#else
+#define KB_HD inline
+#endif
 
 // (int)floor((double)pos0 + (double)vel0 * time + 0.5) with every operation
 // rounded separately.  Returns false when the value does not fit an int (the
