@@ -225,6 +225,12 @@ int kb_coadd_stamps(const float* sci_dev, const float* var_dev, int32_t num_time
                     const int32_t* x_dev, const int32_t* y_dev, const uint8_t* include_dev, uint64_t n, int32_t radius,
                     int32_t coadd_type, float* out_dev, void* stream);
 
+/* All stamps of result trajectories (append_all_stamps, src/kbmod/filters/stamp_filters.py:171-211, a loop of
+ * extract_stamp_stack over the results): out_dev is [n][T][2r+1][2r+1] float32, NaN outside the image.
+ * Synchronises the stream. */
+int kb_extract_stamps(const float* sci_dev, int32_t num_times, int32_t height, int32_t width, const int32_t* x_dev,
+                      const int32_t* y_dev, uint64_t n, int32_t radius, float* out_dev, void* stream);
+
 /* ---- multi-GPU: merge of per-rank top-K lists (new; the reference is single-GPU).
  * lists_dev: [n_lists][n_pixels][K] as gathered by one RCCL all_gather of each
  * rank's kb_device_search_filter output over its candidate slice; out_dev:

@@ -365,6 +365,7 @@ PYBIND11_MODULE(search, m) {
             .def_property_readonly("height", &DeviceImageStack::height)
             .def_property_readonly("width", &DeviceImageStack::width)
             .def_property_readonly("has_variance", &DeviceImageStack::has_variance)
+            .def("all_stamps", &DeviceImageStack::all_stamps, py::arg("xvals"), py::arg("yvals"), py::arg("radius"))
             .def("coadds", &DeviceImageStack::coadds, py::arg("xvals"), py::arg("yvals"), py::arg("to_include") = py::none(),
                  py::arg("radius") = 10, py::arg("coadd_types") = std::vector<std::string>{"mean"});
 

@@ -19,6 +19,47 @@
 namespace search {
 namespace py = pybind11;
 
+// A block of HBM owned by a scope or an object (freed when it goes away, also on the error paths).
+class HbmBlock {
+public:
+    HbmBlock() = default;
+    HbmBlock(const void* host, uint64_t bytes) {
+        check(kb_allocate_gpu_block(bytes == 0 ? 4 : bytes, &ptr_));
+        if (host != nullptr && bytes != 0 && kb_copy_block_to_gpu(host, ptr_, bytes) != 0) {
+            const std::string what = kb_last_error();
+            reset();
+            throw std::runtime_error(what);
+        }
+    }
+    HbmBlock(const HbmBlock&) = delete;
+    HbmBlock& operator=(const HbmBlock&) = delete;
+    HbmBlock(HbmBlock&& o) noexcept : ptr_(o.ptr_) { o.ptr_ = nullptr; }
+    HbmBlock& operator=(HbmBlock&& o) noexcept {
+        if (this != &o) {
+            reset();
+            ptr_ = o.ptr_;
+            o.ptr_ = nullptr;
+        }
+        return *this;
+    }
+    ~HbmBlock() { reset(); }
+    void reset() {
+        if (ptr_ != nullptr) (void)kb_free_gpu_block(ptr_);
+        ptr_ = nullptr;
+    }
+    template <typename T>
+    T* as() const {
+        return reinterpret_cast<T*>(ptr_);
+    }
+    explicit operator bool() const { return ptr_ != nullptr; }
+    static void check(int rc) {
+        if (rc != 0) throw std::runtime_error(kb_last_error());
+    }
+
+private:
+    void* ptr_ = nullptr;
+};
+
 class DeviceImageStack {
 public:
     typedef py::array_t<float, py::array::c_style | py::array::forcecast> FloatArray;
@@ -31,24 +72,39 @@ public:
         T_ = (int)sci.shape(0);
         H_ = (int)sci.shape(1);
         W_ = (int)sci.shape(2);
-        sci_ = upload(sci.data(), (uint64_t)sci.size() * sizeof(float));
+        sci_ = HbmBlock(sci.data(), (uint64_t)sci.size() * sizeof(float));
         if (!var.is_none()) {
             FloatArray v = var.cast<FloatArray>();
             if (v.ndim() != 3 || v.shape(0) != sci.shape(0) || v.shape(1) != sci.shape(1) || v.shape(2) != sci.shape(2)) {
-                release();
                 throw std::runtime_error("science and variance stacks differ in shape");
             }
-            var_ = upload(v.data(), (uint64_t)v.size() * sizeof(float));
+            var_ = HbmBlock(v.data(), (uint64_t)v.size() * sizeof(float));  // sci_ is released if this throws
         }
     }
-    DeviceImageStack(const DeviceImageStack&) = delete;
-    DeviceImageStack& operator=(const DeviceImageStack&) = delete;
-    ~DeviceImageStack() { release(); }
 
     int num_times() const { return T_; }
     int height() const { return H_; }
     int width() const { return W_; }
-    bool has_variance() const { return var_ != nullptr; }
+    bool has_variance() const { return (bool)var_; }
+
+    // xvals / yvals: N x T integer stamp centres; returns N x T x (2r+1) x (2r+1) float32 (append_all_stamps)
+    py::array_t<float> all_stamps(IntArray xvals, IntArray yvals, int radius) {
+        if (radius < 1) throw std::invalid_argument("Invalid stamp radius: " + std::to_string(radius));
+        if (xvals.ndim() != 2 || yvals.ndim() != 2 || xvals.shape(0) != yvals.shape(0) || xvals.shape(1) != T_ ||
+            yvals.shape(1) != T_) {
+            throw std::invalid_argument("X and Y values must have the same length as the number of times.");
+        }
+        const uint64_t n = (uint64_t)xvals.shape(0);
+        const int S = 2 * radius + 1;
+        py::array_t<float> out({(py::ssize_t)n, (py::ssize_t)T_, (py::ssize_t)S, (py::ssize_t)S});
+        if (n == 0 || T_ == 0) return out;
+        const uint64_t nt = n * (uint64_t)T_, out_bytes = nt * (uint64_t)S * S * sizeof(float);
+        HbmBlock x_dev(xvals.data(), nt * sizeof(int32_t)), y_dev(yvals.data(), nt * sizeof(int32_t)), out_dev(nullptr, out_bytes);
+        HbmBlock::check(kb_extract_stamps(sci_.as<const float>(), T_, H_, W_, x_dev.as<const int32_t>(), y_dev.as<const int32_t>(),
+                                          n, radius, out_dev.as<float>(), nullptr));
+        HbmBlock::check(kb_copy_block_to_cpu(out.mutable_data(), out_dev.as<void>(), out_bytes));
+        return out;
+    }
 
     // xvals / yvals: N x T integer stamp centres; to_include: N x T bool (None = every epoch);
     // returns {type: N x (2r+1) x (2r+1) float32}
@@ -70,7 +126,7 @@ public:
             else if (c == "median") types.push_back(KB_COADD_MEDIAN);
             else if (c == "weighted") types.push_back(KB_COADD_WEIGHTED);
             else throw std::invalid_argument("Unknown coadd type " + c);
-            if (c == "weighted" && var_ == nullptr) throw std::runtime_error("the weighted coadd needs the variance stack");
+            if (c == "weighted" && !var_) throw std::runtime_error("the weighted coadd needs the variance stack");
         }
         for (const std::string& c : coadd_types) {
             out[c] = py::array_t<float>({(py::ssize_t)n, (py::ssize_t)S, (py::ssize_t)S});
@@ -83,52 +139,21 @@ public:
                 throw std::invalid_argument("Time mask must have the same length as the number of times.");
             }
         }
-        void *x_dev = nullptr, *y_dev = nullptr, *inc_dev = nullptr, *out_dev = nullptr;
-        auto cleanup = [&]() {
-            if (x_dev) kb_free_gpu_block(x_dev);
-            if (y_dev) kb_free_gpu_block(y_dev);
-            if (inc_dev) kb_free_gpu_block(inc_dev);
-            if (out_dev) kb_free_gpu_block(out_dev);
-        };
-        try {
-            x_dev = upload(xvals.data(), nt * sizeof(int32_t));
-            y_dev = upload(yvals.data(), nt * sizeof(int32_t));
-            if (!to_include.is_none()) inc_dev = upload(inc.data(), nt);
-            const uint64_t out_bytes = n * (uint64_t)S * S * sizeof(float);
-            check(kb_allocate_gpu_block(out_bytes, &out_dev));
-            for (size_t k = 0; k < types.size(); ++k) {
-                check(kb_coadd_stamps(sci_, var_, T_, H_, W_, (const int32_t*)x_dev, (const int32_t*)y_dev,
-                                      (const uint8_t*)inc_dev, n, radius, types[k], (float*)out_dev, nullptr));
-                check(kb_copy_block_to_cpu(out[coadd_types[k]].mutable_data(), out_dev, out_bytes));
-            }
-        } catch (...) {
-            cleanup();
-            throw;
+        const uint64_t out_bytes = n * (uint64_t)S * S * sizeof(float);
+        HbmBlock x_dev(xvals.data(), nt * sizeof(int32_t)), y_dev(yvals.data(), nt * sizeof(int32_t)), out_dev(nullptr, out_bytes);
+        HbmBlock inc_dev;
+        if (!to_include.is_none()) inc_dev = HbmBlock(inc.data(), nt);
+        for (size_t k = 0; k < types.size(); ++k) {
+            HbmBlock::check(kb_coadd_stamps(sci_.as<const float>(), var_.as<const float>(), T_, H_, W_, x_dev.as<const int32_t>(),
+                                            y_dev.as<const int32_t>(), inc_dev.as<const uint8_t>(), n, radius, types[k],
+                                            out_dev.as<float>(), nullptr));
+            HbmBlock::check(kb_copy_block_to_cpu(out[coadd_types[k]].mutable_data(), out_dev.as<void>(), out_bytes));
         }
-        cleanup();
         return out;
     }
 
 private:
-    static void check(int rc) {
-        if (rc != 0) throw std::runtime_error(kb_last_error());
-    }
-    static float* upload(const void* host, uint64_t bytes) {
-        void* dev = nullptr;
-        check(kb_allocate_gpu_block(bytes == 0 ? 4 : bytes, &dev));
-        if (bytes != 0 && kb_copy_block_to_gpu(host, dev, bytes) != 0) {
-            kb_free_gpu_block(dev);
-            throw std::runtime_error(kb_last_error());
-        }
-        return (float*)dev;
-    }
-    void release() {
-        if (sci_) kb_free_gpu_block(sci_);
-        if (var_) kb_free_gpu_block(var_);
-        sci_ = var_ = nullptr;
-    }
-    float* sci_ = nullptr;
-    float* var_ = nullptr;
+    HbmBlock sci_, var_;
     int T_ = 0, H_ = 0, W_ = 0;
 };
 

@@ -187,6 +187,23 @@ __global__ __launch_bounds__(256) void kb_coadd_median64_kernel(const CoaddArgs 
     }
 }
 
+// All stamps of every trajectory (append_all_stamps, stamp_filters.py:171-211): out[n][t] is the
+// (2r+1)^2 stamp of epoch t around (x[n][t], y[n][t]), NaN outside the image.  One workgroup per
+// trajectory; consecutive threads take consecutive stamp pixels (rows of 2r+1 contiguous image pixels).
+__global__ __launch_bounds__(256) void kb_extract_stamps_kernel(const CoaddArgs a) {
+    const uint64_t n = a.n0 + blockIdx.x;
+    const int S2 = a.S * a.S;
+    const int32_t* __restrict__ xs = a.x + n * (uint64_t)a.T;
+    const int32_t* __restrict__ ys = a.y + n * (uint64_t)a.T;
+    const size_t image = (size_t)a.H * a.W;
+    float* __restrict__ out = a.out + n * (uint64_t)a.T * S2;
+    for (int e = threadIdx.x; e < a.T * S2; e += blockDim.x) {
+        const int t = e / S2, pix = e - t * S2;
+        const int j = pix / a.S, i = pix - j * a.S;
+        out[e] = stamp_pixel(a.sci + t * image, a.H, a.W, xs[t], ys[t], a.radius, j, i);
+    }
+}
+
 static std::mutex g_scratch_mutex;
 static float* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
@@ -273,6 +290,36 @@ extern "C" int kb_coadd_stamps(const float* sci_dev, const float* var_dev, int32
                 hipLaunchKernelGGL((kb_coadd_kernel<KB_COADD_WEIGHTED>), dim3(blocks), dim3(threads), 0, stream, a);
                 break;
         }
+        KB_HIP_TRY(hipGetLastError());
+    }
+    KB_HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+extern "C" int kb_extract_stamps(const float* sci_dev, int32_t num_times, int32_t height, int32_t width, const int32_t* x_dev,
+                                 const int32_t* y_dev, uint64_t n, int32_t radius, float* out_dev, void* stream_v) {
+    using namespace kb;
+    if (radius < 1) return fail("Invalid stamp radius: " + std::to_string(radius));  // stamp_filters.py:188-189
+    if (n == 0 || num_times == 0) return 0;
+    if (sci_dev == nullptr || x_dev == nullptr || y_dev == nullptr || out_dev == nullptr) {
+        return fail("extract_stamps: null pointer");
+    }
+    if (num_times < 0 || height <= 0 || width <= 0) return fail("extract_stamps: invalid image stack shape");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    CoaddArgs a{};
+    a.sci = sci_dev;
+    a.x = x_dev;
+    a.y = y_dev;
+    a.out = out_dev;
+    a.T = num_times;
+    a.H = height;
+    a.W = width;
+    a.radius = radius;
+    a.S = 2 * radius + 1;
+    const uint64_t batch = 1u << 20;
+    for (uint64_t n0 = 0; n0 < n; n0 += batch) {
+        a.n0 = n0;
+        hipLaunchKernelGGL(kb_extract_stamps_kernel, dim3((unsigned)std::min<uint64_t>(batch, n - n0)), dim3(256), 0, stream, a);
         KB_HIP_TRY(hipGetLastError());
     }
     KB_HIP_TRY(hipStreamSynchronize(stream));

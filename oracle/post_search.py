@@ -287,6 +287,60 @@ def coadds_for_trajectories(sci, var, xvals, yvals, obs_valid, radius, coadd_typ
     return out
 
 
+def mjd_to_day(mjd):
+    """util_functions.py:52-65 (astropy Time(mjd, format="mjd").strftime("%Y-%m-%d"), UTC): the calendar date
+    floor(mjd) days after 1858-11-17.  Known answer: mjd 60000 -> 2023-02-25."""
+    import datetime
+
+    return (datetime.date(1858, 11, 17) + datetime.timedelta(days=int(np.floor(mjd)))).isoformat()
+
+
+def append_coadds_columns(sci, var, times_mjd, xvals, yvals, obs_valid, radius, coadd_types, nightly):
+    """The whole loop of append_coadds (stamp_filters.py:72-168) on plain arrays, nightly columns included:
+    {column name: float32 [N][S][S]}."""
+    import warnings
+
+    s = 2 * radius + 1
+    n = len(xvals)
+    day_strs = np.array([f"_{mjd_to_day(t)}" for t in times_mjd])
+    days_to_use = np.unique(day_strs) if nightly else []
+    out = {f"coadd_{c}": np.zeros((n, s, s), dtype=np.float32) for c in coadd_types}
+    for day in days_to_use:
+        for c in coadd_types:
+            out[f"coadd_{c}{day}"] = np.zeros((n, s, s), dtype=np.float32)
+    to_include = np.full(len(times_mjd), True)
+    for idx in range(n):
+        if obs_valid is not None:
+            to_include = obs_valid[idx]
+        with warnings.catch_warnings(), np.errstate(invalid="ignore", divide="ignore"):
+            warnings.simplefilter("ignore")
+            sci_stack = np.asanyarray(extract_stamp_stack(sci, xvals[idx], yvals[idx], radius, to_include=to_include))
+            var_stack = None
+            if "weighted" in coadd_types:
+                var_stack = np.asanyarray(extract_stamp_stack(var, xvals[idx], yvals[idx], radius, to_include=to_include))
+            for c in coadd_types:
+                out[f"coadd_{c}"][idx] = coadd_weighted(sci_stack, var_stack) if c == "weighted" else COADDS[c](sci_stack)
+            for day in days_to_use:
+                day_mask = day == day_strs[to_include]
+                sci_day = sci_stack[day_mask]
+                for c in coadd_types:
+                    if c == "weighted":
+                        out[f"coadd_{c}{day}"][idx] = coadd_weighted(sci_day, var_stack[day_mask])
+                    else:
+                        out[f"coadd_{c}{day}"][idx] = COADDS[c](sci_day)
+    return out
+
+
+def all_stamps_for_trajectories(sci, xvals, yvals, radius):
+    """append_all_stamps (stamp_filters.py:171-211): float32 [N][T][S][S]."""
+    n, T = len(xvals), len(sci)
+    s = 2 * radius + 1
+    out = np.zeros((n, T, s, s), dtype=np.float32)
+    for idx in range(n):
+        out[idx] = extract_stamp_stack(sci, xvals[idx], yvals[idx], radius)
+    return out
+
+
 # ---------------------------------------------------------------------------
 # near-duplicate grid filter (SURVEY.md section 8(f2)): src/kbmod/filters/clustering_grid.py
 # ---------------------------------------------------------------------------

@@ -122,6 +122,42 @@ def test_append_coadds_table(su):
     assert np.array_equal(table["coadd_sum"], ps.coadds_for_trajectories(sci, var, xv, yv, None, 4, ["sum"])["sum"])
 
 
+@pytest.mark.parametrize("valid_only", [True, False])
+def test_nightly_coadds(su, valid_only):
+    # stamp_filters.py:85-102, 150-166: one coadd per calendar night next to the overall one
+    sci, var, times, x0, y0, vx, vy, obs_valid = _random_case(21, 24, 48, 56, 80)
+    mjd = 60000.3 + np.sort(np.concatenate([np.arange(8) * 0.01, 1.0 + np.arange(9) * 0.01, 3.9 + np.arange(7) * 0.03]))
+    zeroed = mjd - mjd[0]
+    obs_valid[2, :8] = False  # a trajectory without a valid epoch in the first night
+    table = {"x": x0, "y": y0, "vx": vx, "vy": vy, "obs_valid": obs_valid}
+    stack = su.DeviceStack(sci, var, zeroed_times=zeroed, times=mjd)
+    su.append_coadds(table, stack, ALL, 3, valid_only=valid_only, nightly=True)
+    xv = ps.predict_pixel_locations(zeroed, x0, vx)
+    yv = ps.predict_pixel_locations(zeroed, y0, vy)
+    exp = ps.append_coadds_columns(sci, var, mjd, xv, yv, obs_valid if valid_only else None, 3, ALL, True)
+    nights = sorted(k for k in exp if k.startswith("coadd_sum_"))
+    assert len(nights) == 3 and nights[0] == "coadd_sum_2023-02-25"  # 60000 is 2023-02-25 (util_functions.py:63)
+    assert set(exp) == {k for k in table if k.startswith("coadd_")}
+    for k, v in exp.items():
+        assert table[k].dtype == np.float32
+        assert np.array_equal(table[k], v, equal_nan=True), k
+
+
+@pytest.mark.parametrize("radius", [1, 4, 10])
+def test_all_stamps(su, radius):
+    sci, var, times, x0, y0, vx, vy, _ = _random_case(31 + radius, 19, 44, 50, 70)
+    table = {"x": x0, "y": y0, "vx": vx, "vy": vy}
+    stack = su.DeviceStack(sci, zeroed_times=times)
+    su.append_all_stamps(table, stack, radius)
+    xv = ps.predict_pixel_locations(times, x0, vx)
+    yv = ps.predict_pixel_locations(times, y0, vy)
+    exp = ps.all_stamps_for_trajectories(sci, xv, yv, radius)
+    assert table["all_stamps"].dtype == np.float32 and table["all_stamps"].shape == exp.shape
+    assert np.array_equal(table["all_stamps"], exp, equal_nan=True)
+    with pytest.raises(ValueError):
+        su.append_all_stamps(table, stack, 0)
+
+
 def test_errors(su):
     sci, var = _kat_images()
     stack = su.DeviceStack(sci)
