@@ -62,7 +62,7 @@ def test_batch_equals_single(sg, num_obs, clipped):
         clipper = sg.SigmaGClipping(25, 75, clip_negative=clipped)
         batch = clipper.compute_clipped_sigma_g_matrix(data)
         for row in range(20):
-            ind = clipper.compute_clipped_sigma_g(data[row])
+            ind = ps.clipped_sigma_g(data[row], 25, 75, 2, clip_negative=clipped)  # the reference's single-curve helper
             assert np.array_equal(batch[row], [(i in ind) for i in range(num_obs)])
 
 
