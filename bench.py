@@ -242,9 +242,9 @@ def main():
     alg_rate = float(last.algorithmic_bytes) / (k_ms * 1e-3) / 1e9
     dtype = {-1: "f32", 4: "f32", 1: "u8", 2: "u16"}[args.num_bytes]
 
-    # measured HBM peak: a streaming device copy (1 GiB each way) timed with HIP events in this run
+    # measured HBM peak: a streaming device copy (4 GiB each way) timed with HIP events in this run
     copy_gbps = C.c_double(0.0)
-    check(lib, lib.kb_measure_copy_bandwidth(1 << 30, 10, stream, C.byref(copy_gbps)))
+    check(lib, lib.kb_measure_copy_bandwidth(4 << 30, 10, stream, C.byref(copy_gbps)))
 
     # fabric-side traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (it cannot be
     # read from inside this process); attached when the workload matches a profiled configuration.

@@ -15,7 +15,17 @@ int fail(const std::string& msg) {
 // Streaming copy used to measure what HBM delivers on this device (the "measured peak" next to the
 // nominal 8 TB/s in the roofline report): 16 bytes per lane, grid-stride.
 __global__ __launch_bounds__(256) void kb_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    // four independent 16-byte loads in flight per lane before the first store
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a;
+        dst[i + stride] = b;
+        dst[i + 2 * stride] = c;
+        dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
 }
 }  // namespace kb
 
@@ -119,7 +129,7 @@ int kb_measure_copy_bandwidth(uint64_t bytes, int32_t iters, void* stream_v, dou
         return fail("measure_copy_bandwidth: out of device memory");
     }
     (void)hipMemsetAsync(src, 1, n * 16, stream);
-    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
     float ms = 0.0f;
     {
         EventTimer timer(stream, true);

@@ -16,6 +16,7 @@
 #include <rocprim/device/device_select.hpp>
 
 #include "kb_common.h"
+#include "wave_ops.h"
 
 #pragma clang fp contract(off)
 
@@ -179,6 +180,40 @@ __global__ __launch_bounds__(CLIP_ROWS_PER_BLOCK* WAVE) void kb_sigma_g_clip_ker
         const float v = src[i];
         dst[i] = (__builtin_isfinite(v) && v < upper && v > lower) ? 1 : 0;
     }
+}
+
+// Curves of up to 64 points (the usual stack depth): the row never leaves the registers.  One wavefront
+// per row, lane i holds point i as an ordered key, the keys are sorted across the lanes by the DPP /
+// permlane-swap network of wave_ops.h (no LDS, no barriers), the quantile neighbours are lane reads.
+__global__ __launch_bounds__(CLIP_ROWS_PER_BLOCK* WAVE) void kb_sigma_g_clip64_kernel(
+        const float* __restrict__ lh, uint64_t n_rows, int n_cols, float q_low, float q_high, float scale,
+        int clip_negative, uint8_t* __restrict__ valid) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint64_t row = (uint64_t)blockIdx.x * CLIP_ROWS_PER_BLOCK + threadIdx.x / WAVE;
+    if (row >= n_rows) return;  // whole wave
+    const float* src = lh + row * (uint64_t)n_cols;
+    const float own = (lane < n_cols) ? src[lane] : __uint_as_float(0x7fc00000u);
+    float v = own;
+    if (clip_negative && !(v > 0.0f)) v = __uint_as_float(0x7fc00000u);  // torch.where(lh > 0, lh, nan)
+    const int n_valid = __popcll(__ballot(v == v));
+    uint32_t key = float_sort_key(v), unused = 0;
+    wave_sort64(key, unused, lane);
+    float quant[3];
+    const float qs[3] = {q_low, 0.5f, q_high};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float rank = qs[i] * (float)(n_valid - 1);
+        if (rank < 0.0f) rank = 0.0f;
+        const float below = floorf(rank);
+        const int ib = __builtin_amdgcn_readfirstlane((int)below), ia = __builtin_amdgcn_readfirstlane((int)ceilf(rank));
+        const uint32_t kb_ = (uint32_t)__builtin_amdgcn_readlane((int)key, ib), ka = (uint32_t)__builtin_amdgcn_readlane((int)key, ia);
+        quant[i] = lerp_aten(key_to_float(kb_), key_to_float(ka), rank - below);
+    }
+    float delta = quant[2] - quant[0];
+    if (delta < 1e-5f) delta = 1e-5f;
+    const float n_sigma_g = scale * delta;
+    const float lower = quant[1] - n_sigma_g, upper = quant[1] + n_sigma_g;
+    if (lane < n_cols) valid[row * (uint64_t)n_cols + lane] = (__builtin_isfinite(own) && own < upper && own > lower) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -356,9 +391,15 @@ extern "C" int kb_sigma_g_clip_matrix(const float* lh_dev, uint64_t n_rows, int3
     if (blocks > 0x7fffffffull) return fail("sigma_g_clip_matrix: too many rows for one launch");
     // the reference forms n_sigma * coeff in double and multiplies the float32 tensor by it
     const float scale = (float)((double)n_sigma * (double)coeff);
-    hipLaunchKernelGGL(kb_sigma_g_clip_kernel, dim3((unsigned)blocks), dim3(CLIP_ROWS_PER_BLOCK * WAVE),
-                       (size_t)CLIP_ROWS_PER_BLOCK * P * sizeof(uint32_t), stream, lh_dev, n_rows, (int)n_cols, P,
-                       low_pct / 100.0f, high_pct / 100.0f, scale, (int)clip_negative, valid_dev);
+    if (n_cols <= WAVE) {
+        hipLaunchKernelGGL(kb_sigma_g_clip64_kernel, dim3((unsigned)blocks), dim3(CLIP_ROWS_PER_BLOCK * WAVE), 0, stream,
+                           lh_dev, n_rows, (int)n_cols, low_pct / 100.0f, high_pct / 100.0f, scale, (int)clip_negative,
+                           valid_dev);
+    } else {
+        hipLaunchKernelGGL(kb_sigma_g_clip_kernel, dim3((unsigned)blocks), dim3(CLIP_ROWS_PER_BLOCK * WAVE),
+                           (size_t)CLIP_ROWS_PER_BLOCK * P * sizeof(uint32_t), stream, lh_dev, n_rows, (int)n_cols, P,
+                           low_pct / 100.0f, high_pct / 100.0f, scale, (int)clip_negative, valid_dev);
+    }
     KB_HIP_TRY(hipGetLastError());
     KB_HIP_TRY(hipStreamSynchronize(stream));
     return 0;
