@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "../search_math.h"
 #include "common.h"
 #include "image_utils.h"
 
@@ -79,30 +80,11 @@ public:
 
     // psi_phi_array.cpp:172-205
     PsiPhi read_psi_phi(uint64_t time, int row, int col) {
-        PsiPhi result = {NO_DATA, NO_DATA};
-        if (!cpu_array_allocated() || (row < 0) || (col < 0) || ((uint64_t)row >= meta_data.height) ||
-            ((uint64_t)col >= meta_data.width) || (time >= meta_data.num_times)) {
-            return result;
+        PsiPhi sample = {NO_DATA, NO_DATA};
+        if (cpu_array_allocated()) {  // bounds, decode and the NO_DATA rule live in search_math.h, shared with the kernels
+            kb::read_psi_phi(meta_data, host_ptr(), time, row, col, &sample.psi, &sample.phi);
         }
-        const void* arr = host_ptr();
-        uint64_t start_index =
-                2 * (meta_data.pixels_per_image * time + static_cast<uint64_t>(row * meta_data.width + col));
-        if (meta_data.num_bytes == 4) {
-            result.psi = reinterpret_cast<const float*>(arr)[start_index];
-            result.phi = reinterpret_cast<const float*>(arr)[start_index + 1];
-        } else {
-            float psi_value = (meta_data.num_bytes == 1)
-                                      ? (float)reinterpret_cast<const uint8_t*>(arr)[start_index]
-                                      : (float)reinterpret_cast<const uint16_t*>(arr)[start_index];
-            result.psi = (psi_value == 0.0) ? NO_DATA
-                                            : (psi_value - 1.0) * meta_data.psi_scale + meta_data.psi_min_val;
-            float phi_value = (meta_data.num_bytes == 1)
-                                      ? (float)reinterpret_cast<const uint8_t*>(arr)[start_index + 1]
-                                      : (float)reinterpret_cast<const uint16_t*>(arr)[start_index + 1];
-            result.phi = (phi_value == 0.0) ? NO_DATA
-                                            : (phi_value - 1.0) * meta_data.phi_scale + meta_data.phi_min_val;
-        }
-        return result;
+        return sample;
     }
 
     // psi_phi_array.cpp:207-212
@@ -115,33 +97,29 @@ public:
 
     // psi_phi_array.cpp:113-148
     void set_meta_data(int new_num_bytes, uint64_t new_num_times, uint64_t new_height, uint64_t new_width) {
-        if (new_num_bytes != -1 && new_num_bytes != 1 && new_num_bytes != 2 && new_num_bytes != 4) {
+        const bool known_size = new_num_bytes == -1 || new_num_bytes == 1 || new_num_bytes == 2 || new_num_bytes == 4;
+        if (!known_size) {
             throw std::runtime_error("Invalid setting of num_bytes. Must be (-1 [use default], 1, 2, or 4). Got " +
                                      std::to_string(new_num_bytes));
         }
-        if (new_num_times == 0)
-            throw std::runtime_error("Invalid num_times passed to set_meta_data: " + std::to_string(new_num_times));
-        if (new_width == 0)
-            throw std::runtime_error("Invalid width passed to set_meta_data: " + std::to_string(new_width));
-        if (new_height == 0)
-            throw std::runtime_error("Invalid height passed to set_meta_data: " + std::to_string(new_height));
+        const std::pair<const char*, uint64_t> extents[] = {
+                {"num_times", new_num_times}, {"width", new_width}, {"height", new_height}};
+        for (const auto& e : extents) {
+            if (e.second == 0) {
+                throw std::runtime_error(std::string("Invalid ") + e.first + " passed to set_meta_data: 0");
+            }
+        }
         if (cpu_array_ptr != nullptr || gpu_array_ptr != nullptr) {
             throw std::runtime_error("Cannot change meta data with allocated arrays. Call clear() first.");
         }
-        meta_data.num_bytes = new_num_bytes;
-        if (meta_data.num_bytes == 1) {
-            meta_data.block_size = sizeof(uint8_t);
-        } else if (meta_data.num_bytes == 2) {
-            meta_data.block_size = sizeof(uint16_t);
-        } else {
-            meta_data.num_bytes = 4;
-            meta_data.block_size = sizeof(float);
-        }
+        const int bytes = (new_num_bytes == 1 || new_num_bytes == 2) ? new_num_bytes : 4;  // -1 and 4: float32
+        meta_data.num_bytes = bytes;
+        meta_data.block_size = (uint64_t)bytes;
         meta_data.num_times = new_num_times;
         meta_data.width = new_width;
         meta_data.height = new_height;
-        meta_data.pixels_per_image = meta_data.width * meta_data.height;
-        meta_data.num_entries = 2 * meta_data.pixels_per_image * meta_data.num_times;
+        meta_data.pixels_per_image = new_width * new_height;
+        meta_data.num_entries = 2 * meta_data.pixels_per_image * new_num_times;
         meta_data.total_array_size = meta_data.block_size * meta_data.num_entries;
     }
 
@@ -294,105 +272,98 @@ private:
 
 // ---- utility functions: psi_phi_array.cpp:219-410 -----------------------------
 
-// psi_phi_array.cpp:219-245
+// psi_phi_array.cpp:219-245: finite range of a set of images and the code width that spans it.
 inline std::array<float, 3> compute_scale_params_from_image_vect(const std::vector<Image>& imgs, int num_bytes) {
-    float min_val = FLT_MAX;
-    float max_val = -FLT_MAX;
+    float lo = FLT_MAX, hi = -FLT_MAX;
     for (const Image& im : imgs) {
-        for (float elem : im.data) {
-            if (pixel_value_valid(elem)) {
-                min_val = std::min(min_val, elem);
-                max_val = std::max(max_val, elem);
-            }
+        for (const float v : im.data) {
+            if (!pixel_value_valid(v)) continue;
+            lo = std::min(lo, v);
+            hi = std::max(hi, v);
         }
     }
     float scale = 1.0;
     if (num_bytes == 1 || num_bytes == 2) {
-        float width = (max_val - min_val);
-        if (width < 1e-6) width = 1e-6;
-        uint64_t num_values = (1 << (8 * num_bytes)) - 1;
-        scale = width / (double)num_values;
+        const float span = std::max(hi - lo, 1e-6f);
+        const uint64_t codes = (1ull << (8 * num_bytes)) - 1;
+        scale = span / (double)codes;
     }
-    return {min_val, max_val, scale};
+    return {lo, hi, scale};
 }
 
-// psi_phi_array.cpp:247-291
+// The host build of the array (psi_phi_array.cpp:247-319): psi and phi of every pixel side by side, epoch after
+// epoch, each value passed through `code` (the identity for float arrays, encode_uint_scalar + truncation for
+// encoded ones).
+template <typename T, typename PsiCode, typename PhiCode>
+void interleave_on_host(PsiPhiArray& data, const std::vector<Image>& psi_imgs, const std::vector<Image>& phi_imgs,
+                        PsiCode psi_code, PhiCode phi_code) {
+    if (data.get_cpu_array_ptr() != nullptr) throw std::runtime_error("CPU PsiPhi already allocated.");
+    T* out = static_cast<T*>(malloc(data.get_total_array_size()));
+    if (out == nullptr) throw std::runtime_error("Unable to allocate space for CPU PsiPhi array.");
+    T* cursor = out;
+    for (uint64_t t = 0; t < data.get_num_times(); ++t) {
+        const std::vector<float>& psi = psi_imgs[t].data;
+        const std::vector<float>& phi = phi_imgs[t].data;
+        for (size_t p = 0; p < psi.size(); ++p) {
+            *cursor++ = static_cast<T>(psi_code(psi[p]));
+            *cursor++ = static_cast<T>(phi_code(phi[p]));
+        }
+    }
+    data.set_cpu_array_ptr(out);
+}
+
 template <typename T>
 void set_encode_cpu_psi_phi_array(PsiPhiArray& data, const std::vector<Image>& psi_imgs,
                                   const std::vector<Image>& phi_imgs) {
-    if (data.get_cpu_array_ptr() != nullptr) throw std::runtime_error("CPU PsiPhi already allocated.");
-    T* encoded = (T*)malloc(data.get_total_array_size());
-    if (encoded == nullptr) throw std::runtime_error("Unable to allocate space for CPU PsiPhi array.");
-    float safe_max_psi = data.get_psi_max_val() - data.get_psi_scale() / 100.0;
-    float safe_max_phi = data.get_phi_max_val() - data.get_phi_scale() / 100.0;
-    uint64_t current_index = 0;
-    for (uint64_t t = 0; t < data.get_num_times(); ++t) {
-        const Image& psi = psi_imgs[t];
-        const Image& phi = phi_imgs[t];
-        for (size_t p = 0; p < psi.data.size(); ++p) {
-            float psi_value = encode_uint_scalar(psi.data[p], data.get_psi_min_val(), safe_max_psi, data.get_psi_scale());
-            float phi_value = encode_uint_scalar(phi.data[p], data.get_phi_min_val(), safe_max_phi, data.get_phi_scale());
-            encoded[current_index++] = static_cast<T>(psi_value);
-            encoded[current_index++] = static_cast<T>(phi_value);
-        }
-    }
-    data.set_cpu_array_ptr((void*)encoded);
+    // psi_phi_array.cpp:264-265: the largest value stays one hundredth of a code below the top
+    const float psi_lo = data.get_psi_min_val(), psi_w = data.get_psi_scale(), psi_top = data.get_psi_max_val() - psi_w / 100.0;
+    const float phi_lo = data.get_phi_min_val(), phi_w = data.get_phi_scale(), phi_top = data.get_phi_max_val() - phi_w / 100.0;
+    interleave_on_host<T>(
+            data, psi_imgs, phi_imgs, [=](float v) { return encode_uint_scalar(v, psi_lo, psi_top, psi_w); },
+            [=](float v) { return encode_uint_scalar(v, phi_lo, phi_top, phi_w); });
 }
 
-// psi_phi_array.cpp:293-319
 inline void set_float_cpu_psi_phi_array(PsiPhiArray& data, const std::vector<Image>& psi_imgs,
                                         const std::vector<Image>& phi_imgs) {
-    if (data.get_cpu_array_ptr() != nullptr) throw std::runtime_error("CPU PsiPhi already allocated.");
-    float* encoded = (float*)malloc(data.get_total_array_size());
-    if (encoded == nullptr) throw std::runtime_error("Unable to allocate space for CPU PsiPhi array.");
-    uint64_t current_index = 0;
-    for (uint64_t t = 0; t < data.get_num_times(); ++t) {
-        const Image& psi = psi_imgs[t];
-        const Image& phi = phi_imgs[t];
-        for (size_t p = 0; p < psi.data.size(); ++p) {
-            encoded[current_index++] = psi.data[p];
-            encoded[current_index++] = phi.data[p];
-        }
-    }
-    data.set_cpu_array_ptr((void*)encoded);
+    interleave_on_host<float>(data, psi_imgs, phi_imgs, [](float v) { return v; }, [](float v) { return v; });
 }
 
 // psi_phi_array.cpp:321-372
 inline void fill_psi_phi_array(PsiPhiArray& result_data, int num_bytes, const std::vector<Image>& psi_imgs,
                                const std::vector<Image>& phi_imgs, const std::vector<double> zeroed_times) {
     if (result_data.get_cpu_array_ptr() != nullptr || result_data.device_resident()) return;
-    uint64_t num_times = psi_imgs.size();
+    const uint64_t num_times = psi_imgs.size();
     if (num_times == 0) throw std::runtime_error("Trying to fill PsiPhi from empty vectors.");
     assert_sizes_equal(phi_imgs.size(), num_times, "psi and phi arrays");
-    uint64_t width = phi_imgs[0].cols;
-    uint64_t height = phi_imgs[0].rows;
+    const int64_t rows = phi_imgs[0].rows, cols = phi_imgs[0].cols;
     for (uint64_t t = 0; t < num_times; ++t) {
-        if ((uint64_t)psi_imgs[t].rows != height || (uint64_t)psi_imgs[t].cols != width ||
-            (uint64_t)phi_imgs[t].rows != height || (uint64_t)phi_imgs[t].cols != width) {
-            throw std::runtime_error("All psi and phi images must have the same dimensions.");
-        }
+        const bool same = psi_imgs[t].rows == rows && psi_imgs[t].cols == cols && phi_imgs[t].rows == rows &&
+                          phi_imgs[t].cols == cols;
+        if (!same) throw std::runtime_error("All psi and phi images must have the same dimensions.");
     }
-    result_data.set_meta_data(num_bytes, num_times, height, width);
+    result_data.set_meta_data(num_bytes, num_times, (uint64_t)rows, (uint64_t)cols);
 
-    if (result_data.get_num_bytes() == 1 || result_data.get_num_bytes() == 2) {
-        std::array<float, 3> psi_params = compute_scale_params_from_image_vect(psi_imgs, result_data.get_num_bytes());
-        result_data.set_psi_scaling(psi_params[0], psi_params[1], psi_params[2]);
-        std::array<float, 3> phi_params = compute_scale_params_from_image_vect(phi_imgs, result_data.get_num_bytes());
-        result_data.set_phi_scaling(phi_params[0], phi_params[1], phi_params[2]);
+    const int bytes = result_data.get_num_bytes();
+    if (bytes == 4) {
+        set_float_cpu_psi_phi_array(result_data, psi_imgs, phi_imgs);
+    } else {
+        const std::array<float, 3> psi_range = compute_scale_params_from_image_vect(psi_imgs, bytes);
+        const std::array<float, 3> phi_range = compute_scale_params_from_image_vect(phi_imgs, bytes);
+        result_data.set_psi_scaling(psi_range[0], psi_range[1], psi_range[2]);
+        result_data.set_phi_scaling(phi_range[0], phi_range[1], phi_range[2]);
         logging::Logger* lg = logging::getLogger("kbmod.search.psi_phi_array");
-        lg->info("Encoding psi to " + std::to_string(result_data.get_num_bytes()) +
-                 ": min=" + std::to_string(psi_params[0]) + ", max=" + std::to_string(psi_params[1]) +
-                 ", scale=" + std::to_string(psi_params[2]));
-        lg->info("Encoding phi to " + std::to_string(result_data.get_num_bytes()) +
-                 ": min=" + std::to_string(phi_params[0]) + ", max=" + std::to_string(phi_params[1]) +
-                 ", scale=" + std::to_string(phi_params[2]));
-        if (result_data.get_num_bytes() == 1) {
+        const char* names[2] = {"psi", "phi"};
+        const std::array<float, 3>* ranges[2] = {&psi_range, &phi_range};
+        for (int i = 0; i < 2; ++i) {
+            lg->info(std::string("Encoding ") + names[i] + " to " + std::to_string(bytes) + ": min=" +
+                     std::to_string((*ranges[i])[0]) + ", max=" + std::to_string((*ranges[i])[1]) +
+                     ", scale=" + std::to_string((*ranges[i])[2]));
+        }
+        if (bytes == 1) {
             set_encode_cpu_psi_phi_array<uint8_t>(result_data, psi_imgs, phi_imgs);
         } else {
             set_encode_cpu_psi_phi_array<uint16_t>(result_data, psi_imgs, phi_imgs);
         }
-    } else {
-        set_float_cpu_psi_phi_array(result_data, psi_imgs, phi_imgs);
     }
     result_data.set_time_array(zeroed_times);
 }

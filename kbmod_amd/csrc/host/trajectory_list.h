@@ -36,36 +36,36 @@ public:
 
     inline Trajectory& get_trajectory(uint64_t index) {
         if (index >= max_size) throw std::runtime_error("Index out of bounds.");
-        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        host_only();
         return cpu_list[index];
     }
     inline std::vector<Trajectory>& get_list() {
-        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        host_only();
         return cpu_list;
     }
     void reset_all() {  // :62-67
-        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        host_only();
         for (uint64_t i = 0; i < max_size; ++i) cpu_list[i].clear();
     }
     inline void set_trajectory(uint64_t index, const Trajectory& new_value) {
         if (index >= max_size) throw std::runtime_error("Index out of bounds.");
-        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        host_only();
         cpu_list[index] = new_value;
     }
     void set_trajectories(const std::vector<Trajectory>& new_values) {  // :69-80
-        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        host_only();
         const uint64_t new_size = new_values.size();
         resize(new_size);
         for (uint64_t i = 0; i < new_size; ++i) cpu_list[i] = new_values[i];
         assert_valid();
     }
     void resize(uint64_t new_size) {  // :48-60 (vector::resize value-initialises == clear())
-        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        host_only();
         cpu_list.resize(new_size);
         max_size = new_size;
     }
     std::vector<Trajectory> get_batch(uint64_t start, uint64_t count) {  // :82-94
-        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        host_only();
         if (count == 0) throw std::runtime_error("count must be greater than 0");
         if (start >= max_size) return std::vector<Trajectory>();
         if (start + count >= max_size) return std::vector<Trajectory>(cpu_list.begin() + start, cpu_list.end());
@@ -75,7 +75,7 @@ public:
     // :96-107.  The reference's sort is unstable; a stable sort is one of the
     // orders it may produce and makes results reproducible.
     void sort_by_likelihood() {
-        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        host_only();
         auto cmp = [](const Trajectory& a, const Trajectory& b) { return b.lh < a.lh; };
 #ifdef _OPENMP
         __gnu_parallel::stable_sort(cpu_list.begin(), cpu_list.end(), cmp);
@@ -84,19 +84,10 @@ public:
 #endif
     }
     void filter_by_likelihood(float min_lh) {  // :109-116
-        if (data_on_gpu) throw std::runtime_error("Data on GPU");
-        auto new_end = std::remove_if(cpu_list.begin(), cpu_list.end(),
-                                      [min_lh](const Trajectory& a) { return (a.lh < min_lh); });
-        cpu_list.erase(new_end, cpu_list.end());
-        resize(cpu_list.size());
+        drop_where([min_lh](const Trajectory& t) { return t.lh < min_lh; });
     }
     void filter_by_obs_count(int min_obs_count) {  // :118-126
-        if (data_on_gpu) throw std::runtime_error("Data on GPU");
-        auto new_end = std::remove_if(cpu_list.begin(), cpu_list.end(), [min_obs_count](const Trajectory& a) {
-            return (a.obs_count < min_obs_count);
-        });
-        cpu_list.erase(new_end, cpu_list.end());
-        resize(cpu_list.size());
+        drop_where([min_obs_count](const Trajectory& t) { return t.obs_count < min_obs_count; });
     }
 
     inline bool on_gpu() const { return data_on_gpu; }
@@ -120,7 +111,7 @@ public:
     inline Trajectory* get_gpu_list_ptr() { return reinterpret_cast<Trajectory*>(gpu_ptr); }
 
     void assert_valid() const {  // :155-164
-        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+        host_only();
         for (size_t i = 0; i < cpu_list.size(); ++i) {
             if (!cpu_list[i].is_valid()) {
                 throw std::runtime_error("Invalid trajectory detected at index " + std::to_string(i) + ": " +
@@ -130,6 +121,16 @@ public:
     }
 
 private:
+    // The host vector is the list only while the data is not on the device (gpu_array.h state machine).
+    void host_only() const {
+        if (data_on_gpu) throw std::runtime_error("Data on GPU");
+    }
+    template <typename Pred>
+    void drop_where(Pred reject) {  // order-preserving removal
+        host_only();
+        cpu_list.erase(std::remove_if(cpu_list.begin(), cpu_list.end(), reject), cpu_list.end());
+        max_size = cpu_list.size();
+    }
     void free_device() {
         if (gpu_ptr != nullptr) {
             (void)kb_free_gpu_block(gpu_ptr);

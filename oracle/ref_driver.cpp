@@ -11,9 +11,11 @@
  * (the Makefile passes -I); nothing of them is copied into this repository and
  * the built library lives only in oracle/_ref/ (git-ignored).
  *
- * NOT buildable here, hence not wrapped: psi_phi_array.cpp, image_utils_cpp.cpp,
- * cpu_search_algorithms.cpp, stack_search.cpp (need <Eigen/Core>, absent) and
- * kernels/ *.cu (need the CUDA toolkit, absent).
+ * NOT buildable here, hence not wrapped: psi_phi_array.cpp, image_utils_cpp.cpp and
+ * stack_search.cpp include <Eigen/Core> (absent: include/eigen is an empty submodule);
+ * cpu_search_algorithms.cpp parses on its own (g++ -fsyntax-only) but cannot link
+ * without PsiPhiArray's members, which live in psi_phi_array.cpp; kernels/ *.cu need
+ * the CUDA toolkit (absent).
  */
 #include <cstdint>
 #include <cstring>
