@@ -120,6 +120,7 @@ int kb_copy_block_to_cpu(void* dst_host, const void* src_dev, uint64_t memory_si
 int kb_measure_copy_bandwidth(uint64_t bytes, int32_t iters, void* stream_v, double* gbps_out) {
     using namespace kb;
     if (gbps_out == nullptr || iters <= 0 || bytes < 16) return fail("measure_copy_bandwidth: bad argument");
+    KB_REQUIRE_DEVICE("the copy-bandwidth probe.");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     const size_t n = (size_t)(bytes / 16);
     void *src = nullptr, *dst = nullptr;

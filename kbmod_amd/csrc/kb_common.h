@@ -25,6 +25,15 @@ int fail(const std::string& msg);  // set_error + return 1
 
 constexpr int WAVE = 64;  // gfx950 wavefront
 
+// Every entry point that launches work starts with this: it fails loudly without a device, makes sure the
+// runtime is initialised in this process even when the call is the library's first, and drops a stale error
+// another library may have left on the calling thread (the launch checks below read the thread's last error).
+#define KB_REQUIRE_DEVICE(what)                                                              \
+    do {                                                                                     \
+        if (kb_device_count() == 0) return kb::fail(std::string("GPU is not available for ") + (what)); \
+        (void)hipGetLastError();                                                             \
+    } while (0)
+
 // RAII pair of HIP events recorded on the launch stream (bench/roofline timing).
 struct EventTimer {
     hipEvent_t start = nullptr, stop = nullptr;

@@ -301,6 +301,7 @@ static int sort_pairs(bool descending, K* keys_in, K* keys_out, uint32_t* val_in
 extern "C" int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs,
                                       kb_trajectory* out_dev, uint64_t* n_out_host, void* stream_v) {
     using namespace kb;
+    KB_REQUIRE_DEVICE("the result filter.");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (n_out_host == nullptr) return fail("filter_sort_results: null count pointer");
     *n_out_host = 0;
@@ -358,6 +359,7 @@ extern "C" int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t
 extern "C" int kb_psi_phi_curves(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
                                  const kb_trajectory* trjs_dev, uint64_t n, float* out_dev, void* stream_v) {
     using namespace kb;
+    KB_REQUIRE_DEVICE("the psi/phi curves.");
     if (meta == nullptr || psi_phi_dev == nullptr || times_dev == nullptr) return fail("psi_phi_curves: null input");
     if (n == 0) return 0;
     if (trjs_dev == nullptr || out_dev == nullptr) return fail("psi_phi_curves: null pointer");
@@ -377,6 +379,7 @@ extern "C" int kb_sigma_g_clip_matrix(const float* lh_dev, uint64_t n_rows, int3
                                       void* stream_v) {
     using namespace kb;
     if (n_rows == 0 || n_cols == 0) return 0;
+    KB_REQUIRE_DEVICE("sigma-G clipping.");
     if (lh_dev == nullptr || valid_dev == nullptr) return fail("sigma_g_clip_matrix: null pointer");
     if (n_cols < 0 || n_cols > 4096) return fail("sigma_g_clip_matrix: curves longer than 4096 points are not supported");
     if (!(low_pct > 0.0f) || !(high_pct < 100.0f) || low_pct > high_pct) {  // sigma_g_filter.py:38-39
@@ -439,6 +442,7 @@ extern "C" int kb_sigma_g_clip_matrix_host(const float* lh_host, uint64_t n_rows
 extern "C" int kb_grid_filter(const kb_trajectory* trjs_dev, uint64_t n, double bin_width, double max_time,
                               uint32_t* kept_idx_dev, uint64_t* n_kept_host, void* stream_v) {
     using namespace kb;
+    KB_REQUIRE_DEVICE("the grid filter.");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (n_kept_host == nullptr) return fail("grid_filter: null count pointer");
     *n_kept_host = 0;

@@ -32,7 +32,10 @@ __host__ __device__ constexpr int lds_group_bytes(int rows) { return 5120 * rows
 // LDS staging (kb_search_lds): per (chunk, epoch) the workgroup stages a slab of
 // rows_max(chunk) x LDS_COLS raw pairs -- the union footprint of its 64 x ROWS tile
 // under the chunk's shifts -- from a padded HBM copy of the array into a ring of slab slots in LDS.
-constexpr int LDS_COLS = 88;          // slab pitch in pixels: 64 start columns + up to 24 of dx spread
+#ifndef KB_LDS_COLS
+#define KB_LDS_COLS 88
+#endif
+constexpr int LDS_COLS = KB_LDS_COLS;  // slab pitch in pixels: 64 start columns + up to 24 of dx spread
                                       // (88 * {8,4,2} bytes are multiples of the 16-byte DMA granule)
 constexpr int LDS_ALIGN_PX = 8;         // slab origins are multiples of 8 columns of the padded frame
 #ifndef KB_LDS_SLOTS

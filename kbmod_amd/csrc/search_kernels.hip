@@ -887,6 +887,7 @@ int kb_merge_topk(const kb_trajectory* lists_dev, int32_t n_lists, uint64_t n_pi
     if (n_lists <= 0 || n_lists > MERGE_MAX_LISTS) return fail("merge_topk: unsupported number of lists");
     if (K <= 0 || K > 255) return fail("merge_topk: unsupported K");
     if (n_pixels == 0) return 0;
+    KB_REQUIRE_DEVICE("the list merge.");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     const unsigned blocks = (unsigned)((n_pixels + 255) / 256);
     hipLaunchKernelGGL(kb_merge_topk_kernel, dim3(blocks), dim3(256), 0, stream, lists_dev, n_lists, n_pixels, K,
@@ -905,6 +906,7 @@ int kb_merge_compact(const kb_compact_result* lists_dev, int32_t n_lists, kb_sea
     const int K = (int)params.results_per_pixel;
     if (sw <= 0 || sh <= 0) return fail("merge_compact: invalid search bounds");
     if (K <= 0 || K > 32) return fail("merge_compact: unsupported K");
+    KB_REQUIRE_DEVICE("the list merge.");
     (void)hipGetLastError();
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     const uint64_t n_pixels = (uint64_t)sw * (uint64_t)sh;

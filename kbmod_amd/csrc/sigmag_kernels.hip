@@ -249,17 +249,32 @@ __global__ __launch_bounds__(256) void kb_sigmag_select_kernel(const ResolveArgs
     }
 
     const uint32_t* slot_row = a.sg.slots + (size_t)row * a.sg.batch_cands;
+    constexpr int AHEAD = 4;  // entries whose mask and likelihoods are fetched together
     for (int c0 = 0; c0 < a.sg.batch_cands; c0 += WAVE) {
         const uint32_t slot = (c0 + lane < a.sg.batch_cands) ? slot_row[c0 + lane] : 0u;
         uint64_t m = __ballot(slot != 0u);
         while (m != 0) {  // candidate order
-            const int b = __ffsll((unsigned long long)m) - 1;
-            m &= m - 1;
-            const int e = __builtin_amdgcn_readlane((int)slot, b) - 1;
-            const uint64_t mask = a.sg.entries[e].mask;
-            const float lh = a.sg.lh[(size_t)e * WAVE + lane];
-            // kernels.cu:318-320 on the clipped value (obs_count was tested before the clip and is unchanged)
-            if (((mask >> lane) & 1) && !(lh < a.params.min_lh)) top.insert(lh, e);
+            int e[AHEAD];
+            uint64_t mask[AHEAD];
+            float lh[AHEAD];
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) {
+                e[k] = -1;
+                mask[k] = 0;
+                lh[k] = 0.0f;
+                if (m != 0) {  // uniform
+                    const int b = __ffsll((unsigned long long)m) - 1;
+                    m &= m - 1;
+                    e[k] = __builtin_amdgcn_readlane((int)slot, b) - 1;
+                    mask[k] = a.sg.entries[e[k]].mask;
+                    lh[k] = a.sg.lh[(size_t)e[k] * WAVE + lane];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) {
+                // kernels.cu:318-320 on the clipped value (obs_count was tested before the clip and is unchanged)
+                if (e[k] >= 0 && ((mask[k] >> lane) & 1) && !(lh[k] < a.params.min_lh)) top.insert(lh[k], e[k]);
+            }
         }
     }
 
@@ -363,6 +378,7 @@ extern "C" int kb_debug_wave_ops(const uint32_t* keys_dev, uint32_t* keys_out_de
     using namespace kb;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (n_waves == 0) return 0;
+    KB_REQUIRE_DEVICE("the wave-ops self-test.");
     (void)hipGetLastError();  // a stale error of this thread (another library's probing) is not ours
     if (keys_dev != nullptr) {
         hipLaunchKernelGGL(kb_debug_wave_sort_kernel, dim3((unsigned)n_waves), dim3(WAVE), 0, stream, keys_dev, keys_out_dev,

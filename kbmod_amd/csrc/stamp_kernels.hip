@@ -217,6 +217,7 @@ extern "C" int kb_coadd_stamps(const float* sci_dev, const float* var_dev, int32
     using namespace kb;
     if (radius <= 0) return fail("Invalid stamp radius " + std::to_string(radius));  // stamp_filters.py:89-90
     if (n == 0) return 0;
+    KB_REQUIRE_DEVICE("stamp coadds.");
     if (sci_dev == nullptr || x_dev == nullptr || y_dev == nullptr || out_dev == nullptr) {
         return fail("coadd_stamps: null pointer");
     }
@@ -301,6 +302,7 @@ extern "C" int kb_extract_stamps(const float* sci_dev, int32_t num_times, int32_
     using namespace kb;
     if (radius < 1) return fail("Invalid stamp radius: " + std::to_string(radius));  // stamp_filters.py:188-189
     if (n == 0 || num_times == 0) return 0;
+    KB_REQUIRE_DEVICE("stamp extraction.");
     if (sci_dev == nullptr || x_dev == nullptr || y_dev == nullptr || out_dev == nullptr) {
         return fail("extract_stamps: null pointer");
     }

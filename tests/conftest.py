@@ -15,6 +15,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def kb():
     """The native module; building it here keeps a fresh checkout self-contained."""
+    # Some GPU tests hold device buffers in torch tensors.  The PyTorch-ROCm wheel bundles its own copy of
+    # libamdhip64, and two copies of the runtime cannot both initialise in one process: whichever is loaded first
+    # serves both.  Load torch's first, so that the order does not depend on which test files are collected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         import kbmod_amd.search as mod
     except ImportError:
