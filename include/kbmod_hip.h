@@ -64,6 +64,8 @@ typedef struct kb_search_stats {
     uint64_t sigmag_work_items;   /* in-search sigma-G: (row of 64 start pixels, candidate) pairs with a trajectory to clip */
     uint64_t sigmag_trajectories; /* ... and the trajectories clipped */
     uint64_t lds_read_bytes;      /* kb_search_lds: bytes the sums read out of LDS (num_evals x staged pair size), else 0 */
+    uint64_t sigmag_literal;      /* ... of the clipped trajectories, those that took the literal per-lane exchange sort
+                                     (equal ratios from different (psi, phi) pairs, stacks deeper than 256 epochs) */
 } kb_search_stats;
 
 const char* kb_last_error(void);

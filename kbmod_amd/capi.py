@@ -30,7 +30,8 @@ class Stats(C.Structure):
     """kb_search_stats"""
     _fields_ = [("search_kernel_ms", C.c_float), ("table_kernel_ms", C.c_float), ("num_evals", C.c_uint64),
                 ("algorithmic_bytes", C.c_uint64), ("kernel_variant", C.c_int32), ("num_search_launches", C.c_int32),
-                ("sigmag_work_items", C.c_uint64), ("sigmag_trajectories", C.c_uint64), ("lds_read_bytes", C.c_uint64)]
+                ("sigmag_work_items", C.c_uint64), ("sigmag_trajectories", C.c_uint64), ("lds_read_bytes", C.c_uint64),
+                ("sigmag_literal", C.c_uint64)]
 
 
 def lib_path():

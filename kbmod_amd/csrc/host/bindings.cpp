@@ -483,6 +483,7 @@ PYBIND11_MODULE(search, m) {
                 d["num_search_launches"] = st.num_search_launches;
                 d["sigmag_work_items"] = st.sigmag_work_items;
                 d["sigmag_trajectories"] = st.sigmag_trajectories;
+                d["sigmag_literal"] = st.sigmag_literal;
                 return d;
             });
 

@@ -87,7 +87,7 @@ struct SigmaGWork {
     uint32_t* slots;   // [rows][batch_cands]: entry index + 1 of (row, candidate), 0 = nothing passed
     SgEntry* entries;  // [capacity]
     int* n_entries;    // device counter of the batch in flight
-    unsigned long long* totals;  // {work items, trajectories} of the whole search
+    unsigned long long* totals;  // {work items, trajectories, trajectories clipped by the literal code} of the whole search
     float* lh;         // [capacity][64] clipped likelihood of the entry's lanes
     float* flux;       // [capacity][64]
     int* obs;          // [capacity][64]

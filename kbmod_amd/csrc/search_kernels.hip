@@ -747,7 +747,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         cold.sg.slots = reinterpret_cast<uint32_t*>(wc);
         cold.sg.n_entries = reinterpret_cast<int*>(wc + slot_bytes);
         cold.sg.totals = reinterpret_cast<unsigned long long*>(wc + slot_bytes + 64);
-        KB_HIP_TRY(hipMemsetAsync(cold.sg.totals, 0, 2 * sizeof(unsigned long long), stream));
+        KB_HIP_TRY(hipMemsetAsync(cold.sg.totals, 0, 3 * sizeof(unsigned long long), stream));
         cold.sg.entries = reinterpret_cast<SgEntry*>(wc + slot_bytes + 256);
         cold.sg.lh = reinterpret_cast<float*>(wc + slot_bytes + 256 + entry_bytes);
         cold.sg.flux = reinterpret_cast<float*>(wc + slot_bytes + 256 + entry_bytes + out_bytes);
@@ -827,12 +827,14 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                                                : (which == 1 ? stats_out->num_evals * 2ull * (uint64_t)meta->block_size : 0ull);
         stats_out->sigmag_work_items = 0;
         stats_out->sigmag_trajectories = 0;
+        stats_out->sigmag_literal = 0;
         if (cold.sg.totals != nullptr) {
-            unsigned long long totals[2] = {0, 0};
+            unsigned long long totals[3] = {0, 0, 0};
             KB_HIP_TRY(hipMemcpyAsync(totals, cold.sg.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
             KB_HIP_TRY(hipStreamSynchronize(stream));
             stats_out->sigmag_work_items = totals[0];
             stats_out->sigmag_trajectories = totals[1];
+            stats_out->sigmag_literal = totals[2];
         }
     } else {
         // kernels.cu:396 -- the reference call is synchronous.

@@ -66,19 +66,6 @@ struct Samples {
     float psi, phi;
 };
 
-__device__ __forceinline__ Samples gather_samples(const ResolveArgs& a, int lane, double tm, bool y_ok, int cy, int x,
-                                                  float vx) {
-    Samples s;
-    s.psi = NAN;
-    s.phi = NAN;
-    if (lane < a.T) {
-        int cx;
-        const bool x_ok = predict_index(x, vx, tm, &cx);
-        if (x_ok && y_ok) read_psi_phi(a.meta, a.psi_phi, (uint64_t)lane, cy, cx, &s.psi, &s.phi);
-    }
-    return s;
-}
-
 // Clip of ONE trajectory by the whole wavefront (T <= 64, all 64 lanes active).  Returns false when a
 // run of equal ratios mixes different (psi, phi) pairs: the exchange sort's own order then matters
 // and the caller runs the literal code for that lane.
@@ -143,18 +130,139 @@ __device__ __forceinline__ bool clip_wave(const ResolveArgs& a, int lane, const 
     return true;
 }
 
+// The same clip for stacks of 65 .. 64 * E epochs: lane l holds epochs l, l + 64, ... (E slots), the
+// network sorts 64 * E keys (wave_ops.h), sorted position p lives in slot p / 64 of lane p % 64, and the
+// chained sums carry from one slot's lane 63 into the next slot's lane 0.
+template <int E>
+__device__ __forceinline__ float slot_value(const float (&v)[E], int pos) {  // pos: wave-uniform
+    float r = 0.0f;
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+        if ((pos >> 6) == s) r = lane_value(v[s], pos & 63);
+    }
+    return r;
+}
+
+template <int E>
+__device__ __forceinline__ bool clip_wave_multi(const ResolveArgs& a, int lane, const float (&psi)[E], const float (&phi)[E],
+                                                float* lh_out, float* flux_out, int* obs_out) {
+    uint32_t key[E], src[E];
+    int n = 0;
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+        const bool valid = __builtin_isfinite(psi[s]) && __builtin_isfinite(phi[s]);
+        n += __popcll(__ballot(valid));
+        const float lc = valid ? ((phi[s] != 0.0f) ? (psi[s] / phi[s]) : 0.0f) : 0.0f;
+        key[s] = valid ? ratio_sort_key(lc) : 0xffffffffu;  // invalid samples sort behind every ratio
+        src[s] = (uint32_t)(s * WAVE + lane);
+    }
+    *obs_out = n;
+    if (n == 0) {  // kernels.cu:201: nothing to clip, the unclipped values stand
+        *lh_out = -1.0f;
+        *flux_out = -1.0f;
+        return true;
+    }
+    wave_sort_multi<E>(key, src, lane);
+    // sorted position p = s * 64 + lane now holds the p-th smallest ratio and the epoch it came from
+    float spsi[E], sphi[E], sv[E];
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+        float gp = 0.0f, gf = 0.0f;
+#pragma unroll
+        for (int u = 0; u < E; ++u) {  // the sample sits in slot u = src / 64 of lane src % 64
+            const float cp = __shfl(psi[u], (int)(src[s] & 63u)), cf = __shfl(phi[u], (int)(src[s] & 63u));
+            if ((src[s] >> 6) == (uint32_t)u) {
+                gp = cp;
+                gf = cf;
+            }
+        }
+        spsi[s] = gp;
+        sphi[s] = gf;
+        sv[s] = ratio_from_key(key[s]);
+    }
+    // a run of equal ratios made of different (psi, phi) pairs: the exchange sort's own order matters
+    bool mixed_tie = false;
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+        uint32_t k_next = lane_next(key[s]), p_next = lane_next(__float_as_uint(spsi[s])),
+                 f_next = lane_next(__float_as_uint(sphi[s]));
+        if (s + 1 < E && lane == WAVE - 1) {  // the neighbour of lane 63 is lane 0 of the next slot
+            k_next = (uint32_t)__builtin_amdgcn_readlane((int)key[s + 1 < E ? s + 1 : s], 0);
+            p_next = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(spsi[s + 1 < E ? s + 1 : s]), 0);
+            f_next = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(sphi[s + 1 < E ? s + 1 : s]), 0);
+        }
+        const int pos = s * WAVE + lane;
+        mixed_tie = mixed_tie || ((pos + 1 < n) && key[s] == k_next &&
+                                  (p_next != __float_as_uint(spsi[s]) || f_next != __float_as_uint(sphi[s])));
+    }
+    if (__ballot(mixed_tie) != 0) return false;
+
+    float sgl0 = a.params.sgl_L, sgl1 = a.params.sgl_H;
+    if ((double)sgl0 < 0.0001) sgl0 = (float)0.0001;
+    if ((double)sgl1 > 0.9999) sgl1 = (float)0.9999;
+    int pct_L = (int)((double)ceilf((float)n * sgl0) + 0.001) - 1;
+    pct_L = (pct_L < 0) ? 0 : pct_L;
+    pct_L = (pct_L >= n) ? (n - 1) : pct_L;
+    int pct_H = (int)((double)ceilf((float)n * sgl1) + 0.001) - 1;
+    pct_H = (pct_H < 0) ? 0 : pct_H;
+    pct_H = (pct_H >= n) ? (n - 1) : pct_H;
+    int median_ind = (int)(ceil((double)n * 0.5) + 0.001) - 1;
+    median_ind = (median_ind < 0) ? 0 : median_ind;
+    median_ind = (median_ind >= n) ? (n - 1) : median_ind;
+    pct_L = __builtin_amdgcn_readfirstlane(pct_L);
+    pct_H = __builtin_amdgcn_readfirstlane(pct_H);
+    median_ind = __builtin_amdgcn_readfirstlane(median_ind);
+    const float sigma_g = a.params.sigmag_coeff * (slot_value<E>(sv, pct_H) - slot_value<E>(sv, pct_L));
+    const float wsg = 2.0f * sigma_g;
+    const float vmed = slot_value<E>(sv, median_ind);
+    const float min_value = vmed - wsg;
+    const float max_value = vmed + wsg;
+    int below = 0, upto = 0;
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+        const int pos = s * WAVE + lane;
+        below += __popcll(__ballot((pos < n) && (sv[s] < min_value)));
+        upto += __popcll(__ballot((pos < n) && (sv[s] <= max_value)));
+    }
+    const int min_keep = min(below, median_ind);
+    const int max_keep = max(median_ind + 1, upto) - 1;
+    // ((0 + v[min_keep]) + v[min_keep + 1]) + ... + v[max_keep], chained across the lanes, slot after slot
+    float sum_psi = 0.0f, sum_phi = 0.0f;
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+        const int lo = max(min_keep, s * WAVE) - s * WAVE, hi = min(max_keep, s * WAVE + WAVE - 1) - s * WAVE;
+        if (lo <= hi) {  // uniform
+            float acc_psi = 0.0f, acc_phi = 0.0f;
+            for (int i = lo; i <= hi; ++i) {
+                acc_psi = chain_add_carry(acc_psi, spsi[s], sum_psi);
+                acc_phi = chain_add_carry(acc_phi, sphi[s], sum_phi);
+            }
+            sum_psi = lane_value(acc_psi, hi);
+            sum_phi = lane_value(acc_phi, hi);
+        }
+    }
+    *lh_out = lh_from_sums(sum_psi, sum_phi);
+    *flux_out = flux_from_sums(sum_psi, sum_phi);
+    return true;
+}
+
 constexpr int CLIP_BLOCK = 256;
 
+// E: epochs per lane of the cooperative clip (1: up to 64 epochs, 2: up to 128, 4: up to 256); beyond 64 * E epochs
+// every trajectory takes the literal per-lane code.
+template <int E>
 __global__ __launch_bounds__(CLIP_BLOCK) void kb_sigmag_clip_kernel(const ResolveArgs a) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (CLIP_BLOCK / WAVE) + (threadIdx.x >> 6)));
     const int n_waves = gridDim.x * (CLIP_BLOCK / WAVE);
     const int n_entries = *a.sg.n_entries;
-    const bool cooperative = a.T <= WAVE;
-    const double tm = (lane < a.T) ? a.times[lane] : 0.0;
+    const bool cooperative = a.T <= E * WAVE;
+    double tm[E];
+#pragma unroll
+    for (int s = 0; s < E; ++s) tm[s] = (s * WAVE + lane < a.T) ? a.times[s * WAVE + lane] : 0.0;
     const SigmaGScratch<WAVE> scratch = make_scratch(a.sg_scratch, a.T, (size_t)wave, lane);
 
-    unsigned long long n_clipped = 0;
+    unsigned long long n_clipped = 0, n_literal = 0;
     for (int e = wave; e < n_entries; e += n_waves) {
         const SgEntry ent = a.sg.entries[e];
         const uint64_t mask = ent.mask;
@@ -167,20 +275,53 @@ __global__ __launch_bounds__(CLIP_BLOCK) void kb_sigmag_clip_kernel(const Resolv
         uint64_t literal = mask;
         if (cooperative) {
             literal = 0;
-            int cy = 0;
-            const bool y_ok = (lane < a.T) && predict_index(y, vy, tm, &cy);
+            int cy[E];
+            bool y_ok[E];
+#pragma unroll
+            for (int s = 0; s < E; ++s) {
+                cy[s] = 0;
+                y_ok[s] = (s * WAVE + lane < a.T) && predict_index(y, vy, tm[s], &cy[s]);
+            }
+            auto gather = [&](int x, float (&psi)[E], float (&phi)[E]) {
+#pragma unroll
+                for (int s = 0; s < E; ++s) {
+                    psi[s] = NAN;
+                    phi[s] = NAN;
+                    const int t = s * WAVE + lane;
+                    if (t < a.T) {
+                        int cx;
+                        const bool x_ok = predict_index(x, vx, tm[s], &cx);
+                        if (x_ok && y_ok[s]) read_psi_phi(a.meta, a.psi_phi, (uint64_t)t, cy[s], cx, &psi[s], &phi[s]);
+                    }
+                }
+            };
             // the samples of the next trajectory are fetched while this one is sorted
             uint64_t m = mask;
             int L = __ffsll((unsigned long long)m) - 1;
-            Samples cur = gather_samples(a, lane, tm, y_ok, cy, x0 + L, vx);
+            float cur_psi[E], cur_phi[E];
+            gather(x0 + L, cur_psi, cur_phi);
             while (m != 0) {
                 m &= m - 1;
                 const int L_next = (m != 0) ? __ffsll((unsigned long long)m) - 1 : L;
-                Samples nxt = cur;
-                if (m != 0) nxt = gather_samples(a, lane, tm, y_ok, cy, x0 + L_next, vx);
+                float nxt_psi[E], nxt_phi[E];
+#pragma unroll
+                for (int s = 0; s < E; ++s) {
+                    nxt_psi[s] = cur_psi[s];
+                    nxt_phi[s] = cur_phi[s];
+                }
+                if (m != 0) gather(x0 + L_next, nxt_psi, nxt_phi);
                 float r_lh, r_flux;
                 int r_obs;
-                if (clip_wave(a, lane, cur, &r_lh, &r_flux, &r_obs)) {
+                bool done;
+                if constexpr (E == 1) {
+                    Samples one;
+                    one.psi = cur_psi[0];
+                    one.phi = cur_phi[0];
+                    done = clip_wave(a, lane, one, &r_lh, &r_flux, &r_obs);
+                } else {
+                    done = clip_wave_multi<E>(a, lane, cur_psi, cur_phi, &r_lh, &r_flux, &r_obs);
+                }
+                if (done) {
                     if (lane == L) {
                         lh = r_lh;
                         flux = r_flux;
@@ -189,10 +330,15 @@ __global__ __launch_bounds__(CLIP_BLOCK) void kb_sigmag_clip_kernel(const Resolv
                 } else {
                     literal |= 1ull << L;
                 }
-                cur = nxt;
+#pragma unroll
+                for (int s = 0; s < E; ++s) {
+                    cur_psi[s] = nxt_psi[s];
+                    cur_phi[s] = nxt_phi[s];
+                }
                 L = L_next;
             }
         }
+        n_literal += (unsigned long long)__popcll(literal);
         if ((literal >> lane) & 1) {  // kernels.cu:154-242 as written, one trajectory per lane
             kb_trajectory trj;
             trj.x = x0 + lane;
@@ -214,6 +360,7 @@ __global__ __launch_bounds__(CLIP_BLOCK) void kb_sigmag_clip_kernel(const Resolv
     if (lane == 0) {
         if (wave == 0) atomicAdd(&a.sg.totals[0], (unsigned long long)n_entries);
         if (n_clipped != 0) atomicAdd(&a.sg.totals[1], n_clipped);
+        if (n_literal != 0) atomicAdd(&a.sg.totals[2], n_literal);
     }
 }
 
@@ -333,7 +480,13 @@ int launch_sigmag_resolve(const SearchArgs& s, const SearchCold& cold, const Res
     a.tiles_x = s.tiles_x;
     a.n_rows = s.tiles_x * s.sh;
     const int clip_blocks = std::max(1, scratch_waves / (CLIP_BLOCK / WAVE));
-    hipLaunchKernelGGL(kb_sigmag_clip_kernel, dim3(clip_blocks), dim3(CLIP_BLOCK), 0, stream, a);
+    if (a.T <= WAVE || a.T > 4 * WAVE) {  // beyond 256 epochs: the literal code only
+        hipLaunchKernelGGL(kb_sigmag_clip_kernel<1>, dim3(clip_blocks), dim3(CLIP_BLOCK), 0, stream, a);
+    } else if (a.T <= 2 * WAVE) {
+        hipLaunchKernelGGL(kb_sigmag_clip_kernel<2>, dim3(clip_blocks), dim3(CLIP_BLOCK), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(kb_sigmag_clip_kernel<4>, dim3(clip_blocks), dim3(CLIP_BLOCK), 0, stream, a);
+    }
     KB_HIP_TRY(hipGetLastError());
     const dim3 grid((unsigned)((a.n_rows + 3) / 4)), block(256);
     if (a.K <= 8) {

@@ -108,6 +108,60 @@ __device__ __forceinline__ void wave_sort64(uint32_t& key, uint32_t& pay, int la
     merge_block<64>(key, pay, lane);
 }
 
+// Sorting more than 64 keys with one wavefront: E keys per lane, key position p = slot * 64 + lane.
+// The classic bitonic network on 64 * E positions: distances below 64 exchange between lanes (the moves
+// above), distances of 64 and more between the registers of one lane.
+template <int J>
+__device__ __forceinline__ void exchange_between_lanes(uint32_t& key, uint32_t& pay, bool descending, int lane) {
+    const uint32_t pkey = lane_xor<J>(key, lane), ppay = lane_xor<J>(pay, lane);
+    const bool keep_larger = ((lane & J) != 0) != descending;
+    const uint32_t lo = min(key, pkey), hi = max(key, pkey);
+    const uint32_t nk = keep_larger ? hi : lo;
+    pay = (nk != key) ? ppay : pay;
+    key = nk;
+}
+
+template <int E>
+__device__ __forceinline__ void wave_sort_multi(uint32_t (&key)[E], uint32_t (&pay)[E], int lane) {
+    static_assert(E == 2 || E == 4, "keys per lane");
+    constexpr int N = 64 * E;
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {  // partners are registers of the same lane: slots s and s ^ (j / 64)
+                constexpr int unused = 0;
+                (void)unused;
+#pragma unroll
+                for (int s = 0; s < E; ++s) {
+                    const int t = s ^ (j >> 6);
+                    if (t > s) {
+                        const bool descending = ((s * 64) & k) != 0;  // (p & k), the lane bits are below 64 <= j < k
+                        const bool swap = descending ? (key[s] < key[t]) : (key[s] > key[t]);
+                        const uint32_t ks = swap ? key[t] : key[s], kt = swap ? key[s] : key[t];
+                        const uint32_t ps = swap ? pay[t] : pay[s], pt = swap ? pay[s] : pay[t];
+                        key[s] = ks;
+                        key[t] = kt;
+                        pay[s] = ps;
+                        pay[t] = pt;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < E; ++s) {
+                    const bool descending = (((s * 64) | lane) & k) != 0;
+                    if (j == 32) exchange_between_lanes<32>(key[s], pay[s], descending, lane);
+                    if (j == 16) exchange_between_lanes<16>(key[s], pay[s], descending, lane);
+                    if (j == 8) exchange_between_lanes<8>(key[s], pay[s], descending, lane);
+                    if (j == 4) exchange_between_lanes<4>(key[s], pay[s], descending, lane);
+                    if (j == 2) exchange_between_lanes<2>(key[s], pay[s], descending, lane);
+                    if (j == 1) exchange_between_lanes<1>(key[s], pay[s], descending, lane);
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t lane_next(uint32_t v) {  // lane i <- lane i + 1 (lane 63: 0)
     return dpp_move<DPP_WAVE_SHL1>(v);
 }
@@ -117,6 +171,12 @@ __device__ __forceinline__ uint32_t lane_next(uint32_t v) {  // lane i <- lane i
 // sequential sum of m consecutive lanes without moving a value through a scalar register.
 __device__ __forceinline__ float chain_add(float acc, float y) {
     const float prev = __uint_as_float(dpp_move<DPP_WAVE_SHR1>(__float_as_uint(acc)));
+    return prev + y;
+}
+// The same step with a carry entering at lane 0 (the running sum of the 64 positions before this slot).
+__device__ __forceinline__ float chain_add_carry(float acc, float y, float carry) {
+    const float prev = __int_as_float(
+            __builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(acc), DPP_WAVE_SHR1, 0xf, 0xf, false));
     return prev + y;
 }
 

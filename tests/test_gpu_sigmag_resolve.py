@@ -89,7 +89,7 @@ def test_sigma_g_candidate_batches(kb, orc, kern, cap, monkeypatch):
 @pytest.mark.parametrize("kern", [DIRECT, LDS])
 @pytest.mark.parametrize("num_bytes", [-1, 2])
 def test_sigma_g_equal_ratios_from_different_pairs(kb, orc, kern, num_bytes):
-    # Epochs t and t + 6 hold the same science image under variances that differ by a power of two: for a
+    # Epochs t and t + 6 hold the same science image under variances that differ by a factor of four: for a
     # trajectory that does not move, psi/phi of the two epochs is EQUAL while (psi, phi) differ, so the
     # permutation the reference's exchange sort leaves among the equal ratios decides the summation order.
     # The cooperative clip must hand these to the literal code.
@@ -97,13 +97,54 @@ def test_sigma_g_equal_ratios_from_different_pairs(kb, orc, kern, num_bytes):
     T, H, W = 12, 24, 70
     st = util.make_stack(T, H, W, seed=41, noise=1.0)
     for t in range(6):
-        st.sci[t + 6][:, :] = st.sci[t] * np.float32(4.0)
+        st.sci[t + 6][:, :] = st.sci[t]  # psi and phi of epoch t + 6 are those of epoch t divided by 4, exactly
         st.var[t][:, :] = np.float32(1.0)
         st.var[t + 6][:, :] = np.float32(4.0)
     fd.add_fake_object(st, 30, 10, 0.0, 0.0, flux=40.0)
     vx = np.array([0.0, 0.0, 1.5, 0.0, -2.0, 0.3, 0.0, 4.0, 0.0], dtype=np.float32)
     vy = np.array([0.0, 1.0, 0.0, -0.7, 0.5, 0.0, 2.5, 1.0, 0.0], dtype=np.float32)
     cfg = {"sigmag": (0.25, 0.75, 0.7413, -100.0), "min_obs": 4, "K": 4}
-    got, exp, _ = util.run_both(kb, orc, st, vx, vy, cfg, num_bytes=num_bytes, flags=kern)
+    got, exp, s = util.run_both(kb, orc, st, vx, vy, cfg, num_bytes=num_bytes, flags=kern)
     _check(got, exp)
     assert len(got) > 0
+    stats = s.last_search_stats()
+    assert stats["sigmag_literal"] <= stats["sigmag_trajectories"]
+    if num_bytes == -1:
+        # (quantised to uint16 the two epochs' values no longer stand in an exact ratio of four: no ties there)
+        assert stats["sigmag_literal"] > 0
+
+
+@pytest.mark.parametrize("kern", [DIRECT, LDS])
+@pytest.mark.parametrize("T", [65, 100, 128, 129, 200, 256, 257])
+def test_sigma_g_deep_stacks(kb, orc, kern, T):
+    # 65 .. 256 epochs: two or four epochs per lane in the cooperative clip (64-lane sorting network on 128 / 256
+    # keys, sums carried from slot to slot); beyond 256 the literal per-lane code
+    st = util.make_stack(T, 20, 66, seed=1000 + T, noise=2.0, objects=[(9, 7, 4.0, 1.5, 60.0)], mask_fraction=0.04,
+                         times=np.arange(T) / 40.0)
+    vx, vy = fd.kbmod_v1_candidates(8, 1.0, 6.0, 5, 0.0, 0.9)
+    cfg = {"sigmag": (0.25, 0.75, 0.7413, 1.5), "min_obs": T // 3, "K": 4}
+    got, exp, s = util.run_both(kb, orc, st, vx, vy, cfg, flags=kern)
+    _check(got, exp)
+    assert len(got) > 50
+    stats = s.last_search_stats()
+    assert stats["sigmag_trajectories"] > 100
+    # float data without equal ratios: nothing takes the literal code up to 256 epochs, everything beyond
+    assert stats["sigmag_literal"] == (0 if T <= 256 else stats["sigmag_trajectories"])
+
+
+def test_sigma_g_deep_stack_mixed_ties(kb, orc):
+    # the equal-ratio / different-pair construction of the shallow test on 140 epochs (the slot-boundary neighbours
+    # included): the cooperative clip must hand these trajectories to the literal code
+    T, H, W = 140, 16, 66
+    st = util.make_stack(T, H, W, seed=77, noise=1.0)
+    for t in range(70):
+        st.sci[t + 70][:, :] = st.sci[t]
+        st.var[t][:, :] = np.float32(1.0)
+        st.var[t + 70][:, :] = np.float32(4.0)
+    vx = np.array([0.0, 0.0, 0.4, 0.0, -0.3, 0.1, 0.0, 0.6], dtype=np.float32)
+    vy = np.array([0.0, 0.2, 0.0, -0.1, 0.1, 0.0, 0.3, 0.2], dtype=np.float32)
+    cfg = {"sigmag": (0.25, 0.75, 0.7413, -100.0), "min_obs": 4, "K": 4}
+    got, exp, s = util.run_both(kb, orc, st, vx, vy, cfg, flags=LDS)
+    _check(got, exp)
+    assert len(got) > 0
+    assert s.last_search_stats()["sigmag_literal"] > 0
