@@ -91,6 +91,10 @@ int kb_copy_block_between_gpus(void* dst_dev, int32_t dst_device, const void* sr
 /* new: streaming device-to-device copy of `bytes`, `iters` timed passes; *gbps_out = (read + written bytes) / time.
  * The measured HBM peak of the roofline report (bench.py). */
 int kb_measure_copy_bandwidth(uint64_t bytes, int32_t iters, void* stream, double* gbps_out);
+/* new: read-only stream over a block of `bytes`; *gbps_out = bytes read / time.  With a block that fits the 256 MiB
+ * Infinity Cache this is the rate at which that cache feeds the L2s (the ceiling of the cfg2 search, whose 134 MB
+ * array stays resident there). */
+int kb_measure_read_bandwidth(uint64_t bytes, int32_t iters, void* stream, double* gbps_out);
 
 /* ---- PSF convolution: kernels/image_kernels.cu:68-108 (deviceConvolve) --- */
 /* Host image in, host image out, one image.  empty_is_nan = 0 reproduces the

@@ -63,6 +63,7 @@ def load_lib():
     lib.kb_copy_block_to_cpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.kb_copy_block_to_gpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.kb_measure_copy_bandwidth.argtypes = [C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]
+    lib.kb_measure_read_bandwidth.argtypes = [C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]
     lib.kb_debug_wave_ops.argtypes = [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]
     _lib = lib
     return lib

@@ -27,6 +27,26 @@ __global__ __launch_bounds__(256) void kb_copy_kernel(const uint4* __restrict__ 
     }
     for (; i < n; i += stride) dst[i] = src[i];
 }
+
+// Read-only stream over the same block: what the fabric delivers to the L2s without any write traffic (for a
+// block smaller than the Infinity Cache: the rate at which that cache feeds the XCDs).
+__global__ __launch_bounds__(256) void kb_read_kernel(const uint4* __restrict__ src, size_t n, uint32_t* __restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i + 7 * stride < n; i += 8 * stride) {
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    }
+    for (; i < n; i += stride) {
+        const uint4 v = src[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;  // never true for the memset pattern; keeps the loads alive
+}
 }  // namespace kb
 
 extern "C" {
@@ -148,6 +168,36 @@ int kb_measure_copy_bandwidth(uint64_t bytes, int32_t iters, void* stream_v, dou
     KB_HIP_TRY(hipGetLastError());
     if (!(ms > 0.0f)) return fail("measure_copy_bandwidth: no time measured");
     *gbps_out = 2.0 * (double)(n * 16) * iters / ((double)ms * 1e-3) / 1e9;
+    return 0;
+}
+
+// Reads `bytes` (rounded down to 16) `iters` times after one untimed pass; *gbps_out = bytes read / time.
+int kb_measure_read_bandwidth(uint64_t bytes, int32_t iters, void* stream_v, double* gbps_out) {
+    using namespace kb;
+    if (gbps_out == nullptr || iters <= 0 || bytes < 16) return fail("measure_read_bandwidth: bad argument");
+    KB_REQUIRE_DEVICE("the read-bandwidth probe.");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    const size_t n = (size_t)(bytes / 16);
+    void* src = nullptr;
+    KB_HIP_TRY(hipMalloc(&src, n * 16 + 16));
+    (void)hipMemsetAsync(src, 1, n * 16 + 16, stream);
+    uint32_t* sink = reinterpret_cast<uint32_t*>(static_cast<char*>(src) + n * 16);
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+    float ms = 0.0f;
+    {
+        EventTimer timer(stream, true);
+        hipLaunchKernelGGL(kb_read_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4*>(src), n, sink);
+        timer.begin();
+        for (int i = 0; i < iters; ++i) {
+            hipLaunchKernelGGL(kb_read_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4*>(src), n,
+                               sink);
+        }
+        ms = timer.end();
+    }
+    (void)hipFree(src);
+    KB_HIP_TRY(hipGetLastError());
+    if (!(ms > 0.0f)) return fail("measure_read_bandwidth: no time measured");
+    *gbps_out = (double)(n * 16) * iters / ((double)ms * 1e-3) / 1e9;
     return 0;
 }
 

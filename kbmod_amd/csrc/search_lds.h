@@ -4,11 +4,19 @@
 #ifndef KB_SEARCH_LDS_H_
 #define KB_SEARCH_LDS_H_
 
+#include <type_traits>
+
 #include "search_device.h"
 
 #pragma clang fp contract(off)
 
+#ifndef KB_STAGE_DEPTH
+#define KB_STAGE_DEPTH 1
+#endif
+
 namespace kb {
+
+constexpr int STAGE_DEPTH = KB_STAGE_DEPTH;  // staged slabs a wave holds in registers: 1, or 2 (eight more registers)
 
 // Staging map.  A slab (rows x LDS_COLS raw pairs, dense) is copied in workgroup-wide steps of
 // 4 KiB: in step j thread tid moves the 16 bytes at slab offset o = 16 * (tid + 256 j), i.e.
@@ -147,6 +155,8 @@ __device__ __forceinline__ void special_epoch(const SearchArgs& a, const TileCoo
 // Staging schedule of one chunk.
 struct ChunkPlan {
     int slab_bytes;  // rows_max * LDS_COLS * BYTES
+    int stride;      // distance of the group's slabs in LDS: slab_bytes rounded up to a wave's 1 KiB of pieces, so that
+                     // a wave can write all 64 of its pieces without a lane mask
     int E;           // epochs per group
     int clean;       // every epoch is staged with uniform shifts: the summing loop needs no per-epoch test
 };
@@ -155,7 +165,8 @@ __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) 
     ChunkPlan p;
     const ConstIntPtr ci = as_const_ints(&a.chunks[chunk]);  // {dx_min, dx_max, dy_min, dy_max, unsafe, lds_ok, rows_max}
     p.slab_bytes = ci[6] * LDS_COLS * BYTES;
-    p.E = max(1, min(a.T, lds_group_bytes(ROWS) / p.slab_bytes));
+    p.stride = (p.slab_bytes + 1023) & ~1023;
+    p.E = max(1, min(a.T, lds_group_bytes(ROWS) / p.stride));
     p.clean = (ci[4] == 0 && ci[5] != 0) ? 1 : 0;
     return p;
 }
@@ -198,9 +209,9 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
         for (int e = 0; e < n; ++e) {
             const int64_t o = origin_of(org[e]);
             load_slab<BYTES, ROWS>(a, n_sl, tile_base + o, plan.slab_bytes, regs);
-            write_slab<ROWS>(smem + e * plan.slab_bytes, plan.slab_bytes, regs);
+            write_slab<ROWS>(smem + e * plan.stride, plan.slab_bytes, regs);
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            copy_slab_tail<BYTES, ROWS>(a, sl, tile_base + o, plan.slab_bytes, smem + e * plan.slab_bytes, regs);
+            copy_slab_tail<BYTES, ROWS>(a, sl, tile_base + o, plan.slab_bytes, smem + e * plan.stride, regs);
         }
     }
     __syncthreads();
@@ -229,10 +240,10 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             return true;
         };
         auto next_write = [&](int e) {
-            write_slab<ROWS>(nb + e * n_plan.slab_bytes, n_plan.slab_bytes, regs);
+            write_slab<ROWS>(nb + e * n_plan.stride, n_plan.slab_bytes, regs);
             if (n_plan.slab_bytes > LDS_SLOTS * stage_round(ROWS)) {  // uniform, rare
                 __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-                copy_slab_tail<BYTES, ROWS>(a, sl, n_base, n_plan.slab_bytes, nb + e * n_plan.slab_bytes, regs);
+                copy_slab_tail<BYTES, ROWS>(a, sl, n_base, n_plan.slab_bytes, nb + e * n_plan.stride, regs);
             }
         };
 
@@ -240,7 +251,8 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
         const char* cb = smem + buf * lds_group_bytes(ROWS) + lane_b;
         const int n_cur = min(plan.E, T - t0);
         // C samples of one staged epoch with uniform shifts: slab offsets o[] (scalars) -> LDS reads -> sums
-        auto sum_epoch = [&](const int (&o)[C], int e) {
+        auto no_hook = []() {};
+        auto sum_epoch = [&](const int (&o)[C], int e, auto between) {
             // eight reads in flight at a time (a chunk of 16 goes in two halves: the registers of the samples
             // are the ones this kernel is short of)
             constexpr int HALF = 8;
@@ -250,7 +262,12 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
                 for (int c = 0; c < HALF; ++c) {
                     const int off = (BYTES == 8) ? o[c0 + c] : (o[c0 + c] >> 3) * BYTES;
-                    raw[c] = *reinterpret_cast<const typename R::type*>(cb + e * plan.slab_bytes + off);
+                    raw[c] = *reinterpret_cast<const typename R::type*>(cb + e * plan.stride + off);
+                }
+                if (c0 == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    between();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 // one wait for the reads instead of the compiler's one per read (instruction issue is the bound)
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
@@ -290,13 +307,101 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
             for (int c = 0; c < C; ++c) o_cur[c] = offs[c];
             int64_t org_cur = origin_of(n_org[0]);
-            for (int e = 0; e < n_cur; ++e) {
+            int e = 0;
+            // Epochs that both sum and stage, slabs of at most LDS_SLOTS rounds (the rule): the loop is specialised
+            // by the number of rounds in which this wave has pieces inside the slab (wave-uniform, fixed for the
+            // group), so that its body holds no test at all -- loads, sums, table fetch, LDS writes of whole
+            // 1 KiB wave pieces (the slab stride in LDS leaves room for the last one's overhang).
+            const int n_both = (n_plan.slab_bytes <= LDS_SLOTS * stage_round(ROWS)) ? min(n_cur, n_next) : 0;
+            auto staged_run = [&](auto np_tag) {
+                constexpr int NP = decltype(np_tag)::value;
+                char* wdst = nb + 16 * (int)threadIdx.x;
+                int64_t org_nxt = origin_of(n_org[1]);  // origin of the slab whose loads are issued next
+                auto load = [&](Piece (&v)[LDS_SLOTS], int64_t org) {
+                    const char* base = tile_base + org;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        uint32_t off = n_sl.goff[j];
+                        asm volatile("" : "+v"(off));  // (see load_slab)
+                        const PieceMem<(BYTES < 4 ? BYTES : 4)>* src =
+                                reinterpret_cast<const PieceMem<(BYTES < 4 ? BYTES : 4)>*>(base + off);
+                        v[j] = Piece{src->w[0], src->w[1], src->w[2], src->w[3]};
+                    }
+                };
+                // sums of epoch e, then the LDS write of staged slab e out of v
+                auto step = [&](Piece (&v)[LDS_SLOTS]) {
+                    // The table words of the next epoch are fetched right behind the issue of this epoch's LDS reads
+                    // and waited for together with them, i.e. BEFORE the slab is written.  The wait for a scalar
+                    // load is a wait for every LDS operation of the wave; placed behind the write, as it was, it
+                    // holds the next epoch's reads until that write has completed.
+                    sum_epoch(o_cur, e, [&]() {
+                        ConstIntPtr po = offs + (e + 1) * C;
+                        ConstSlabPtr pg = n_org + (e + STAGE_DEPTH);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) o_cur[c] = po[c];
+                        org_nxt = origin_of(pg[0]);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);  // the sums stay in front of the write and its vmcnt wait
+                    if (!FAST) {
+                        // (keeps the counts of two unrolled epochs from being merged into three-operand adds that
+                        // hold eight more registers across the pair)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) asm volatile("" : "+v"(cnt[c]));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) *reinterpret_cast<Piece*>(wdst + stage_round(ROWS) * j) = v[j];
+                    wdst += n_plan.stride;
+                    ++e;
+                };
+                if constexpr (STAGE_DEPTH == 2) {
+                    // Two slabs in flight: the loads of slab e + 1 are issued before the sums of epoch e, the
+                    // registers of slab e (issued an epoch earlier) are written behind them; the two register
+                    // sets swap roles.  Every load in the pair loop is unconditional, so the wait in front of a
+                    // write counts the younger loads (vmcnt(NP)) instead of draining them.
+                    Piece va[LDS_SLOTS], vb[LDS_SLOTS];
+                    load(va, org_cur);
+                    while (e + 2 < n_both) {
+                        load(vb, org_nxt);
+                        step(va);
+                        load(va, org_nxt);
+                        step(vb);
+                    }
+                    if (e + 1 < n_both) {
+                        load(vb, org_nxt);
+                        step(va);
+                        step(vb);
+                    } else {
+                        step(va);
+                    }
+                } else {
+                    Piece va[LDS_SLOTS];
+                    org_nxt = org_cur;
+                    while (e < n_both) {
+                        load(va, org_nxt);
+                        step(va);
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+                org_cur = origin_of(n_org[e]);       // (for the loop below)
+            };
+            if (n_both > 0) {
+                const int wave_piece = 1024 * tc.wv;
+                if (LDS_SLOTS >= 2 && wave_piece + stage_round(ROWS) < n_plan.slab_bytes) {
+                    staged_run(std::integral_constant<int, (LDS_SLOTS >= 2 ? 2 : 1)>{});
+                } else if (wave_piece < n_plan.slab_bytes) {
+                    staged_run(std::integral_constant<int, 1>{});
+                } else {
+                    staged_run(std::integral_constant<int, 0>{});
+                }
+            }
+            // what is left: sums of a group longer than the next one, slabs of more rounds
+            for (; e < n_cur; ++e) {
                 const bool staging = e < n_next;
                 if (staging) {
                     n_base = tile_base + org_cur;
                     load_slab<BYTES, ROWS>(a, n_sl, n_base, n_plan.slab_bytes, regs);
                 }
-                sum_epoch(o_cur, e);
+                sum_epoch(o_cur, e, no_hook);
                 pin_sums();
                 ConstIntPtr po = offs + (e + 1) * C;
                 ConstSlabPtr pg = n_org + (e + 1);
@@ -314,10 +419,10 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
                 for (int c = 0; c < C; ++c) o[c] = offs[e * C + c];
                 if (o[0] >= 0) {
-                    sum_epoch(o, e);
+                    sum_epoch(o, e, no_hook);
                 } else {
                     special_epoch<C, SF, CANON>(a, tc, chunk, t0 + e, o[0] == LDS_OFF_PER_LANE,
-                                                smem + buf * lds_group_bytes(ROWS) + e * plan.slab_bytes, acc, cnt);
+                                                smem + buf * lds_group_bytes(ROWS) + e * plan.stride, acc, cnt);
                 }
                 pin_sums();
                 if (staging) next_write(e);

@@ -7,3 +7,7 @@ for mb in (256, 1024, 4096):
     g = C.c_double()
     capi.check(lib.kb_measure_copy_bandwidth(mb << 20, 10, None, C.byref(g)))
     print(f"{mb} MiB each way: {g.value:.0f} GB/s (read + write)")
+for mb in (32, 128, 200, 512, 4096):
+    g = C.c_double()
+    capi.check(lib.kb_measure_read_bandwidth(mb << 20, 20, None, C.byref(g)))
+    print(f"{mb} MiB read-only: {g.value:.0f} GB/s")
