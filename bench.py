@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--max-vel", type=float, default=40.0)
     ap.add_argument("--min-ang", type=float, default=0.0)
     ap.add_argument("--max-ang", type=float, default=1.5)
+    ap.add_argument("--results-per-pixel", type=int, default=8, help="K (BASELINE: 8); other values for kernel work only")
     ap.add_argument("--inset", type=int, default=0, help="shrink the start-pixel grid by this many pixels per side")
     ap.add_argument("--flags", type=int, default=0, help="kb_device_search_filter flags (1 exact positions, 4 LDS-staged kernel)")
     ap.add_argument("--sigmag", action="store_true",
@@ -152,7 +153,7 @@ def main():
 
     lib = load_lib()
     T, H, W = args.frames, args.size, args.size
-    K = 8
+    K = args.results_per_pixel
 
     sci, var, times, psf = synthetic_stack(torch, dev, T, H, W, args.mask_fraction)
     tcpu = times.cpu().numpy()
@@ -286,7 +287,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{T}x{H}x{W} psi/phi ({'float32' if args.num_bytes in (-1, 4) else 'uint%d' % (8 * args.num_bytes)}), "
-                        f"full {W}x{H} start grid x {n_local} (v,theta) candidates per GPU, K=8, "
+                        f"full {W}x{H} start grid x {n_local} (v,theta) candidates per GPU, K={K}, "
                         f"sigma-G {'on, min_obs %d' % (T // 2) if args.sigmag else 'off'}"
                         + (f", {args.mask_fraction:g} of the science pixels masked" if args.mask_fraction > 0 else ""),
             "frames": T, "height": H, "width": W, "candidates_per_gpu": n_local, "results_per_pixel": K,

@@ -154,6 +154,7 @@ struct SearchArgs {
     const int* lds_off;        // [n_chunks][T][C] byte offset of the shifted tile inside the slab
     const int* global_box;     // {dx_min, dx_max, dy_min, dy_max, rows_max} over every (candidate, epoch)
     const int* n_invalid;      // device counter: non-zero when the image holds NO_DATA pixels (kb_pad_kernel)
+    uint2* lists;              // kb_search_lds: per-pixel lists between chunks, [tile][slot][thread of the tile] of (lh bits, candidate)
     int T, W, H, Wp;
     int n_cands, n_chunks;
     int chunk_lo, chunk_hi;    // candidate chunks [chunk_lo, chunk_hi) of this launch
@@ -297,6 +298,28 @@ struct TopK {
             id[s] = -1;
         }
     }
+    // The list of a thread in the lane-interleaved store of kb_search_lds: slot s of the tile at
+    // tile_list + s * stride_bytes (uniform: scalar arithmetic) plus the thread's own 32-bit offset -- one
+    // address register for the whole list instead of a 64-bit pointer per slot.
+    __device__ __forceinline__ void load(const char* tile_list, uint32_t lane_off, int stride_bytes) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint32_t off = lane_off;
+            asm volatile("" : "+v"(off));
+            const uint2 v = *reinterpret_cast<const uint2*>(tile_list + (size_t)s * stride_bytes + off);
+            lh[s] = __uint_as_float(v.x);
+            id[s] = (int)v.y;
+        }
+    }
+    __device__ __forceinline__ void store(char* tile_list, uint32_t lane_off, int stride_bytes) const {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint32_t off = lane_off;
+            asm volatile("" : "+v"(off));
+            *reinterpret_cast<uint2*>(tile_list + (size_t)s * stride_bytes + off) =
+                    make_uint2(__float_as_uint(lh[s]), (uint32_t)id[s]);
+        }
+    }
     // kernels.cu:323-330: strict '>' swap-down, reproduced slot by slot.
     __device__ __forceinline__ void insert(float cand_lh, int cand) {
         if (cand_lh > lh[KS - 1]) {
@@ -314,6 +337,13 @@ struct TopK {
             }
         }
     }
+};
+
+// What kb_search_lds keeps in registers of a thread's list while it sums the next chunk: the likelihood a candidate
+// has to beat, and whether the list exists in the store yet (wave-uniform).
+struct ListState {
+    float threshold;
+    int stored;
 };
 
 // Lane-interleaved scratch of the literal sigma-G clip for the wave in slot wave_slot of its launch

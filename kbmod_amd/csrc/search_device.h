@@ -87,6 +87,40 @@ __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoor
     }
 }
 
+// finish_chunk for kb_search_lds without the sigma-G filter.  The per-pixel lists are touched once per chunk of C
+// candidates, i.e. once per C x T samples: kept in registers they would cost the summing loop 2 KS registers for
+// nothing.  They live in a lane-interleaved store in HBM (L2-resident in practice) instead; the loop carries the
+// likelihood to beat.  A wave none of whose lanes has a candidate above its threshold does not touch the store.
+template <int KS, int C>
+__device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chunk, float (&ps)[C], const float (&ph)[C],
+                                                    const int (&cnt)[C], ListState& ls, char* tile_list, uint32_t lane_off,
+                                                    int stride_bytes) {
+    // likelihoods one after the other (see finish_chunk); a candidate that may not enter (past the end of the
+    // list, too few observations) becomes -FLT_MAX, which the insertion's strict '>' never admits
+    bool beats = false;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float p = ps[c], f = ph[c];
+        asm volatile("" : "+v"(p), "+v"(f), "+v"(ls.threshold));
+        const bool real = (chunk * C + c) < a.n_cands;  // uniform
+        const float lh = (real && !(cnt[c] < a.min_obs)) ? lh_from_sums(p, f) : -FLT_MAX;
+        ps[c] = lh;
+        beats = beats || (lh > ls.threshold);
+    }
+    if (__ballot(beats) == 0) return;  // uniform
+    TopK<KS> top;
+    if (ls.stored) {
+        top.load(tile_list, lane_off, stride_bytes);
+    } else {
+        top.init();
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) top.insert(ps[c], chunk * C + c);
+    top.store(tile_list, lane_off, stride_bytes);
+    ls.stored = 1;
+    ls.threshold = top.lh[KS - 1];
+}
+
 // Epilogue (no sigma-G; with it kb_sigmag_select_kernel writes the results): the K winners are
 // re-evaluated with exact per-lane positions to produce flux / obs_count; the likelihood this yields
 // is bit-identical to the one that won the slot.
@@ -111,6 +145,25 @@ __device__ __forceinline__ void write_results(const SearchArgs& a, const TileCoo
     }
 }
 
+
+// The epilogue of kb_search_lds: the winners' candidate indices come out of the list store slot by slot (nothing of
+// the list is held across the exact re-evaluation, the register-hungriest code of the kernel).
+__device__ __forceinline__ void write_results_stored(const SearchArgs& a, const TileCoords& tc, const ListState& ls,
+                                                     const char* tile_list, uint32_t lane_off, int stride_bytes) {
+    if (tc.x_i >= a.sw || !tc.row_active) return;
+    const size_t slot0 = ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
+    for (int s = 0; s < a.K; ++s) {
+        const int id_s = ls.stored ? (int)reinterpret_cast<const uint2*>(tile_list + (size_t)s * stride_bytes + lane_off)->y : -1;
+        kb_trajectory res = placeholder_result(tc.x, tc.y);  // kernels.cu:293-301
+        if (id_s >= 0) {
+            res.vx = a.cold->cands[id_s].vx;
+            res.vy = a.cold->cands[id_s].vy;
+            evaluate_trajectory_full<WAVE>(a.cold->meta, a.psi_phi, a.cold->times, a.cold->params, &res,
+                                           static_cast<const SigmaGScratch<WAVE>*>(nullptr));
+        }
+        store_result(a.cold->results, slot0 + s, res, id_s);
+    }
+}
 
 // MODE 0: interior wave, table shifts, no per-lane bounds test.
 // MODE 1: table shifts with per-lane bounds test (image edges / off-image starts).

@@ -379,9 +379,9 @@ struct Workspace {
 // different host threads (StackSearch's fan-out), searches on one device one after the other.
 constexpr int MAX_DEVICES = 64;
 static std::mutex g_ws_mutex[MAX_DEVICES];
-static Workspace g_ws_all[MAX_DEVICES][6];  // 0: shift table + chunk info, 1: literal sigma-G scratch, 2: padded array copy (LDS kernel),
+static Workspace g_ws_all[MAX_DEVICES][7];  // 0: shift table + chunk info, 1: literal sigma-G scratch, 2: padded array copy (LDS kernel),
                             // 3: sigma-G work items + clipped values, 4: second per-pixel list buffer (sigma-G batches),
-                            // 5: cold block of the kernel arguments
+                            // 5: cold block of the kernel arguments, 6: per-pixel lists of kb_search_lds between chunks
 
 static int current_device_slot() {
     int dev = 0;
@@ -557,12 +557,12 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     a.sw = (int)sw;
     a.sh = (int)sh;
     a.tiles_x = (a.sw + WAVE - 1) / WAVE;
-    // Tile height of kb_search_lds: 64 x 16 for lists of up to 8 (and the sigma-G emit) when the search area
+    // Tile height of kb_search_lds: 64 x 16 when the search area
     // gives every CU a tile of that size, 64 x 8 otherwise; flags bits 6 / 7 force one or the other (tests).
     // Encoded staging is built for 64 x 8 only.
     int lds_rows = LDS_ROWS_WIDE_K;
     {
-        const bool list_fits = params.do_sigmag_filter != 0 || params.results_per_pixel <= 8;
+        const bool list_fits = params.do_sigmag_filter != 0 || params.results_per_pixel <= 32;  // (kb_search_large_k beyond)
         const int64_t tall_tiles = (int64_t)a.tiles_x * ((sh + LDS_ROWS_TALL - 1) / LDS_ROWS_TALL);
         const bool keep_encoded = meta->num_bytes != 4 && (flags & 16u) != 0;
         if (list_fits && !keep_encoded && ((tall_tiles >= 128 && (flags & 128u) == 0) || (flags & 64u) != 0)) {
@@ -765,6 +765,16 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     if (ensure_workspace(5, sizeof(SearchCold), &cold_dev)) return 1;
     a.cold = reinterpret_cast<const SearchCold*>(cold_dev);
     KB_HIP_TRY(hipMemcpyAsync(cold_dev, &cold, sizeof(SearchCold), hipMemcpyHostToDevice, stream));
+
+    a.lists = nullptr;
+    if (which != 0 && !sigmag && a.K > 8 && a.K <= 32) {
+        // the lists of kb_search_lds between chunks: slots x threads of every tile, 8 bytes each
+        const SearchArgs at = with_tile_rows(a, lds_rows);
+        const int ks = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
+        void* lists = nullptr;
+        if (ensure_workspace(6, (size_t)at.n_tiles * ks * block_threads(lds_rows) * sizeof(uint2), &lists)) return 1;
+        a.lists = reinterpret_cast<uint2*>(lists);
+    }
 
     search_timer.begin();
     int variant;

@@ -152,6 +152,18 @@ __device__ __forceinline__ void special_epoch(const SearchArgs& a, const TileCoo
     }
 }
 
+// The per-pixel lists of a tile.  Up to 8 results per pixel they stay in registers (16 per thread).  Longer lists
+// would cost the kernel its 4 waves per SIMD: they live in a lane-interleaved store in HBM between chunks
+// (finish_chunk_stored), the summing loop carries only the likelihood to beat.  (Measured for K = 8, cfg2: registers
+// 5.13 ms, store 5.41 ms -- the store's round trip once per chunk is exposed.)
+template <int KS>
+struct TileLists {
+    static constexpr bool STORED = KS > 8;
+    TopK<KS> top;     // !STORED
+    ListState state;  // STORED
+    char* store;      // STORED: this tile's block of the store (uniform)
+};
+
 // Staging schedule of one chunk.
 struct ChunkPlan {
     int slab_bytes;  // rows_max * LDS_COLS * BYTES
@@ -179,7 +191,7 @@ __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) 
 // every shift, the array has no NO_DATA pixel, every epoch is staged): obs_count is T.
 template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, bool FAST>
 __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileCoords& tc, char* smem,
-                                                const StageLane& sl, TopK<KS>& top) {
+                                                const StageLane& sl, TileLists<KS>& lists) {
     constexpr int SF = CANON ? 4 : NB;  // staged format
     using R = RawPair<SF>;
     constexpr int BYTES = 2 * fmt_bytes(SF);
@@ -443,7 +455,14 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     ph[c] = acc[c].y;
                     if (FAST) cnt[c] = T;
                 }
-                finish_chunk<KS, C, SIGMAG>(a, tc, chunk, ps, ph, cnt, top);
+                if constexpr (SIGMAG) {
+                    TopK<KS> none;  // (the emitting instances keep no list)
+                    finish_chunk<KS, C, true>(a, tc, chunk, ps, ph, cnt, none);
+                } else if constexpr (TileLists<KS>::STORED) {
+                    finish_chunk_stored<KS, C>(a, chunk, ps, ph, cnt, lists.state, lists.store, 8u * threadIdx.x, ROWS * WAVE * 8);
+                } else {
+                    finish_chunk<KS, C, false>(a, tc, chunk, ps, ph, cnt, lists.top);
+                }
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
@@ -461,14 +480,17 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 
 
 template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG>
-// second launch bound = waves per SIMD: 16 waves per CU (one 64 x 16 or two 64 x 8 workgroups) for K <= 8,
-// one 64 x 8 workgroup with twice the registers beyond
-__global__ __launch_bounds__(ROWS * WAVE, (KS <= 8 ? 4 : 2)) void kb_search_lds(const SearchArgs a) {
+// second launch bound = waves per SIMD: 16 waves per CU (one 64 x 16 or two 64 x 8 workgroups)
+__global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // two group buffers
     constexpr int BYTES = 2 * fmt_bytes(CANON ? 4 : NB);
     const TileCoords tc = tile_coords<ROWS>(a);  // rows past the search area stay alive (barriers)
-    TopK<KS> top;
-    top.init();
+    TileLists<KS> lists;
+    lists.top.init();
+    lists.state = {-FLT_MAX, 0};
+    lists.store = (SIGMAG || !TileLists<KS>::STORED)
+                          ? nullptr
+                          : reinterpret_cast<char*>(a.lists) + ((size_t)(tc.ty * a.tiles_x + tc.tx) * KS) * (ROWS * WAVE * 8);
 
     StageLane sl;
 #pragma unroll
@@ -484,11 +506,17 @@ __global__ __launch_bounds__(ROWS * WAVE, (KS <= 8 ? 4 : 2)) void kb_search_lds(
                       (tc.tile_x0 + WAVE + gb[1] <= a.W) && (tc.tile_y0 + gb[2] >= 0) &&
                       (tc.tile_y0 + ROWS + gb[3] <= a.H);
     if (fast) {
-        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, true>(a, tc, smem, sl, top);
+        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, true>(a, tc, smem, sl, lists);
     } else {
-        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, false>(a, tc, smem, sl, top);
+        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, false>(a, tc, smem, sl, lists);
     }
-    if constexpr (!SIGMAG) write_results<KS>(a, tc, top);
+    if constexpr (!SIGMAG) {
+        if constexpr (TileLists<KS>::STORED) {
+            write_results_stored(a, tc, lists.state, lists.store, 8u * threadIdx.x, ROWS * WAVE * 8);
+        } else {
+            write_results<KS>(a, tc, lists.top);
+        }
+    }
 }
 
 // Launch of one instance (two group buffers beyond the default 64 KiB of dynamic LDS need the attribute raised).

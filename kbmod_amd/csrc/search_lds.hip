@@ -20,9 +20,17 @@ void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, hipStre
             launch_lds<8, LDS_ROWS_WIDE_K, 4, true, false>(a, stream);
         }
     } else if (a.K <= 16) {
-        launch_lds<16, LDS_ROWS_WIDE_K, 4, true, false>(a, stream);
+        if (tall) {
+            launch_lds<16, LDS_ROWS_TALL, 4, true, false>(a, stream);
+        } else {
+            launch_lds<16, LDS_ROWS_WIDE_K, 4, true, false>(a, stream);
+        }
     } else {
-        launch_lds<32, LDS_ROWS_WIDE_K, 4, true, false>(a, stream);
+        if (tall) {
+            launch_lds<32, LDS_ROWS_TALL, 4, true, false>(a, stream);
+        } else {
+            launch_lds<32, LDS_ROWS_WIDE_K, 4, true, false>(a, stream);
+        }
     }
 }
 
