@@ -22,7 +22,10 @@ constexpr int SHIFT_UNSAFE = INT32_MIN;  // dx marker: no uniform shift proven f
 #define KB_CHUNK 8
 #endif
 constexpr int CHUNK = KB_CHUNK;    // candidates accumulated together per wave
-constexpr int DIRECT_ROWS = 4;     // kb_search_direct / kb_search_large_k
+#ifndef KB_DIRECT_ROWS
+#define KB_DIRECT_ROWS 4
+#endif
+constexpr int DIRECT_ROWS = KB_DIRECT_ROWS;  // kb_search_direct / kb_search_large_k
 constexpr int LDS_ROWS_TALL = 16;  // kb_search_lds, K <= 8 (and the sigma-G emit)
 constexpr int LDS_ROWS_WIDE_K = 8; // kb_search_lds, 8 < K <= 32; also small search areas
 __host__ __device__ constexpr int block_threads(int rows) { return rows * WAVE; }

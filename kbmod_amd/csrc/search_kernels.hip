@@ -642,7 +642,9 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                              "y [%d, %d], tallest slab %d rows\n",
                              (unsigned long long)n_epochs, back[0], back[6], back[1], back[2], back[3], back[4], back[5]);
             }
-            if (back[1] <= back[2] && (uint64_t)back[0] * 10ull <= n_epochs) {
+            uint64_t unstaged_limit = 10;  // staged unless more than 1 / limit of the (chunk, epoch) pairs cannot be
+            if (const char* env = std::getenv("KBMOD_UNSTAGED_LIMIT")) unstaged_limit = std::max<uint64_t>(1, std::strtoull(env, nullptr, 10));
+            if (back[1] <= back[2] && (uint64_t)back[0] * unstaged_limit <= n_epochs) {
                 // Every slab [origin, origin + rows_max) x [origin, origin + LDS_COLS) lies inside the padded frame.
                 // (the zero shift is included: unstaged epochs copy the slab at the tile's own pixel)
                 back[1] = std::min(back[1], 0);
