@@ -246,6 +246,11 @@ def main():
     # measured HBM peak: a streaming device copy (4 GiB each way) timed with HIP events in this run
     copy_gbps = C.c_double(0.0)
     check(lib, lib.kb_measure_copy_bandwidth(4 << 30, 10, stream, C.byref(copy_gbps)))
+    # ... and what a read-only stream over a block of the array's size reaches (no write traffic; for cfg2's 134 MB
+    # this is the rate at which the Infinity Cache feeds the L2s): the ceiling of the search's fabric traffic,
+    # which is 99 % reads
+    read_gbps = C.c_double(0.0)
+    check(lib, lib.kb_measure_read_bandwidth(min(int(T) * H * W * 8, 4 << 30), 20, stream, C.byref(read_gbps)))
 
     # fabric-side traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (it cannot be
     # read from inside this process); attached when the workload matches a profiled configuration.
@@ -316,6 +321,8 @@ def main():
             "hbm_measured_peak": float(copy_gbps.value),
             "fabric_GBps": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9,
             "fabric_frac_of_measured_peak": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9 / copy_gbps.value,
+            "read_measured_peak": float(read_gbps.value),
+            "fabric_frac_of_read_peak": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9 / read_gbps.value,
             "psi_phi_bytes": int(meta.total_array_size),
         },
     }
