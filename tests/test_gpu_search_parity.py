@@ -164,6 +164,23 @@ def test_results_per_pixel(kb, orc, stack, cands, K, kern):
     assert len(got) == K * 80 * 100  # every slot survives min_lh = -1e30, placeholders are -FLT_MAX
 
 
+@pytest.mark.parametrize("K", [12, 32])
+def test_lists_of_more_than_eight(kb, orc, stack, cands, K, kern):
+    # kb_search_lds keeps lists of more than 8 results in its HBM store between chunks of candidates:
+    # (a) no candidate ever enters (start pixels so far off the image that no sample is ever valid): the store is
+    #     never written, every slot a placeholder
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, {"K": K, "min_obs": 1, "min_lh": -1e30, "xb": (-400, -300)},
+                                flags=KERNELS[kern])
+    _check(got, exp)
+    assert len(got) == 0
+    # (b) a quantised array: equal likelihoods in every list, the order among them is the swap-down's
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, {"K": K, "min_lh": -1e30}, num_bytes=1, flags=KERNELS[kern])
+    _check(got, exp)
+    # (c) a threshold that only few candidates pass: most waves never touch the store after the first chunks
+    got, exp, _ = util.run_both(kb, orc, stack, *cands, {"K": K, "min_obs": 10, "min_lh": 4.0}, flags=KERNELS[kern])
+    _check(got, exp)
+
+
 def test_large_k_keeps_every_candidate(kb, orc):
     # TrajectoryExplorer-style: K >= number of candidates, all of them come back per pixel
     # (reference: tests/test_trajectory_explorer.py:106-124).
