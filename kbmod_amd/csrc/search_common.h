@@ -28,6 +28,10 @@ constexpr int CHUNK = KB_CHUNK;    // candidates accumulated together per wave
 constexpr int DIRECT_ROWS = KB_DIRECT_ROWS;  // kb_search_direct / kb_search_large_k
 constexpr int LDS_ROWS_TALL = 16;  // kb_search_lds, K <= 8 (and the sigma-G emit)
 constexpr int LDS_ROWS_WIDE_K = 8; // kb_search_lds, 8 < K <= 32; also small search areas
+#ifndef KB_TILE_GROUP_ROWS
+#define KB_TILE_GROUP_ROWS 4
+#endif
+constexpr int TILE_GROUP_ROWS = KB_TILE_GROUP_ROWS;  // tile rows walked together by an XCD (tile_coords)
 __host__ __device__ constexpr int block_threads(int rows) { return rows * WAVE; }
 __host__ __device__ constexpr int stage_round(int rows) { return rows * WAVE * 16; }  // bytes one staging round moves
 __host__ __device__ constexpr int lds_group_bytes(int rows) { return 5120 * rows; }   // one of the two group buffers
@@ -276,8 +280,14 @@ __device__ __forceinline__ TileCoords tile_coords(const SearchArgs& a, int b) {
     const int xcd = b & 7, local = b >> 3;
     const int q = a.n_tiles >> 3, r = a.n_tiles & 7;
     const int tile = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-    c.ty = tile / a.tiles_x;
-    c.tx = tile - c.ty * a.tiles_x;
+    // Within an XCD's range the tiles run down groups of TILE_GROUP_ROWS tile rows, column after column: the ~32
+    // tiles an XCD holds at any time form a block (8 columns x 4 rows) whose vertical aprons overlap inside that
+    // XCD's L2, instead of one long row of tiles whose vertical neighbours come a whole pass later.
+    const int per_group = TILE_GROUP_ROWS * a.tiles_x;
+    const int g = tile / per_group, in_group = tile - g * per_group;
+    const int rows_here = min(TILE_GROUP_ROWS, a.tiles_y - g * TILE_GROUP_ROWS);
+    c.tx = in_group / rows_here;
+    c.ty = g * TILE_GROUP_ROWS + (in_group - c.tx * rows_here);
     c.lane = threadIdx.x & (WAVE - 1);
     c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     c.y_i = c.ty * ROWS + c.wv;

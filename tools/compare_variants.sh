@@ -1,8 +1,9 @@
 #!/bin/bash
-# usage: cmp.sh lib1 lib2 ... ; "main" = default library
+# tools/compare_variants.sh lib1 lib2 ...: bench.py kernel time for each variant library of tools/build_variants.sh
+# ("main" = the shipped library); extra bench arguments in $EXTRA, steps in $STEPS.
 for l in "$@"; do for i in 1 2; do
   if [ "$l" = main ]; then unset KBMOD_HIP_LIB; else export KBMOD_HIP_LIB=tools/probe_bin/libkbmod_$l.so; fi
-  timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --verify $EXTRA 2>&1 | python -c "
+  timeout 900 python bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-3} --no-cpu-baseline --verify $EXTRA 2>&1 | python -c "
 import sys,json
 for line in sys.stdin:
     if line.startswith('{'):
