@@ -774,8 +774,11 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         const SearchArgs at = with_tile_rows(a, lds_rows);
         const int ks = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
         void* lists = nullptr;
-        if (ensure_workspace(6, (size_t)at.n_tiles * ks * block_threads(lds_rows) * sizeof(uint2), &lists)) return 1;
-        a.lists = reinterpret_cast<uint2*>(lists);
+        if (try_workspace(6, (size_t)at.n_tiles * ks * block_threads(lds_rows) * sizeof(uint2), &lists)) {
+            a.lists = reinterpret_cast<uint2*>(lists);
+        } else {
+            which = 0;  // no room for the store: kb_search_direct keeps its lists in registers
+        }
     }
 
     search_timer.begin();
