@@ -352,6 +352,69 @@ struct TopK {
     }
 };
 
+// A list of whole results -- likelihood, candidate, flux, observation count -- as 16-byte records of the list store
+// of kb_search_lds: what the search has in hand when a candidate is inserted is exactly what the result needs
+// (lh and flux come from the same two sums, kernels.cu:186-190), so lists of records spare the epilogue its
+// re-evaluation of every winner.
+template <int KS>
+struct TopKRecords {
+    float lh[KS];
+    int id[KS];
+    float flux[KS];
+    int obs[KS];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            lh[s] = -FLT_MAX;
+            id[s] = -1;
+            flux[s] = 0.0f;
+            obs[s] = 0;
+        }
+    }
+    __device__ __forceinline__ void load(const char* tile_list, uint32_t lane_off, int stride_bytes) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint32_t off = lane_off;
+            asm volatile("" : "+v"(off));
+            const uint4 v = *reinterpret_cast<const uint4*>(tile_list + (size_t)s * stride_bytes + off);
+            lh[s] = __uint_as_float(v.x);
+            id[s] = (int)v.y;
+            flux[s] = __uint_as_float(v.z);
+            obs[s] = (int)v.w;
+        }
+    }
+    __device__ __forceinline__ void store(char* tile_list, uint32_t lane_off, int stride_bytes) const {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint32_t off = lane_off;
+            asm volatile("" : "+v"(off));
+            *reinterpret_cast<uint4*>(tile_list + (size_t)s * stride_bytes + off) =
+                    make_uint4(__float_as_uint(lh[s]), (uint32_t)id[s], __float_as_uint(flux[s]), (uint32_t)obs[s]);
+        }
+    }
+    // kernels.cu:323-330: strict '>' swap-down, the whole record travels
+    __device__ __forceinline__ void insert(float cand_lh, int cand, float cand_flux, int cand_obs) {
+        if (cand_lh > lh[KS - 1]) {
+            float cl = cand_lh, cf = cand_flux;
+            int cid = cand, co = cand_obs;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bool g = cl > lh[s];
+                const float tl = lh[s], tf = flux[s];
+                const int ti = id[s], to = obs[s];
+                lh[s] = g ? cl : tl;
+                id[s] = g ? cid : ti;
+                flux[s] = g ? cf : tf;
+                obs[s] = g ? co : to;
+                cl = g ? tl : cl;
+                cid = g ? ti : cid;
+                cf = g ? tf : cf;
+                co = g ? to : co;
+            }
+        }
+    }
+};
+
 // What kb_search_lds keeps in registers of a thread's list while it sums the next chunk: the likelihood a candidate
 // has to beat, and whether the list exists in the store yet (wave-uniform).
 struct ListState {
@@ -385,9 +448,9 @@ __host__ __device__ constexpr size_t scratch_words_per_wave(int T) { return (siz
 // prev (may be null for the first batch) -> next.
 // Launchers of the search kernels (search_direct.hip, search_lds.hip, search_lds_encoded.hip).  fmt: 4 = float,
 // 2 / 1 = encoded with the reference's double-precision decode, 20 / 10 = encoded with the verified single-FMA decode.
-void launch_search_direct(const SearchArgs& a, int fmt, bool sigmag, hipStream_t stream);
+void launch_search_direct(const SearchArgs& a, int fmt, bool sigmag, bool records, hipStream_t stream);
 void launch_search_large_k(const SearchArgs& a, bool sigmag, int blocks, hipStream_t stream);
-void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, hipStream_t stream);
+void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, int list_mode, hipStream_t stream);
 void launch_search_lds_encoded(const SearchArgs& a, int rows, int fmt, bool sigmag, hipStream_t stream);
 
 int launch_sigmag_resolve(const SearchArgs& a, const SearchCold& cold, const ResultSink* prev, const ResultSink& next,

@@ -91,8 +91,8 @@ __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoor
 // candidates, i.e. once per C x T samples: kept in registers they would cost the summing loop 2 KS registers for
 // nothing.  They live in a lane-interleaved store in HBM (L2-resident in practice) instead; the loop carries the
 // likelihood to beat.  A wave none of whose lanes has a candidate above its threshold does not touch the store.
-template <int KS, int C>
-__device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chunk, float (&ps)[C], const float (&ph)[C],
+template <int KS, int C, bool RECORDS>
+__device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chunk, float (&ps)[C], float (&ph)[C],
                                                     const int (&cnt)[C], ListState& ls, char* tile_list, uint32_t lane_off,
                                                     int stride_bytes) {
     // likelihoods one after the other (see finish_chunk); a candidate that may not enter (past the end of the
@@ -104,21 +104,71 @@ __device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chu
         asm volatile("" : "+v"(p), "+v"(f), "+v"(ls.threshold));
         const bool real = (chunk * C + c) < a.n_cands;  // uniform
         const float lh = (real && !(cnt[c] < a.min_obs)) ? lh_from_sums(p, f) : -FLT_MAX;
+        if constexpr (RECORDS) ph[c] = flux_from_sums(p, f);
         ps[c] = lh;
         beats = beats || (lh > ls.threshold);
     }
     if (__ballot(beats) == 0) return;  // uniform
-    TopK<KS> top;
-    if (ls.stored) {
-        top.load(tile_list, lane_off, stride_bytes);
-    } else {
-        top.init();
-    }
+    if constexpr (RECORDS) {
+        TopKRecords<KS> top;
+        if (ls.stored) {
+            top.load(tile_list, lane_off, stride_bytes);
+        } else {
+            top.init();
+        }
 #pragma unroll
-    for (int c = 0; c < C; ++c) top.insert(ps[c], chunk * C + c);
-    top.store(tile_list, lane_off, stride_bytes);
+        for (int c = 0; c < C; ++c) top.insert(ps[c], chunk * C + c, ph[c], cnt[c]);
+        top.store(tile_list, lane_off, stride_bytes);
+        ls.threshold = top.lh[KS - 1];
+    } else {
+        TopK<KS> top;
+        if (ls.stored) {
+            top.load(tile_list, lane_off, stride_bytes);
+        } else {
+            top.init();
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) top.insert(ps[c], chunk * C + c);
+        top.store(tile_list, lane_off, stride_bytes);
+        ls.threshold = top.lh[KS - 1];
+    }
     ls.stored = 1;
-    ls.threshold = top.lh[KS - 1];
+}
+
+// finish_chunk with lists of whole result records in registers (kb_search_direct, lists of up to 16): flux and
+// observation count travel with the likelihood, the epilogue copies them out (write_records).
+template <int KS, int C>
+__device__ __forceinline__ void finish_chunk_records(const SearchArgs& a, int chunk, const float (&ps)[C], const float (&ph)[C],
+                                                     const int (&cnt)[C], TopKRecords<KS>& top) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int cand = chunk * C + c;
+        if (cand >= a.n_cands) break;  // uniform
+        float p = ps[c], f = ph[c];
+        asm volatile("" : "+v"(p), "+v"(f), "+v"(top.lh[KS - 1]));  // one candidate after the other (see finish_chunk)
+        const float lh = lh_from_sums(p, f);
+        if (!(cnt[c] < a.min_obs) && lh > top.lh[KS - 1]) top.insert(lh, cand, flux_from_sums(p, f), cnt[c]);
+    }
+}
+template <int KS>
+__device__ __forceinline__ void write_records(const SearchArgs& a, const TileCoords& tc, const TopKRecords<KS>& top) {
+    if (tc.x_i >= a.sw || !tc.row_active) return;
+    const size_t slot0 = ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (s < a.K) {  // uniform
+            kb_trajectory res = placeholder_result(tc.x, tc.y);  // kernels.cu:293-301
+            const int id_s = top.id[s];
+            if (id_s >= 0) {
+                res.vx = a.cold->cands[id_s].vx;
+                res.vy = a.cold->cands[id_s].vy;
+                res.lh = top.lh[s];
+                res.flux = top.flux[s];
+                res.obs_count = top.obs[s];
+            }
+            store_result(a.cold->results, slot0 + s, res, id_s);
+        }
+    }
 }
 
 // Epilogue (no sigma-G; with it kb_sigmag_select_kernel writes the results): the K winners are
@@ -146,8 +196,10 @@ __device__ __forceinline__ void write_results(const SearchArgs& a, const TileCoo
 }
 
 
-// The epilogue of kb_search_lds: the winners' candidate indices come out of the list store slot by slot (nothing of
-// the list is held across the exact re-evaluation, the register-hungriest code of the kernel).
+// The epilogue of kb_search_lds: with lists of records the results are copied out of the store; with (likelihood,
+// candidate) lists the winners' candidate indices come out of it slot by slot and each winner is re-evaluated
+// (nothing of the list is held across that, the register-hungriest code of the kernel).
+template <bool RECORDS>
 __device__ __forceinline__ void write_results_stored(const SearchArgs& a, const TileCoords& tc, const ListState& ls,
                                                      const char* tile_list, uint32_t lane_off, int stride_bytes) {
     if (tc.x_i >= a.sw || !tc.row_active) return;
@@ -155,7 +207,16 @@ __device__ __forceinline__ void write_results_stored(const SearchArgs& a, const 
     for (int s = 0; s < a.K; ++s) {
         const int id_s = ls.stored ? (int)reinterpret_cast<const uint2*>(tile_list + (size_t)s * stride_bytes + lane_off)->y : -1;
         kb_trajectory res = placeholder_result(tc.x, tc.y);  // kernels.cu:293-301
-        if (id_s >= 0) {
+        if constexpr (RECORDS) {
+            if (id_s >= 0) {
+                const uint4 r = *reinterpret_cast<const uint4*>(tile_list + (size_t)s * stride_bytes + lane_off);
+                res.vx = a.cold->cands[id_s].vx;
+                res.vy = a.cold->cands[id_s].vy;
+                res.lh = __uint_as_float(r.x);
+                res.flux = __uint_as_float(r.z);
+                res.obs_count = (int)r.w;
+            }
+        } else if (id_s >= 0) {
             res.vx = a.cold->cands[id_s].vx;
             res.vy = a.cold->cands[id_s].vy;
             evaluate_trajectory_full<WAVE>(a.cold->meta, a.psi_phi, a.cold->times, a.cold->params, &res,

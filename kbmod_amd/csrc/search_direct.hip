@@ -7,14 +7,19 @@
 
 namespace kb {
 
-template <int KS, int C, int NB, bool SIGMAG>
+template <int KS, int C, int NB, bool SIGMAG, bool RECORDS>
 // second launch bound = waves per SIMD: 4 / 3 / 2 four-wave workgroups per CU for K <= 8 / 16 / 32
 __global__ __launch_bounds__(DIRECT_ROWS * WAVE, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 2))) void kb_search_direct(const SearchArgs a) {
     const TileCoords tc = tile_coords<DIRECT_ROWS>(a);
     if (!tc.row_active) return;  // whole wave (no barriers in this kernel)
     const int pix0 = tc.y * a.W + tc.x;
+    // RECORDS (lists of up to 16, no sigma-G): whole result records in registers -- no re-evaluation of the
+    // winners, which costs K x T exact samples per pixel: for a short candidate list more than the search itself
+    // (the host chooses: records when the list is short against the stack depth)
     TopK<KS> top;
+    TopKRecords<KS> rec;
     top.init();
+    rec.init();
 
     for (int chunk = a.chunk_lo; chunk < a.chunk_hi; ++chunk) {
         float ps[C], ph[C];
@@ -36,9 +41,17 @@ __global__ __launch_bounds__(DIRECT_ROWS * WAVE, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 
         } else {
             accumulate_chunk_direct_all<C, NB, 1>(a, chunk, tc.x, tc.y, pix0, ps, ph, cnt);
         }
-        finish_chunk<KS, C, SIGMAG>(a, tc, chunk, ps, ph, cnt, top);
+        if constexpr (RECORDS) {
+            finish_chunk_records<KS, C>(a, chunk, ps, ph, cnt, rec);
+        } else {
+            finish_chunk<KS, C, SIGMAG>(a, tc, chunk, ps, ph, cnt, top);
+        }
     }
-    if constexpr (!SIGMAG) write_results<KS>(a, tc, top);
+    if constexpr (RECORDS) {
+        write_records<KS>(a, tc, rec);
+    } else if constexpr (!SIGMAG) {
+        write_results<KS>(a, tc, top);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -89,44 +102,46 @@ __global__ __launch_bounds__(DIRECT_ROWS * WAVE) void kb_search_large_k(const Se
 // launchers (declared in search_common.h)
 // ---------------------------------------------------------------------------
 template <int KS, int NB>
-static void launch_direct_fmt(const SearchArgs& a, bool sigmag, hipStream_t stream) {
+static void launch_direct_fmt(const SearchArgs& a, bool sigmag, bool records, hipStream_t stream) {
     const dim3 grid(a.n_tiles), block(DIRECT_ROWS * WAVE);
     if (sigmag) {
         // the emitting instances keep no list: one set (KS = 8) serves every K
-        if constexpr (KS == 8) hipLaunchKernelGGL((kb_search_direct<8, CHUNK, NB, true>), grid, block, 0, stream, a);
+        if constexpr (KS == 8) hipLaunchKernelGGL((kb_search_direct<8, CHUNK, NB, true, false>), grid, block, 0, stream, a);
+    } else if (records && KS <= 16) {
+        if constexpr (KS <= 16) hipLaunchKernelGGL((kb_search_direct<KS, CHUNK, NB, false, true>), grid, block, 0, stream, a);
     } else {
-        hipLaunchKernelGGL((kb_search_direct<KS, CHUNK, NB, false>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((kb_search_direct<KS, CHUNK, NB, false, false>), grid, block, 0, stream, a);
     }
 }
 
 template <int KS>
-static void launch_direct_ks(const SearchArgs& a, int fmt, bool sigmag, hipStream_t stream) {
+static void launch_direct_ks(const SearchArgs& a, int fmt, bool sigmag, bool records, hipStream_t stream) {
     switch (fmt) {
         case 1:
-            launch_direct_fmt<KS, 1>(a, sigmag, stream);
+            launch_direct_fmt<KS, 1>(a, sigmag, records, stream);
             break;
         case 10:
-            launch_direct_fmt<KS, 10>(a, sigmag, stream);
+            launch_direct_fmt<KS, 10>(a, sigmag, records, stream);
             break;
         case 2:
-            launch_direct_fmt<KS, 2>(a, sigmag, stream);
+            launch_direct_fmt<KS, 2>(a, sigmag, records, stream);
             break;
         case 20:
-            launch_direct_fmt<KS, 20>(a, sigmag, stream);
+            launch_direct_fmt<KS, 20>(a, sigmag, records, stream);
             break;
         default:
-            launch_direct_fmt<KS, 4>(a, sigmag, stream);
+            launch_direct_fmt<KS, 4>(a, sigmag, records, stream);
             break;
     }
 }
 
-void launch_search_direct(const SearchArgs& a, int fmt, bool sigmag, hipStream_t stream) {
+void launch_search_direct(const SearchArgs& a, int fmt, bool sigmag, bool records, hipStream_t stream) {
     if (sigmag || a.K <= 8) {
-        launch_direct_ks<8>(a, fmt, sigmag, stream);
+        launch_direct_ks<8>(a, fmt, sigmag, records, stream);
     } else if (a.K <= 16) {
-        launch_direct_ks<16>(a, fmt, false, stream);
+        launch_direct_ks<16>(a, fmt, false, records, stream);
     } else {
-        launch_direct_ks<32>(a, fmt, false, stream);
+        launch_direct_ks<32>(a, fmt, false, false, stream);
     }
 }
 

@@ -442,13 +442,15 @@ static SearchArgs with_tile_rows(SearchArgs a, int rows) {
 }
 
 // which: 0 = kb_search_direct, 1 = kb_search_lds on an encoded padded copy, 2 = kb_search_lds on canonical floats
-static void launch_search(const SearchArgs& a, int fmt, bool sigmag, int which, int lds_rows, hipStream_t stream) {
+static void launch_search(const SearchArgs& a, int fmt, bool sigmag, int which, int lds_rows, int list_mode,
+                          hipStream_t stream) {
     if (which == 2) {
-        launch_search_lds_canon(with_tile_rows(a, lds_rows), lds_rows, sigmag, stream);
+        launch_search_lds_canon(with_tile_rows(a, lds_rows), lds_rows, sigmag, list_mode, stream);
     } else if (which == 1) {
         launch_search_lds_encoded(with_tile_rows(a, lds_rows), lds_rows, fmt, sigmag, stream);
     } else {
-        launch_search_direct(with_tile_rows(a, DIRECT_ROWS), fmt, sigmag, stream);
+        // (list_mode 2 = whole records: in the store of kb_search_lds, in registers here)
+        launch_search_direct(with_tile_rows(a, DIRECT_ROWS), fmt, sigmag, list_mode == 2, stream);
     }
 }
 
@@ -768,16 +770,33 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     a.cold = reinterpret_cast<const SearchCold*>(cold_dev);
     KB_HIP_TRY(hipMemcpyAsync(cold_dev, &cold, sizeof(SearchCold), hipMemcpyHostToDevice, stream));
 
+    // Where kb_search_lds keeps its per-pixel lists (ListMode, search_lds.h): whole result records in the HBM store
+    // when the candidate list is short against the stack depth (the store is visited once per chunk of
+    // candidates; registers / ids cost an exact re-evaluation of every winner: K x T samples per pixel),
+    // (likelihood, candidate) pairs in that store for lists of more than 8, registers otherwise.
+    // KBMOD_LIST_MODE = 0 / 1 / 2 overrides where the pair (K, mode) exists (tests).
     a.lists = nullptr;
-    if (which != 0 && !sigmag && a.K > 8 && a.K <= 32) {
-        // the lists of kb_search_lds between chunks: slots x threads of every tile, 8 bytes each
-        const SearchArgs at = with_tile_rows(a, lds_rows);
+    int list_mode = 0;
+    if (!sigmag && a.K <= 32) {
         const int ks = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
-        void* lists = nullptr;
-        if (try_workspace(6, (size_t)at.n_tiles * ks * block_threads(lds_rows) * sizeof(uint2), &lists)) {
-            a.lists = reinterpret_cast<uint2*>(lists);
-        } else {
-            which = 0;  // no room for the store: kb_search_direct keeps its lists in registers
+        const bool short_list = a.n_chunks <= a.T;
+        list_mode = ks == 32 ? 1 : (short_list ? 2 : (ks == 16 ? 1 : 0));
+        if (const char* env = std::getenv("KBMOD_LIST_MODE")) {
+            const int want = std::atoi(env);
+            if ((ks == 8 && (want == 0 || want == 2)) || (ks == 16 && (want == 1 || want == 2))) list_mode = want;
+        }
+        if (which == 1 && list_mode != 0) list_mode = 0;  // encoded staging: registers (K <= 8)
+        if (which == 2 && list_mode != 0) {
+            const SearchArgs at = with_tile_rows(a, lds_rows);
+            const size_t slot_bytes = list_mode == 2 ? 16 : 8;  // TileLists::SLOT_BYTES
+            void* lists = nullptr;
+            if (try_workspace(6, (size_t)at.n_tiles * ks * block_threads(lds_rows) * slot_bytes, &lists)) {
+                a.lists = reinterpret_cast<uint2*>(lists);
+            } else if (ks == 8) {
+                list_mode = 0;  // no room for the store: lists of 8 fit the registers
+            } else {
+                which = 0;  // ... longer ones do in kb_search_direct
+            }
         }
     }
 
@@ -808,7 +827,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
             a.chunk_hi = std::min(a.n_chunks, a.chunk_lo + batch_chunks);
             KB_HIP_TRY(hipMemsetAsync(cold.sg.slots, 0, (size_t)n_rows * cold.sg.batch_cands * sizeof(uint32_t), stream));
             KB_HIP_TRY(hipMemsetAsync(cold.sg.n_entries, 0, sizeof(int), stream));
-            if (a.chunk_lo < a.chunk_hi) launch_search(a, fmt, true, which, lds_rows, stream);  // the emitting instances keep no list
+            if (a.chunk_lo < a.chunk_hi) launch_search(a, fmt, true, which, lds_rows, 0, stream);  // the emitting instances keep no list
             KB_HIP_TRY(hipGetLastError());
             const ResultSink* next = &bufs[(n_batches - 1 - b) % 2];
             if (launch_sigmag_resolve(a, cold, prev, *next, resolve_waves, stream)) return 1;
@@ -816,7 +835,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         }
         variant = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
     } else {
-        launch_search(a, fmt, false, which, lds_rows, stream);
+        launch_search(a, fmt, false, which, lds_rows, list_mode, stream);
         variant = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
     }
     KB_HIP_TRY(hipGetLastError());

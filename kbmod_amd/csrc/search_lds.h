@@ -152,13 +152,21 @@ __device__ __forceinline__ void special_epoch(const SearchArgs& a, const TileCoo
     }
 }
 
-// The per-pixel lists of a tile.  Up to 8 results per pixel they stay in registers (16 per thread).  Longer lists
-// would cost the kernel its 4 waves per SIMD: they live in a lane-interleaved store in HBM between chunks
-// (finish_chunk_stored), the summing loop carries only the likelihood to beat.  (Measured for K = 8, cfg2: registers
-// 5.13 ms, store 5.41 ms -- the store's round trip once per chunk is exposed.)
-template <int KS>
+// The per-pixel lists of a tile, three ways (LM):
+//  LIST_REGISTERS  (likelihood, candidate) in registers, 16 per thread for K <= 8; the epilogue re-evaluates every
+//                  winner with exact positions for its flux and observation count.
+//  LIST_STORE_IDS  the same pairs in a lane-interleaved store in HBM between chunks (finish_chunk_stored): the
+//                  summing loop carries only the likelihood to beat, so lists of 16 / 32 keep 4 waves per SIMD.
+//  LIST_STORE_RECORDS  whole results (likelihood, candidate, flux, count) in that store: no re-evaluation at all.
+// The store is read and written once per chunk of candidates, the re-evaluation costs K x T exact samples per
+// pixel: the host takes records when the candidate list is short against the stack depth (cfg4's 64 candidates on
+// 128 epochs: 124 -> 53 ms) and registers / ids when it is long (cfg2's 1024 on 64: 5.16 vs 5.61 ms).
+enum ListMode { LIST_REGISTERS = 0, LIST_STORE_IDS = 1, LIST_STORE_RECORDS = 2 };
+template <int KS, int LM>
 struct TileLists {
-    static constexpr bool STORED = KS > 8;
+    static constexpr bool STORED = LM != LIST_REGISTERS;
+    static constexpr bool RECORDS = LM == LIST_STORE_RECORDS;
+    static constexpr uint32_t SLOT_BYTES = RECORDS ? 16u : 8u;
     TopK<KS> top;     // !STORED
     ListState state;  // STORED
     char* store;      // STORED: this tile's block of the store (uniform)
@@ -189,9 +197,9 @@ __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) 
 // the epoch's sums and written to LDS after them.
 // FAST: no sample of this tile can be NO_DATA (the tile stays inside the image under
 // every shift, the array has no NO_DATA pixel, every epoch is staged): obs_count is T.
-template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, bool FAST>
+template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, bool FAST>
 __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileCoords& tc, char* smem,
-                                                const StageLane& sl, TileLists<KS>& lists) {
+                                                const StageLane& sl, TileLists<KS, LM>& lists) {
     constexpr int SF = CANON ? 4 : NB;  // staged format
     using R = RawPair<SF>;
     constexpr int BYTES = 2 * fmt_bytes(SF);
@@ -458,8 +466,10 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 if constexpr (SIGMAG) {
                     TopK<KS> none;  // (the emitting instances keep no list)
                     finish_chunk<KS, C, true>(a, tc, chunk, ps, ph, cnt, none);
-                } else if constexpr (TileLists<KS>::STORED) {
-                    finish_chunk_stored<KS, C>(a, chunk, ps, ph, cnt, lists.state, lists.store, 8u * threadIdx.x, ROWS * WAVE * 8);
+                } else if constexpr (TileLists<KS, LM>::STORED) {
+                    finish_chunk_stored<KS, C, TileLists<KS, LM>::RECORDS>(a, chunk, ps, ph, cnt, lists.state, lists.store,
+                                                                      TileLists<KS, LM>::SLOT_BYTES * threadIdx.x,
+                                                                      ROWS * WAVE * TileLists<KS, LM>::SLOT_BYTES);
                 } else {
                     finish_chunk<KS, C, false>(a, tc, chunk, ps, ph, cnt, lists.top);
                 }
@@ -479,18 +489,19 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 }
 
 
-template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG>
+template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, int LM>
 // second launch bound = waves per SIMD: 16 waves per CU (one 64 x 16 or two 64 x 8 workgroups)
 __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // two group buffers
     constexpr int BYTES = 2 * fmt_bytes(CANON ? 4 : NB);
     const TileCoords tc = tile_coords<ROWS>(a);  // rows past the search area stay alive (barriers)
-    TileLists<KS> lists;
+    TileLists<KS, LM> lists;
     lists.top.init();
     lists.state = {-FLT_MAX, 0};
-    lists.store = (SIGMAG || !TileLists<KS>::STORED)
+    lists.store = (SIGMAG || !TileLists<KS, LM>::STORED)
                           ? nullptr
-                          : reinterpret_cast<char*>(a.lists) + ((size_t)(tc.ty * a.tiles_x + tc.tx) * KS) * (ROWS * WAVE * 8);
+                          : reinterpret_cast<char*>(a.lists) +
+                                    ((size_t)(tc.ty * a.tiles_x + tc.tx) * KS) * (ROWS * WAVE * TileLists<KS, LM>::SLOT_BYTES);
 
     StageLane sl;
 #pragma unroll
@@ -506,13 +517,14 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
                       (tc.tile_x0 + WAVE + gb[1] <= a.W) && (tc.tile_y0 + gb[2] >= 0) &&
                       (tc.tile_y0 + ROWS + gb[3] <= a.H);
     if (fast) {
-        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, true>(a, tc, smem, sl, lists);
+        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, true>(a, tc, smem, sl, lists);
     } else {
-        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, false>(a, tc, smem, sl, lists);
+        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, false>(a, tc, smem, sl, lists);
     }
     if constexpr (!SIGMAG) {
-        if constexpr (TileLists<KS>::STORED) {
-            write_results_stored(a, tc, lists.state, lists.store, 8u * threadIdx.x, ROWS * WAVE * 8);
+        if constexpr (TileLists<KS, LM>::STORED) {
+            write_results_stored<TileLists<KS, LM>::RECORDS>(a, tc, lists.state, lists.store, TileLists<KS, LM>::SLOT_BYTES * threadIdx.x,
+                                                         ROWS * WAVE * TileLists<KS, LM>::SLOT_BYTES);
         } else {
             write_results<KS>(a, tc, lists.top);
         }
@@ -520,12 +532,12 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
 }
 
 // Launch of one instance (two group buffers beyond the default 64 KiB of dynamic LDS need the attribute raised).
-template <int KS, int ROWS, int NB, bool CANON, bool SIGMAG>
+template <int KS, int ROWS, int NB, bool CANON, bool SIGMAG, int LM>
 static void launch_lds(const SearchArgs& a, hipStream_t stream) {
     constexpr size_t lds_bytes = 2 * lds_group_bytes(ROWS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb_search_lds<KS, CHUNK, ROWS, NB, CANON, SIGMAG>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb_search_lds<KS, CHUNK, ROWS, NB, CANON, SIGMAG, LM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, ROWS, NB, CANON, SIGMAG>), dim3(a.n_tiles), dim3(ROWS * WAVE), lds_bytes,
+    hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, ROWS, NB, CANON, SIGMAG, LM>), dim3(a.n_tiles), dim3(ROWS * WAVE), lds_bytes,
                        stream, a);
 }
 

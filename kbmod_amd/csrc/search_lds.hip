@@ -5,32 +5,39 @@
 
 namespace kb {
 
-void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, hipStream_t stream) {
+template <int KS, int LM>
+static void launch_canon(const SearchArgs& a, bool tall, hipStream_t stream) {
+    if (tall) {
+        launch_lds<KS, LDS_ROWS_TALL, 4, true, false, LM>(a, stream);
+    } else {
+        launch_lds<KS, LDS_ROWS_WIDE_K, 4, true, false, LM>(a, stream);
+    }
+}
+
+// list_mode: ListMode; valid pairs are K <= 8 with registers or records, K <= 16 with ids or records, K <= 32 with ids
+// (the host chooses, search_kernels.hip)
+void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, int list_mode, hipStream_t stream) {
     const bool tall = rows == LDS_ROWS_TALL;
     if (sigmag) {  // the emitting instances keep no list: KS is irrelevant
         if (tall) {
-            launch_lds<8, LDS_ROWS_TALL, 4, true, true>(a, stream);
+            launch_lds<8, LDS_ROWS_TALL, 4, true, true, LIST_REGISTERS>(a, stream);
         } else {
-            launch_lds<8, LDS_ROWS_WIDE_K, 4, true, true>(a, stream);
+            launch_lds<8, LDS_ROWS_WIDE_K, 4, true, true, LIST_REGISTERS>(a, stream);
         }
     } else if (a.K <= 8) {
-        if (tall) {
-            launch_lds<8, LDS_ROWS_TALL, 4, true, false>(a, stream);
+        if (list_mode == LIST_STORE_RECORDS) {
+            launch_canon<8, LIST_STORE_RECORDS>(a, tall, stream);
         } else {
-            launch_lds<8, LDS_ROWS_WIDE_K, 4, true, false>(a, stream);
+            launch_canon<8, LIST_REGISTERS>(a, tall, stream);
         }
     } else if (a.K <= 16) {
-        if (tall) {
-            launch_lds<16, LDS_ROWS_TALL, 4, true, false>(a, stream);
+        if (list_mode == LIST_STORE_RECORDS) {
+            launch_canon<16, LIST_STORE_RECORDS>(a, tall, stream);
         } else {
-            launch_lds<16, LDS_ROWS_WIDE_K, 4, true, false>(a, stream);
+            launch_canon<16, LIST_STORE_IDS>(a, tall, stream);
         }
     } else {
-        if (tall) {
-            launch_lds<32, LDS_ROWS_TALL, 4, true, false>(a, stream);
-        } else {
-            launch_lds<32, LDS_ROWS_WIDE_K, 4, true, false>(a, stream);
-        }
+        launch_canon<32, LIST_STORE_IDS>(a, tall, stream);
     }
 }
 

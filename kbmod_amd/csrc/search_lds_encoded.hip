@@ -8,9 +8,9 @@ namespace kb {
 template <int NB>
 static void launch_encoded_fmt(const SearchArgs& a, bool sigmag, hipStream_t stream) {
     if (sigmag) {
-        launch_lds<8, LDS_ROWS_WIDE_K, NB, false, true>(a, stream);
+        launch_lds<8, LDS_ROWS_WIDE_K, NB, false, true, LIST_REGISTERS>(a, stream);
     } else {
-        launch_lds<8, LDS_ROWS_WIDE_K, NB, false, false>(a, stream);
+        launch_lds<8, LDS_ROWS_WIDE_K, NB, false, false, LIST_REGISTERS>(a, stream);
     }
 }
 

@@ -181,6 +181,22 @@ def test_lists_of_more_than_eight(kb, orc, stack, cands, K, kern):
     _check(got, exp)
 
 
+@pytest.mark.parametrize("K,mode", [(3, 0), (3, 2), (8, 0), (8, 2), (12, 1), (12, 2), (16, 1), (16, 2)])
+def test_list_modes_agree_with_the_oracle(kb, orc, stack, cands, K, mode, kern, monkeypatch):
+    # kb_search_lds keeps its lists in registers (0), as (likelihood, candidate) pairs in its HBM store (1) or as
+    # whole result records there (2, no re-evaluation of the winners): the host chooses by the shape of the
+    # search, KBMOD_LIST_MODE pins the choice.  Flux and observation counts of mode 2 come from the search's own
+    # sums, those of modes 0 / 1 from the exact re-evaluation: all must equal the oracle's bit for bit.
+    # (kb_search_direct: mode 2 = records in registers, modes 0 / 1 = pairs in registers + re-evaluation)
+    monkeypatch.setenv("KBMOD_LIST_MODE", str(mode))
+    for cfg, nb in (({"K": K, "min_lh": -1e30}, -1), ({"K": K, "min_obs": 9, "min_lh": 1.0}, 1),
+                    ({"K": K, "xb": (-20, 130), "yb": (-15, 95), "min_lh": -1e30}, 2)):
+        got, exp, s = util.run_both(kb, orc, stack, *cands, cfg, num_bytes=nb, flags=KERNELS[kern])
+        _check_kernel(s, kern)
+        _check(got, exp)
+        assert len(got) > 100
+
+
 def test_large_k_keeps_every_candidate(kb, orc):
     # TrajectoryExplorer-style: K >= number of candidates, all of them come back per pixel
     # (reference: tests/test_trajectory_explorer.py:106-124).
