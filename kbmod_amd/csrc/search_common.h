@@ -416,7 +416,7 @@ struct TopKRecords {
 };
 
 // What kb_search_lds keeps in registers of a thread's list while it sums the next chunk: the likelihood a candidate
-// has to beat, and whether the list exists in the store yet (wave-uniform).
+// has to beat, and whether the list exists in the store yet.
 struct ListState {
     float threshold;
     int stored;

@@ -90,7 +90,7 @@ __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoor
 // finish_chunk for kb_search_lds without the sigma-G filter.  The per-pixel lists are touched once per chunk of C
 // candidates, i.e. once per C x T samples: kept in registers they would cost the summing loop 2 KS registers for
 // nothing.  They live in a lane-interleaved store in HBM (L2-resident in practice) instead; the loop carries the
-// likelihood to beat.  A wave none of whose lanes has a candidate above its threshold does not touch the store.
+// likelihood to beat.  A lane none of whose candidates is above its threshold does not touch the store.
 template <int KS, int C, bool RECORDS>
 __device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chunk, float (&ps)[C], float (&ph)[C],
                                                     const int (&cnt)[C], ListState& ls, char* tile_list, uint32_t lane_off,
@@ -108,7 +108,9 @@ __device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chu
         ps[c] = lh;
         beats = beats || (lh > ls.threshold);
     }
-    if (__ballot(beats) == 0) return;  // uniform
+    // per lane: a lane none of whose candidates beats its threshold neither reads nor writes its list (the
+    // memory operations below run under the exec mask of the lanes that do)
+    if (!beats) return;
     if constexpr (RECORDS) {
         TopKRecords<KS> top;
         if (ls.stored) {
