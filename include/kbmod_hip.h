@@ -162,6 +162,9 @@ int kb_generate_psi_phi_host(const float* sci_host, const float* var_host, int w
  *      has room, which makes the search as fast as on a float array);
  *  64 / 128  kb_search_lds with 64 x 16 / 64 x 8 start-pixel tiles whatever the search area (default:
  *      64 x 16 for lists of up to 8 results per pixel when that still gives >= 128 tiles).
+ * 256  the caller vouches that the array at psi_phi_dev has not changed since its previous search on this
+ *      device: the padded copy of that search is reused when array, meta data and frame geometry are the same
+ *      (a StackSearch owns its array and sets this from its second search on; cfg4: 7 ms of 60 per search).
  * The library keeps its workspaces (shift tables, sigma-G scratch, padded copy) between
  * calls; kb_release_workspaces() returns them. */
 int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,

@@ -257,11 +257,13 @@ public:
         if (psi_phi_array.on_gpu()) return;
         psi_phi_array.move_to_gpu();
         psi_phi_preloaded = true;
+        resident_searched = false;
     }
     void unload_psi_phi_array() {
         if (!psi_phi_array.on_gpu()) return;
         psi_phi_array.clear_from_gpu();
         psi_phi_preloaded = false;
+        resident_searched = false;
     }
     bool psi_phi_array_on_gpu() const { return psi_phi_array.on_gpu(); }
 
@@ -332,11 +334,15 @@ public:
                 search_on_devices(candidate_list, raw.as<kb_trajectory>(), max_results);
             } else {
                 candidate_list.move_to_gpu();
+                // flag 256: this object owns the array and has not touched it since its last search on the device
+                // (the library then reuses its padded copy when the frame geometry is the same)
+                const uint32_t unchanged = (psi_phi_preloaded && resident_searched) ? 256u : 0u;
                 check_status(kb_device_search_filter(
                         &psi_phi_array.get_meta_data(), psi_phi_array.get_gpu_array_ptr(),
                         psi_phi_array.get_gpu_time_array_ptr(), params,
                         reinterpret_cast<const kb_trajectory*>(candidate_list.get_gpu_list_ptr()), candidate_list.get_size(),
-                        raw.as<kb_trajectory>(), max_results, search_flags, nullptr, &last_stats));
+                        raw.as<kb_trajectory>(), max_results, search_flags | unchanged, nullptr, &last_stats));
+                resident_searched = psi_phi_preloaded;
                 candidate_list.move_to_cpu();
             }
             search_timer.stop();
@@ -543,6 +549,7 @@ protected:
     logging::Logger* rs_logger;
     kb_search_stats last_stats{};
     uint32_t search_flags = 0;
+    bool resident_searched = false;  // the resident array has been searched on the device since it was (re)loaded
     std::vector<int> search_devices;
     std::vector<Replica> replicas;
 };

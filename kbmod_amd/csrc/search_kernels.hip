@@ -383,6 +383,26 @@ static Workspace g_ws_all[MAX_DEVICES][7];  // 0: shift table + chunk info, 1: l
                             // 3: sigma-G work items + clipped values, 4: second per-pixel list buffer (sigma-G batches),
                             // 5: cold block of the kernel arguments, 6: per-pixel lists of kb_search_lds between chunks
 
+// What the padded copy in workspace 2 of a device was made from (flag 256 of the search entry points: the caller
+// vouches that the array has not changed since its last search; the copy is then reused when everything else that
+// determines it is the same).
+struct PaddedKey {
+    const void* src = nullptr;
+    void* copy = nullptr;
+    uint64_t T = 0, H = 0, W = 0;
+    int num_bytes = 0, fmt = 0, canon = 0;
+    float scale[4] = {0, 0, 0, 0};
+    int64_t Hp = 0, Wp = 0, px0 = 0, py0 = 0;
+    bool valid = false;
+    bool same(const PaddedKey& o) const {
+        return valid && o.valid && src == o.src && copy == o.copy && T == o.T && H == o.H && W == o.W &&
+               num_bytes == o.num_bytes && fmt == o.fmt && canon == o.canon && scale[0] == o.scale[0] &&
+               scale[1] == o.scale[1] && scale[2] == o.scale[2] && scale[3] == o.scale[3] && Hp == o.Hp && Wp == o.Wp &&
+               px0 == o.px0 && py0 == o.py0;
+    }
+};
+static PaddedKey g_padded_key[MAX_DEVICES];
+
 static int current_device_slot() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -396,6 +416,7 @@ static int ensure_workspace(int which, size_t bytes, void** out) {
         (void)hipFree(w.ptr);
         w.ptr = nullptr;
         w.bytes = 0;
+        if (which == 2) g_padded_key[dev].valid = false;
     }
     if (w.ptr == nullptr) {
         KB_HIP_TRY(hipMalloc(&w.ptr, bytes));
@@ -596,6 +617,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     // the direct kernel is bound by the vector-memory pipe (every sample is its own 512-byte wave
     // load), the staged kernel reads each slab once per workgroup and sums out of LDS.
     int which = 0;
+    int padded_reused = 0;
     const bool want_lds = (flags & 2u) == 0 && (flags & 1u) == 0 && a.K <= 32 &&
                           (n_cands >= 32 || (flags & 4u) != 0);
     if (n_cands > 0) {
@@ -698,8 +720,37 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                     cold.py0 = (int)py0;
                     // bit 5 (debug): never take the count-free specialisation
                     a.all_staged = (back[0] == 0 && (flags & 32u) == 0) ? 1 : 0;
-                    launch_pad(a, cold, fmt, canon, padded, n_invalid, stream);
-                    KB_HIP_TRY(hipGetLastError());
+                    // the NO_DATA counter of the copy lives behind it (it has to outlive this search's tables)
+                    n_invalid = reinterpret_cast<int*>(static_cast<char*>(padded) + frame * pair_bytes);
+                    a.n_invalid = n_invalid;
+                    PaddedKey key;
+                    key.src = psi_phi_dev;
+                    key.copy = padded;
+                    key.T = (uint64_t)a.T;
+                    key.H = (uint64_t)a.H;
+                    key.W = (uint64_t)a.W;
+                    key.num_bytes = meta->num_bytes;
+                    key.fmt = fmt;
+                    key.canon = canon ? 1 : 0;
+                    key.scale[0] = meta->psi_scale;
+                    key.scale[1] = meta->psi_min_val;
+                    key.scale[2] = meta->phi_scale;
+                    key.scale[3] = meta->phi_min_val;
+                    key.Hp = Hp;
+                    key.Wp = Wp;
+                    key.px0 = px0;
+                    key.py0 = py0;
+                    key.valid = true;
+                    PaddedKey& have_key = g_padded_key[current_device_slot()];
+                    if ((flags & 256u) != 0 && have_key.same(key)) {
+                        padded_reused = 1;  // the caller vouches for the array: the copy (and its counter) stand
+                    } else {
+                        have_key.valid = false;
+                        KB_HIP_TRY(hipMemsetAsync(n_invalid, 0, sizeof(int), stream));
+                        launch_pad(a, cold, fmt, canon, padded, n_invalid, stream);
+                        KB_HIP_TRY(hipGetLastError());
+                        have_key = key;
+                    }
                     const int64_t n_org = (int64_t)a.n_chunks * a.T;
                     hipLaunchKernelGGL(kb_slab_ref_kernel, dim3((unsigned)((n_org + SLAB_REF_SLACK + 255) / 256)), dim3(256), 0, stream,
                                        cold.boxes, a.chunks, n_org, a.T, cold.Hp, a.Wp, cold.px0, cold.py0, (int)pair_bytes,
@@ -844,8 +895,8 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         int bad = -1;
         KB_HIP_TRY(hipMemcpyAsync(&bad, a.n_invalid, sizeof(int), hipMemcpyDeviceToHost, stream));
         KB_HIP_TRY(hipStreamSynchronize(stream));
-        std::fprintf(stderr, "[kbmod_hip] padded frame %d x %d (image at %d, %d), NO_DATA pixels %d, all_staged %d\n", a.Wp,
-                     cold.Hp, cold.px0, cold.py0, bad, a.all_staged);
+        std::fprintf(stderr, "[kbmod_hip] padded frame %d x %d (image at %d, %d), NO_DATA pixels %d, all_staged %d%s\n", a.Wp,
+                     cold.Hp, cold.px0, cold.py0, bad, a.all_staged, padded_reused ? ", copy reused" : "");
     }
 
     if (stats_out != nullptr) {
@@ -911,6 +962,7 @@ int kb_release_workspaces(void) {
             }
             w = Workspace();
         }
+        g_padded_key[dev].valid = false;
     }
     if (have_prev) (void)hipSetDevice(prev);
     return 0;

@@ -197,6 +197,36 @@ def test_list_modes_agree_with_the_oracle(kb, orc, stack, cands, K, mode, kern, 
         assert len(got) > 100
 
 
+def test_repeated_searches_reuse_the_padded_copy(kb, orc, stack, cands):
+    # A StackSearch with its array resident in HBM tells the library, from its second search on, that the array is
+    # unchanged (flag 256): the padded copy of kb_search_lds is reused while the frame geometry stays the same,
+    # rebuilt when the bounds move it, and never taken over by another object's array of the same shape.
+    def expect(st, cfg):
+        pp = orc.PsiPhi.from_images(st.sci, st.var, st.psfs, st.zeroed_times, -1)
+        params = util.oracle_params(pp, cfg)
+        raw = pp.search_kernel_semantics(orc.make_candidates(*cands), params)
+        return util.as_table(orc.filter_sort(raw, params.min_lh, params.min_observations))
+
+    other = util.make_stack(len(stack.sci), *stack.sci[0].shape, seed=4242, noise=3.0, objects=[(30, 20, 6.0, -3.0, 200.0)])
+    a = kb.StackSearch(stack.sci, stack.var, stack.psfs, stack.zeroed_times, -1)
+    b = kb.StackSearch(other.sci, other.var, other.psfs, other.zeroed_times, -1)
+    for s in (a, b):
+        s.set_search_flags(KERNELS["lds"])
+        s.preload_psi_phi_array()
+    cfg = {"min_lh": -1e30}
+    for search, st, c in ((a, stack, cfg), (a, stack, cfg), (b, other, cfg), (a, stack, cfg), (a, stack, {"min_lh": -1e30, "xb": (-9, 70)}),
+                          (a, stack, {"min_lh": -1e30, "xb": (-9, 70)}), (b, other, cfg), (b, other, cfg)):
+        util.configure(search, c)
+        search.search_all(util.trajectories(kb, *cands), True)
+        assert _variant(search) == 2
+        _check(search.results_to_numpy(), expect(st, c))
+    a.unload_psi_phi_array()
+    a.preload_psi_phi_array()
+    a.search_all(util.trajectories(kb, *cands), True)
+    _check(a.results_to_numpy(), expect(stack, {"min_lh": -1e30, "xb": (-9, 70)}))
+    # (KBMOD_DEBUG=1 prints "copy reused" for the second, sixth and eighth of the searches above)
+
+
 def test_large_k_keeps_every_candidate(kb, orc):
     # TrajectoryExplorer-style: K >= number of candidates, all of them come back per pixel
     # (reference: tests/test_trajectory_explorer.py:106-124).
