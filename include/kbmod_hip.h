@@ -154,7 +154,7 @@ int kb_generate_psi_phi_host(const float* sci_host, const float* var_host, int w
  *   1  force the per-lane exact-position path of kb_search_direct (debug / self-check);
  *   2  use kb_search_direct (every sample a wave-wide load from the array);
  *   4  use kb_search_lds (slabs staged once per workgroup into LDS from a padded copy of the
- *      array) even for fewer than 32 candidates; the default from 32 candidates on.  Falls back
+ *      array) even for fewer than 8 candidates; the default from 8 candidates (one full chunk) on.  Falls back
  *      to kb_search_direct when more than 10 % of the (chunk, epoch) footprints cannot be staged,
  *      when K > 32, or when the apron of the padded copy would outweigh the image;
  *   8  always decode uint8/uint16 samples in double (skip the verified fp32-FMA form);

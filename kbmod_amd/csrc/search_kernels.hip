@@ -619,7 +619,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     int which = 0;
     int padded_reused = 0;
     const bool want_lds = (flags & 2u) == 0 && (flags & 1u) == 0 && a.K <= 32 &&
-                          (n_cands >= 32 || (flags & 4u) != 0);
+                          (n_cands >= 8 || (flags & 4u) != 0);
     if (n_cands > 0) {
         const size_t table_bytes = (size_t)a.n_chunks * a.T * CHUNK * sizeof(int2);
         const size_t off_bytes = ((size_t)a.n_chunks * a.T * CHUNK + 4 * CHUNK) * sizeof(int);  // + prefetch slack

@@ -71,11 +71,14 @@ def test_float_default(kb, orc, stack, cands, kern):
 
 
 def test_default_kernel_choice(kb, orc, stack, cands):
-    # flags = 0: the LDS kernel from 4 chunks of candidates on, the direct kernel for fewer.
+    # flags = 0: the LDS kernel from one full chunk of 8 candidates on, the direct kernel for fewer.
     got, exp, s = util.run_both(kb, orc, stack, *cands, {})
     assert _variant(s) == 2
     _check(got, exp)
-    got, exp, s = util.run_both(kb, orc, stack, cands[0][:20], cands[1][:20], {})
+    got, exp, s = util.run_both(kb, orc, stack, cands[0][:8], cands[1][:8], {})
+    assert _variant(s) == 2
+    _check(got, exp)
+    got, exp, s = util.run_both(kb, orc, stack, cands[0][:7], cands[1][:7], {})
     assert _variant(s) == 0
     _check(got, exp)
 
