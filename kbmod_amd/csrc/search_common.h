@@ -415,6 +415,42 @@ struct TopKRecords {
     }
 };
 
+// Whole results in registers at three words per slot: likelihood, flux, and candidate index | observation count << 16
+// (both below 65535; the host checks).  What lists of up to 8 cost beyond (likelihood, candidate) pairs is 8
+// registers, and the epilogue needs no re-evaluation.
+template <int KS>
+struct TopKPacked {
+    static constexpr uint32_t EMPTY = 0xffffffffu;
+    float lh[KS];
+    float flux[KS];
+    uint32_t io[KS];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            lh[s] = -FLT_MAX;
+            flux[s] = 0.0f;
+            io[s] = EMPTY;
+        }
+    }
+    // kernels.cu:323-330: strict '>' swap-down
+    __device__ __forceinline__ void insert(float cand_lh, float cand_flux, uint32_t cand_io) {
+        float cl = cand_lh, cf = cand_flux;
+        uint32_t ci = cand_io;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bool g = cl > lh[s];
+            const float tl = lh[s], tf = flux[s];
+            const uint32_t ti = io[s];
+            lh[s] = g ? cl : tl;
+            flux[s] = g ? cf : tf;
+            io[s] = g ? ci : ti;
+            cl = g ? tl : cl;
+            cf = g ? tf : cf;
+            ci = g ? ti : ci;
+        }
+    }
+};
+
 // What kb_search_lds keeps in registers of a thread's list while it sums the next chunk: the likelihood a candidate
 // has to beat, and whether the list exists in the store yet.
 struct ListState {

@@ -137,6 +137,44 @@ __device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chu
     ls.stored = 1;
 }
 
+// finish_chunk / epilogue for packed records in registers (kb_search_lds, lists of up to 8, long candidate lists).
+template <int KS, int C>
+__device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int chunk, const float (&ps)[C], const float (&ph)[C],
+                                                    const int (&cnt)[C], TopKPacked<KS>& top) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int cand = chunk * C + c;
+        if (cand >= a.n_cands) break;  // uniform
+        float p = ps[c], f = ph[c];
+        asm volatile("" : "+v"(p), "+v"(f), "+v"(top.lh[KS - 1]));  // one candidate after the other (see finish_chunk)
+        const float lh = lh_from_sums(p, f);
+        if (!(cnt[c] < a.min_obs) && lh > top.lh[KS - 1]) {
+            top.insert(lh, flux_from_sums(p, f), (uint32_t)cand | ((uint32_t)cnt[c] << 16));
+        }
+    }
+}
+template <int KS>
+__device__ __forceinline__ void write_packed(const SearchArgs& a, const TileCoords& tc, const TopKPacked<KS>& top) {
+    if (tc.x_i >= a.sw || !tc.row_active) return;
+    const size_t slot0 = ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (s < a.K) {  // uniform
+            kb_trajectory res = placeholder_result(tc.x, tc.y);  // kernels.cu:293-301
+            const uint32_t io = top.io[s];
+            const int id_s = (io == TopKPacked<KS>::EMPTY) ? -1 : (int)(io & 0xffffu);
+            if (id_s >= 0) {
+                res.vx = a.cold->cands[id_s].vx;
+                res.vy = a.cold->cands[id_s].vy;
+                res.lh = top.lh[s];
+                res.flux = top.flux[s];
+                res.obs_count = (int)(io >> 16);
+            }
+            store_result(a.cold->results, slot0 + s, res, id_s);
+        }
+    }
+}
+
 // finish_chunk with lists of whole result records in registers (kb_search_direct, lists of up to 16): flux and
 // observation count travel with the likelihood, the epilogue copies them out (write_records).
 template <int KS, int C>

@@ -831,20 +831,25 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     if (!sigmag && a.K <= 32) {
         const int ks = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
         const bool short_list = a.n_chunks <= a.T;
-        list_mode = ks == 32 ? 1 : (short_list ? 2 : (ks == 16 ? 1 : 0));
+        // (3: packed records in registers, K <= 8 on the float-staged kernel; candidate index and count share a word)
+        const bool packable = ks == 8 && which == 2 && a.n_cands < 65535 && a.T < 65535;
+        list_mode = ks == 32 ? 1 : (short_list ? 2 : (ks == 16 ? 1 : (packable ? 3 : 0)));
         if (const char* env = std::getenv("KBMOD_LIST_MODE")) {
             const int want = std::atoi(env);
-            if ((ks == 8 && (want == 0 || want == 2)) || (ks == 16 && (want == 1 || want == 2))) list_mode = want;
+            if ((ks == 8 && (want == 0 || want == 2 || (want == 3 && packable))) || (ks == 16 && (want == 1 || want == 2))) {
+                list_mode = want;
+            }
         }
+        if (which != 2 && list_mode == 3) list_mode = 0;
         if (which == 1 && list_mode != 0) list_mode = 0;  // encoded staging: registers (K <= 8)
-        if (which == 2 && list_mode != 0) {
+        if (which == 2 && (list_mode == 1 || list_mode == 2)) {
             const SearchArgs at = with_tile_rows(a, lds_rows);
             const size_t slot_bytes = list_mode == 2 ? 16 : 8;  // TileLists::SLOT_BYTES
             void* lists = nullptr;
             if (try_workspace(6, (size_t)at.n_tiles * ks * block_threads(lds_rows) * slot_bytes, &lists)) {
                 a.lists = reinterpret_cast<uint2*>(lists);
             } else if (ks == 8) {
-                list_mode = 0;  // no room for the store: lists of 8 fit the registers
+                list_mode = packable ? 3 : 0;  // no room for the store: lists of 8 fit the registers
             } else {
                 which = 0;  // ... longer ones do in kb_search_direct
             }

@@ -108,7 +108,7 @@ typedef float PairF __attribute__((ext_vector_type(2)));
 // kernel's register budget is set by its main loop and not by this path.
 template <int C, int SF, bool CANON>
 __device__ __forceinline__ void special_epoch(const SearchArgs& a, const TileCoords& tc, int chunk, int t, bool in_slab,
-                                              const char* slab, PairF (&acc)[C], int (&cnt)[C]) {
+                                              const char* slab, PairF (&acc)[C], uint32_t (&cntp)[C / 2]) {
     using R = RawPair<SF>;
     constexpr int BYTES = 2 * fmt_bytes(SF);
     typedef const __attribute__((address_space(4))) double* ConstDoublePtr;
@@ -146,7 +146,7 @@ __device__ __forceinline__ void special_epoch(const SearchArgs& a, const TileCoo
         for (int cc = 0; cc < C; ++cc) {
             if (cc == c) {  // uniform
                 acc[cc] += add;
-                cnt[cc] += valid ? 1 : 0;
+                cntp[cc >> 1] += (valid ? 1u : 0u) << (16 * (cc & 1));
             }
         }
     }
@@ -161,13 +161,17 @@ __device__ __forceinline__ void special_epoch(const SearchArgs& a, const TileCoo
 // The store is read and written once per chunk of candidates, the re-evaluation costs K x T exact samples per
 // pixel: the host takes records when the candidate list is short against the stack depth (cfg4's 64 candidates on
 // 128 epochs: 124 -> 53 ms) and registers / ids when it is long (cfg2's 1024 on 64: 5.16 vs 5.61 ms).
-enum ListMode { LIST_REGISTERS = 0, LIST_STORE_IDS = 1, LIST_STORE_RECORDS = 2 };
+//  LIST_REGISTER_RECORDS  whole results in registers at three words per slot (TopKPacked; K <= 8, fewer than 65535
+//                  candidates): no store, no re-evaluation; the default for long candidate lists with K <= 8.
+enum ListMode { LIST_REGISTERS = 0, LIST_STORE_IDS = 1, LIST_STORE_RECORDS = 2, LIST_REGISTER_RECORDS = 3 };
 template <int KS, int LM>
 struct TileLists {
-    static constexpr bool STORED = LM != LIST_REGISTERS;
+    static constexpr bool STORED = LM == LIST_STORE_IDS || LM == LIST_STORE_RECORDS;
+    static constexpr bool PACKED = LM == LIST_REGISTER_RECORDS;
     static constexpr bool RECORDS = LM == LIST_STORE_RECORDS;
     static constexpr uint32_t SLOT_BYTES = RECORDS ? 16u : 8u;
-    TopK<KS> top;     // !STORED
+    TopK<KS> top;     // LIST_REGISTERS
+    TopKPacked<KS> packed;  // LIST_REGISTER_RECORDS
     ListState state;  // STORED
     char* store;      // STORED: this tile's block of the store (uniform)
 };
@@ -207,12 +211,13 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     const int lane_b = (tc.wv * LDS_COLS + tc.lane) * BYTES;  // this lane's start pixel inside a slab
 
     PairF acc[C];  // (psi_sum, phi_sum) as pairs: one v_pk_add_f32 per sample
-    int cnt[C];
+    // observation counts, two 16-bit counts per register (a stack has at most 999 epochs): candidate c in half
+    // c & 1 of cntp[c >> 1]
+    uint32_t cntp[C / 2];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        acc[c] = PairF{0.0f, 0.0f};
-        cnt[c] = 0;
-    }
+    for (int c = 0; c < C; ++c) acc[c] = PairF{0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < C / 2; ++c) cntp[c] = 0u;
 
     int chunk = a.chunk_lo, t0 = 0, buf = 0;
     ChunkPlan plan = chunk_plan<BYTES, ROWS>(a, chunk);
@@ -295,7 +300,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 for (int c = 0; c < HALF; ++c) {
                     if constexpr (CANON) {
                         acc[c0 + c] += PairF{raw[c].x, raw[c].y};
-                        if (!FAST) cnt[c0 + c] += (__float_as_uint(raw[c].y) != 0x80000000u) ? 1 : 0;
+                        if (!FAST) cntp[(c0 + c) >> 1] += ((__float_as_uint(raw[c].y) != 0x80000000u) ? 1u : 0u) << (16 * ((c0 + c) & 1));
                     } else {
                         float psi, phi;
                         R::decode(raw[c], a, &psi, &phi);
@@ -303,7 +308,9 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                             acc[c0 + c] += PairF{psi, phi};
                         } else {
                             float s0 = acc[c0 + c].x, s1 = acc[c0 + c].y;
-                            accumulate(psi, phi, true, s0, s1, cnt[c0 + c]);
+                            int seen = 0;
+                            accumulate(psi, phi, true, s0, s1, seen);
+                            cntp[(c0 + c) >> 1] += (uint32_t)seen << (16 * ((c0 + c) & 1));
                             acc[c0 + c] = PairF{s0, s1};
                         }
                     }
@@ -314,7 +321,9 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
         // sinks the adds behind the writes, whose vmcnt(0) then waits out the loads with nothing to overlap.
         auto pin_sums = [&]() {
 #pragma unroll
-            for (int c = 0; c < C; ++c) asm volatile("" : "+v"(acc[c]), "+v"(cnt[c])::"memory");
+            for (int c = 0; c < C; ++c) asm volatile("" : "+v"(acc[c])::"memory");
+#pragma unroll
+            for (int c = 0; c < C / 2; ++c) asm volatile("" : "+v"(cntp[c])::"memory");
         };
         if (plan.clean) {
             // A block alone on its CU is bound by the chain scalar table fetch -> LDS read -> adds -> slab
@@ -366,7 +375,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                         // (keeps the counts of two unrolled epochs from being merged into three-operand adds that
                         // hold eight more registers across the pair)
 #pragma unroll
-                        for (int c = 0; c < C; ++c) asm volatile("" : "+v"(cnt[c]));
+                        for (int c = 0; c < C / 2; ++c) asm volatile("" : "+v"(cntp[c]));
                     }
 #pragma unroll
                     for (int j = 0; j < NP; ++j) *reinterpret_cast<Piece*>(wdst + stage_round(ROWS) * j) = v[j];
@@ -442,7 +451,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     sum_epoch(o, e, no_hook);
                 } else {
                     special_epoch<C, SF, CANON>(a, tc, chunk, t0 + e, o[0] == LDS_OFF_PER_LANE,
-                                                smem + buf * lds_group_bytes(ROWS) + e * plan.stride, acc, cnt);
+                                                smem + buf * lds_group_bytes(ROWS) + e * plan.stride, acc, cntp);
                 }
                 pin_sums();
                 if (staging) next_write(e);
@@ -457,11 +466,12 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
         if (n_chunk != chunk) {  // chunk complete: likelihoods + top-K, while the next chunk's first group lands
             if (tc.row_active) {
                 float ps[C], ph[C];
+                int cnt[C];
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     ps[c] = acc[c].x;
                     ph[c] = acc[c].y;
-                    if (FAST) cnt[c] = T;
+                    cnt[c] = FAST ? T : (int)((cntp[c >> 1] >> (16 * (c & 1))) & 0xffffu);
                 }
                 if constexpr (SIGMAG) {
                     TopK<KS> none;  // (the emitting instances keep no list)
@@ -470,6 +480,8 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     finish_chunk_stored<KS, C, TileLists<KS, LM>::RECORDS>(a, chunk, ps, ph, cnt, lists.state, lists.store,
                                                                       TileLists<KS, LM>::SLOT_BYTES * threadIdx.x,
                                                                       ROWS * WAVE * TileLists<KS, LM>::SLOT_BYTES);
+                } else if constexpr (TileLists<KS, LM>::PACKED) {
+                    finish_chunk_packed<KS, C>(a, chunk, ps, ph, cnt, lists.packed);
                 } else {
                     finish_chunk<KS, C, false>(a, tc, chunk, ps, ph, cnt, lists.top);
                 }
@@ -477,7 +489,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 acc[c] = PairF{0.0f, 0.0f};
-                cnt[c] = 0;
+                cntp[c >> 1] = 0u;
             }
         }
         __syncthreads();
@@ -497,6 +509,7 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
     const TileCoords tc = tile_coords<ROWS>(a);  // rows past the search area stay alive (barriers)
     TileLists<KS, LM> lists;
     lists.top.init();
+    lists.packed.init();
     lists.state = {-FLT_MAX, 0};
     lists.store = (SIGMAG || !TileLists<KS, LM>::STORED)
                           ? nullptr
@@ -525,6 +538,8 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
         if constexpr (TileLists<KS, LM>::STORED) {
             write_results_stored<TileLists<KS, LM>::RECORDS>(a, tc, lists.state, lists.store, TileLists<KS, LM>::SLOT_BYTES * threadIdx.x,
                                                          ROWS * WAVE * TileLists<KS, LM>::SLOT_BYTES);
+        } else if constexpr (TileLists<KS, LM>::PACKED) {
+            write_packed<KS>(a, tc, lists.packed);
         } else {
             write_results<KS>(a, tc, lists.top);
         }

@@ -14,7 +14,7 @@ static void launch_canon(const SearchArgs& a, bool tall, hipStream_t stream) {
     }
 }
 
-// list_mode: ListMode; valid pairs are K <= 8 with registers or records, K <= 16 with ids or records, K <= 32 with ids
+// list_mode: ListMode; valid pairs are K <= 8 with registers, packed register records or records, K <= 16 with ids or records, K <= 32 with ids
 // (the host chooses, search_kernels.hip)
 void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, int list_mode, hipStream_t stream) {
     const bool tall = rows == LDS_ROWS_TALL;
@@ -27,6 +27,8 @@ void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, int lis
     } else if (a.K <= 8) {
         if (list_mode == LIST_STORE_RECORDS) {
             launch_canon<8, LIST_STORE_RECORDS>(a, tall, stream);
+        } else if (list_mode == LIST_REGISTER_RECORDS) {
+            launch_canon<8, LIST_REGISTER_RECORDS>(a, tall, stream);
         } else {
             launch_canon<8, LIST_REGISTERS>(a, tall, stream);
         }

@@ -184,11 +184,11 @@ def test_lists_of_more_than_eight(kb, orc, stack, cands, K, kern):
     _check(got, exp)
 
 
-@pytest.mark.parametrize("K,mode", [(3, 0), (3, 2), (8, 0), (8, 2), (12, 1), (12, 2), (16, 1), (16, 2)])
+@pytest.mark.parametrize("K,mode", [(3, 0), (3, 2), (3, 3), (8, 0), (8, 2), (8, 3), (12, 1), (12, 2), (16, 1), (16, 2)])
 def test_list_modes_agree_with_the_oracle(kb, orc, stack, cands, K, mode, kern, monkeypatch):
-    # kb_search_lds keeps its lists in registers (0), as (likelihood, candidate) pairs in its HBM store (1) or as
-    # whole result records there (2, no re-evaluation of the winners): the host chooses by the shape of the
-    # search, KBMOD_LIST_MODE pins the choice.  Flux and observation counts of mode 2 come from the search's own
+    # kb_search_lds keeps its lists in registers (0), as (likelihood, candidate) pairs in its HBM store (1), as
+    # whole result records there (2) or as packed records in registers (3; 2 and 3 need no re-evaluation of the
+    # winners): the host chooses by the shape of the search, KBMOD_LIST_MODE pins the choice.  Flux and observation counts of mode 2 come from the search's own
     # sums, those of modes 0 / 1 from the exact re-evaluation: all must equal the oracle's bit for bit.
     # (kb_search_direct: mode 2 = records in registers, modes 0 / 1 = pairs in registers + re-evaluation)
     monkeypatch.setenv("KBMOD_LIST_MODE", str(mode))
