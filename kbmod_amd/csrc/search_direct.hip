@@ -14,12 +14,15 @@ __global__ __launch_bounds__(DIRECT_ROWS * WAVE, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 
     if (!tc.row_active) return;  // whole wave (no barriers in this kernel)
     const int pix0 = tc.y * a.W + tc.x;
     // RECORDS (lists of up to 16, no sigma-G): whole result records in registers -- no re-evaluation of the
-    // winners, which costs K x T exact samples per pixel: for a short candidate list more than the search itself
-    // (the host chooses: records when the list is short against the stack depth)
+    // winners, which costs K x T exact samples per pixel: for a short candidate list more than the search itself.
+    // Lists of up to 8 take the packed form (24 registers: always, when the candidate indices fit 16 bits); lists
+    // of 9 .. 16 four words per slot when the candidate list is short against the stack depth (the host chooses).
     TopK<KS> top;
-    TopKRecords<KS> rec;
+    TopKRecords<KS> rec;    // RECORDS, lists of 9 .. 16
+    TopKPacked<KS> packed;  // RECORDS, lists of up to 8 (the host checks that candidate indices fit 16 bits)
     top.init();
     rec.init();
+    packed.init();
 
     for (int chunk = a.chunk_lo; chunk < a.chunk_hi; ++chunk) {
         float ps[C], ph[C];
@@ -41,13 +44,17 @@ __global__ __launch_bounds__(DIRECT_ROWS * WAVE, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 
         } else {
             accumulate_chunk_direct_all<C, NB, 1>(a, chunk, tc.x, tc.y, pix0, ps, ph, cnt);
         }
-        if constexpr (RECORDS) {
+        if constexpr (RECORDS && KS <= 8) {
+            finish_chunk_packed<KS, C>(a, chunk, ps, ph, cnt, packed);
+        } else if constexpr (RECORDS) {
             finish_chunk_records<KS, C>(a, chunk, ps, ph, cnt, rec);
         } else {
             finish_chunk<KS, C, SIGMAG>(a, tc, chunk, ps, ph, cnt, top);
         }
     }
-    if constexpr (RECORDS) {
+    if constexpr (RECORDS && KS <= 8) {
+        write_packed<KS>(a, tc, packed);
+    } else if constexpr (RECORDS) {
         write_records<KS>(a, tc, rec);
     } else if constexpr (!SIGMAG) {
         write_results<KS>(a, tc, top);

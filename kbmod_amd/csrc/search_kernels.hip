@@ -471,7 +471,8 @@ static void launch_search(const SearchArgs& a, int fmt, bool sigmag, int which, 
         launch_search_lds_encoded(with_tile_rows(a, lds_rows), lds_rows, fmt, sigmag, stream);
     } else {
         // (list_mode 2 = whole records: in the store of kb_search_lds, in registers here)
-        launch_search_direct(with_tile_rows(a, DIRECT_ROWS), fmt, sigmag, list_mode == 2, stream);
+        launch_search_direct(with_tile_rows(a, DIRECT_ROWS), fmt, sigmag,
+                             list_mode == 2 || list_mode == 3 || (a.K <= 8 && a.n_cands < 65535 && a.T < 65535), stream);
     }
 }
 
