@@ -42,9 +42,13 @@ __host__ __device__ constexpr int lds_group_bytes(int rows) { return 5120 * rows
 #ifndef KB_LDS_COLS
 #define KB_LDS_COLS 88
 #endif
-constexpr int LDS_COLS = KB_LDS_COLS;  // slab pitch in pixels: 64 start columns + up to 24 of dx spread
+constexpr int LDS_COLS = KB_LDS_COLS;  // widest slab in pixels: 64 start columns + up to 24 of dx spread (each chunk's slabs
+                                      // are as wide as its own spread needs: ChunkInfo::cols)
                                       // (88 * {8,4,2} bytes are multiples of the 16-byte DMA granule)
-constexpr int LDS_ALIGN_PX = 8;         // slab origins are multiples of 8 columns of the padded frame
+#ifndef KB_LDS_ALIGN_PX
+#define KB_LDS_ALIGN_PX 2
+#endif
+constexpr int LDS_ALIGN_PX = KB_LDS_ALIGN_PX;  // slab origins are multiples of this many columns of the padded frame
 #ifndef KB_LDS_SLOTS
 #define KB_LDS_SLOTS 2
 #endif
@@ -57,7 +61,8 @@ struct ChunkInfo {
     int unsafe;                          // any entry flagged SHIFT_UNSAFE
     int lds_ok;                          // every epoch's footprint fits one LDS slab
     int rows_max;                        // tile rows + largest dy spread of any epoch (slab height)
-    int pad;
+    int cols;                            // slab pitch: 64 + largest dx spread of any staged epoch, rounded up to the
+                                         // staging quantum (16 bytes of raw pairs)
 };
 
 // Per (chunk, epoch) footprint, packed for one 8-byte scalar load:

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
                                                              EpochBox* __restrict__ boxes,
                                                              int* __restrict__ lds_off,
                                                              int* __restrict__ n_not_lds,
-                                                             int* __restrict__ global_box, int tile_rows) {
+                                                             int* __restrict__ global_box, int tile_rows, int col_quantum) {
     // One workgroup per chunk, one thread per epoch (strided): the thread owns the
     // C shifts of its epoch, their bounding box and the LDS offsets derived from it.
     const int chunk = blockIdx.x;
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
     int rows_max = tile_rows;
     int sx_min = INT32_MAX, sx_max = INT32_MIN, sy_min = INT32_MAX, sy_max = INT32_MIN;  // staged epochs only
     int n_per_lane = 0;
+    int cols_max = WAVE + col_quantum;  // widest staged footprint of the chunk
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
         const double tm = times[t];
         int2 sh[C];
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
             box.x = (ey0 << 16) | (ex0 & 0xffff);
             box.y = ((tile_rows + ey1 - ey0) << 16) | (WAVE + ex1 - ex0);
             rows_max = max(rows_max, tile_rows + ey1 - ey0);
+            cols_max = max(cols_max, WAVE + ex1 - ex0);
             sx_min = min(sx_min, ex0);
             sx_max = max(sx_max, ex1);
             sy_min = min(sy_min, ey0);
@@ -141,11 +143,8 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
             const size_t e = ((size_t)chunk * T + t) * C + c;
             table[e] = sh[c];
             const bool real = (chunk * C + c) < n_cands;
-            // >= 0: slab offset of the uniformly shifted tile; LDS_OFF_PER_LANE: staged, but the lanes
-            // find their own pixel inside the slab; LDS_OFF_UNSTAGED: not staged at all
-            lds_off[e] = !fits ? LDS_OFF_UNSTAGED
-                               : (epoch_unsafe ? LDS_OFF_PER_LANE
-                                               : (real ? ((sh[c].y - ey0) * LDS_COLS + (sh[c].x - ex0)) * 8 : 0));
+            // (the slab offsets need the chunk's pitch: second pass below; this pass leaves the case)
+            lds_off[e] = !fits ? LDS_OFF_UNSTAGED : (epoch_unsafe ? LDS_OFF_PER_LANE : (real ? 1 : 0));
         }
         if (epoch_unsafe) any_unsafe = 1;
         if (epoch_unsafe && fits) n_per_lane += 1;
@@ -156,7 +155,7 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
             dy_max = max(dy_max, ey1);
         }
     }
-    __shared__ int red[12][256];
+    __shared__ int red[13][256];
     red[0][threadIdx.x] = dx_min;
     red[1][threadIdx.x] = dx_max;
     red[2][threadIdx.x] = dy_min;
@@ -169,6 +168,7 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
     red[9][threadIdx.x] = sy_min;
     red[10][threadIdx.x] = sy_max;
     red[11][threadIdx.x] = n_per_lane;
+    red[12][threadIdx.x] = cols_max;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
             red[9][threadIdx.x] = min(red[9][threadIdx.x], red[9][threadIdx.x + s]);
             red[10][threadIdx.x] = max(red[10][threadIdx.x], red[10][threadIdx.x + s]);
             red[11][threadIdx.x] += red[11][threadIdx.x + s];
+            red[12][threadIdx.x] = max(red[12][threadIdx.x], red[12][threadIdx.x + s]);
         }
         __syncthreads();
     }
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
         ci.unsafe = red[4][0];
         ci.lds_ok = (red[5][0] == 0) ? 1 : 0;
         ci.rows_max = red[6][0];
-        ci.pad = 0;
+        ci.cols = min(LDS_COLS, (red[12][0] + col_quantum - 1) / col_quantum * col_quantum);
         chunks[chunk] = ci;
         if (red[5][0] != 0) atomicAdd(n_not_lds, red[5][0]);  // (chunk, epoch) pairs that are not staged
         if (red[11][0] != 0) atomicAdd(&global_box[5], red[11][0]);  // ... staged, but summed per lane
@@ -206,6 +207,21 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
             atomicMax(&global_box[1], red[8][0]);
             atomicMin(&global_box[2], red[9][0]);
             atomicMax(&global_box[3], red[10][0]);
+        }
+    }
+    // Second pass: slab offsets of the uniformly shifted tile at the chunk's pitch (>= 0; LDS_OFF_PER_LANE: staged,
+    // but the lanes find their own pixel inside the slab; LDS_OFF_UNSTAGED: not staged at all).
+    const int cols = min(LDS_COLS, (red[12][0] + col_quantum - 1) / col_quantum * col_quantum);
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const EpochBox box = boxes[(size_t)chunk * T + t];  // written by this thread above
+        if (box.x == BOX_NOT_STAGED) continue;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const size_t e = ((size_t)chunk * T + t) * C + c;
+            if (lds_off[e] == 1) {
+                const int2 sh = table[e];
+                lds_off[e] = ((sh.y - box_dy(box)) * cols + (sh.x - box_dx(box))) * 8;
+            }
         }
     }
 }
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(256) void kb_slab_ref_kernel(const EpochBox* __rest
     r.origin = (box.x == BOX_NOT_STAGED)
                        ? (((int64_t)t * Hp + py0) * Wp + px0) * (int64_t)pair_bytes
                        : (((int64_t)t * Hp + box_dy(box) + py0) * Wp + box_dx(box) + px0) * (int64_t)pair_bytes;
-    r.bytes = chunks[i / T].rows_max * LDS_COLS * pair_bytes;
+    r.bytes = chunks[i / T].rows_max * chunks[i / T].cols * pair_bytes;
     r.pad = 0;
     refs[slot] = r;
 }
@@ -645,6 +661,10 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         int* gbox = inv + 2;
         a.n_invalid = n_invalid;
         a.global_box = gbox;
+        // pitch quantum of the slabs: 16 bytes of raw pairs -- 2 pixels of float pairs (the canonical copy), 8 when
+        // the caller keeps an encoded array encoded in the padded copy (flag 16)
+        const bool tables_for_encoded = meta->num_bytes != 4 && (flags & 16u) != 0;
+        const int col_quantum = tables_for_encoded ? 8 : 2;
         table_timer.begin();
         static const int inv_init[8] = {0, 0, INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN, 0, 0};
         KB_HIP_TRY(hipMemcpyAsync(inv, inv_init, sizeof(inv_init), hipMemcpyHostToDevice, stream));
@@ -652,7 +672,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                            times_dev, a.n_cands, a.T, reinterpret_cast<int2*>(wsc),
                            reinterpret_cast<ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes),
                            reinterpret_cast<EpochBox*>(wsc + table_bytes + off_bytes),
-                           reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox, lds_rows);
+                           reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox, lds_rows, col_quantum);
         KB_HIP_TRY(hipGetLastError());
         if (want_lds) {
             // The choice and the apron of the padded copy need six ints back.
@@ -682,10 +702,12 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 // rows a slab's staging rounds can touch (whole rounds are loaded, see load_slab), for either
                 // staged format
                 auto rows_touched = [&](uint64_t pair_b) {
-                    const uint64_t row_b = (uint64_t)LDS_COLS * pair_b;
+                    // (the widest slab for the rounds, the narrowest for the rows they span: a chunk's pitch
+                    // lies between 64 + quantum and LDS_COLS)
+                    const uint64_t row_b = (uint64_t)LDS_COLS * pair_b, row_b_min = (uint64_t)(WAVE + col_quantum) * pair_b;
                     const uint64_t round_b = (uint64_t)stage_round(lds_rows);
                     const uint64_t rounds = ((uint64_t)back[5] * row_b + round_b - 1) / round_b;
-                    return (int64_t)((rounds * round_b + row_b - 1) / row_b);
+                    return (int64_t)((rounds * round_b + row_b_min - 1) / row_b_min);
                 };
                 const int64_t rows_cap = std::max(rows_touched(8), rows_touched(2ull * (uint64_t)meta->block_size));
                 const int64_t y_hi =
@@ -700,7 +722,8 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 const uint64_t image = (uint64_t)a.T * (uint64_t)a.H * (uint64_t)a.W;
                 // Canonical floats unless the caller keeps the array encoded or HBM is short.
                 bool canon = meta->num_bytes == 4 || (flags & 16u) == 0;
-                const bool encoded_instance = (params.do_sigmag_filter != 0 || a.K <= 8) && lds_rows == LDS_ROWS_WIDE_K;  // search_lds_encoded.hip
+                const bool encoded_instance = (params.do_sigmag_filter != 0 || a.K <= 8) && lds_rows == LDS_ROWS_WIDE_K &&
+                                              tables_for_encoded;  // search_lds_encoded.hip (slab pitches in its quantum)
                 size_t free_b = 0, total_b = 0;
                 KB_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
                 const uint64_t have = g_ws[2].ptr != nullptr ? g_ws[2].bytes : 0;

@@ -36,13 +36,17 @@ struct SlabRegs {
     Piece v[LDS_SLOTS];
 };
 
-// Offsets of a thread for slabs of slab_bytes: 0 (re-read the slab's first bytes) past the slab's end.
-template <int ROWS>
-__device__ __forceinline__ StageLane clip_lane(const StageLane& sl, int slab_bytes) {
+// Staging map of a thread for the slabs of one chunk (pitch `cols` pixels, slab_bytes): where its 16 bytes of
+// round j sit in the padded copy relative to the slab origin; 0 (re-read the slab's first bytes) past the slab's end.
+template <int BYTES, int ROWS>
+__device__ __forceinline__ StageLane stage_lanes(const SearchArgs& a, int cols, int slab_bytes) {
     StageLane out;
 #pragma unroll
     for (int j = 0; j < LDS_SLOTS; ++j) {
-        out.goff[j] = (16 * ((int)threadIdx.x + (ROWS * WAVE) * j) < slab_bytes) ? sl.goff[j] : 0u;
+        const int o = 16 * ((int)threadIdx.x + (ROWS * WAVE) * j);
+        const int p = o / BYTES;  // first pixel of this thread's 16 bytes
+        const int r = p / cols, c = p - r * cols;
+        out.goff[j] = (o < slab_bytes) ? (uint32_t)(r * a.Wp + c) * (uint32_t)BYTES : 0u;
     }
     return out;
 }
@@ -53,17 +57,17 @@ __device__ __forceinline__ StageLane clip_lane(const StageLane& sl, int slab_byt
 // write them to LDS.
 template <int BYTES, int ROWS>
 __device__ __forceinline__ void load_slab(const SearchArgs& a, const StageLane& sl, const char* base, int slab_bytes,
-                                          SlabRegs& regs, int j0 = 0) {
+                                          SlabRegs& regs, int j0 = 0, int cols = LDS_COLS) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < LDS_SLOTS; ++j) {
         uint32_t goff = sl.goff[j];
         if (j0 != 0) {  // uniform, rare: rounds after the first compute their map on the fly
             const int p = 16 * (tid + (ROWS * WAVE) * (j0 + j)) / BYTES;
-            const int r = p / LDS_COLS, c = p - r * LDS_COLS;
+            const int r = p / cols, c = p - r * cols;
             goff = (uint32_t)(r * a.Wp + c) * (uint32_t)BYTES;
         }
-        // (round 0: sl already holds 0 for threads past the end of this chunk's slabs, see clip_lane)
+        // (round 0: sl already holds 0 for threads past the end of this chunk's slabs, see stage_lanes)
         uint32_t off = (j0 == 0 || 16 * (tid + (ROWS * WAVE) * (j0 + j)) < slab_bytes) ? goff : 0u;
         // the offset stays a 32-bit register across the loop (uniform base + 32-bit lane offset is an addressing mode;
         // hoisted as a 64-bit value it costs an add per load and a register more)
@@ -89,9 +93,9 @@ __device__ __forceinline__ void write_slab(char* dst, int slab_bytes, const Slab
 // Rounds after the first of a slab larger than LDS_SLOTS x 4 KiB (load, then write, no overlap).
 template <int BYTES, int ROWS>
 __device__ __forceinline__ void copy_slab_tail(const SearchArgs& a, const StageLane& sl, const char* base, int slab_bytes,
-                                               char* dst, SlabRegs& regs) {
+                                               int cols, char* dst, SlabRegs& regs) {
     for (int j0 = LDS_SLOTS; stage_round(ROWS) * j0 < slab_bytes; j0 += LDS_SLOTS) {
-        load_slab<BYTES, ROWS>(a, sl, base, slab_bytes, regs, j0);
+        load_slab<BYTES, ROWS>(a, sl, base, slab_bytes, regs, j0, cols);
         write_slab<ROWS>(dst, slab_bytes, regs, j0);
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
@@ -118,6 +122,7 @@ __device__ __forceinline__ void special_epoch(const SearchArgs& a, const TileCoo
     const EpochBox box = make_int2(box_word, 0);
     const int ox = tc.tile_x0 + box_dx(box), oy = tc.tile_y0 + box_dy(box);  // image coordinates of slab pixel (0, 0)
     const int rows = as_const_ints(&a.chunks[chunk])[6];                     // rows_max: the slab's height
+    const int cols = as_const_ints(&a.chunks[chunk])[7];                     // ... and its pitch
     const kb_trajectory* cands = cold->cands;
 #pragma nounroll
     for (int c = 0; c < C; ++c) {
@@ -129,8 +134,8 @@ __device__ __forceinline__ void special_epoch(const SearchArgs& a, const TileCoo
         float psi = NAN, phi = NAN;
         if (in_slab) {  // uniform
             const int rx = cx - ox, ry = cy - oy;
-            const bool ok = in && ((unsigned)rx < (unsigned)LDS_COLS) && ((unsigned)ry < (unsigned)rows);
-            const int off = ok ? (ry * LDS_COLS + rx) * BYTES : 0;
+            const bool ok = in && ((unsigned)rx < (unsigned)cols) && ((unsigned)ry < (unsigned)rows);
+            const int off = ok ? (ry * cols + rx) * BYTES : 0;
             const typename R::type raw = *reinterpret_cast<const typename R::type*>(slab + off);
             float p0, p1;
             R::decode(raw, a, &p0, &p1);
@@ -178,7 +183,8 @@ struct TileLists {
 
 // Staging schedule of one chunk.
 struct ChunkPlan {
-    int slab_bytes;  // rows_max * LDS_COLS * BYTES
+    int cols;        // pitch of the chunk's slabs in pixels: 64 + its widest dx spread (ChunkInfo::cols)
+    int slab_bytes;  // rows_max * cols * BYTES
     int stride;      // distance of the group's slabs in LDS: slab_bytes rounded up to a wave's 1 KiB of pieces, so that
                      // a wave can write all 64 of its pieces without a lane mask
     int E;           // epochs per group
@@ -187,8 +193,9 @@ struct ChunkPlan {
 template <int BYTES, int ROWS>
 __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) {
     ChunkPlan p;
-    const ConstIntPtr ci = as_const_ints(&a.chunks[chunk]);  // {dx_min, dx_max, dy_min, dy_max, unsafe, lds_ok, rows_max}
-    p.slab_bytes = ci[6] * LDS_COLS * BYTES;
+    const ConstIntPtr ci = as_const_ints(&a.chunks[chunk]);  // {dx_min, dx_max, dy_min, dy_max, unsafe, lds_ok, rows_max, cols}
+    p.cols = ci[7];
+    p.slab_bytes = ci[6] * p.cols * BYTES;
     p.stride = (p.slab_bytes + 1023) & ~1023;
     p.E = max(1, min(a.T, lds_group_bytes(ROWS) / p.stride));
     p.clean = (ci[4] == 0 && ci[5] != 0) ? 1 : 0;
@@ -203,12 +210,11 @@ __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) 
 // every shift, the array has no NO_DATA pixel, every epoch is staged): obs_count is T.
 template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, bool FAST>
 __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileCoords& tc, char* smem,
-                                                const StageLane& sl, TileLists<KS, LM>& lists) {
+                                                TileLists<KS, LM>& lists) {
     constexpr int SF = CANON ? 4 : NB;  // staged format
     using R = RawPair<SF>;
     constexpr int BYTES = 2 * fmt_bytes(SF);
     const int T = a.T;
-    const int lane_b = (tc.wv * LDS_COLS + tc.lane) * BYTES;  // this lane's start pixel inside a slab
 
     PairF acc[C];  // (psi_sum, phi_sum) as pairs: one v_pk_add_f32 per sample
     // observation counts, two 16-bit counts per register (a stack has at most 999 epochs): candidate c in half
@@ -227,7 +233,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     auto origin_of = [](Int4 r) { return (int64_t)(((uint64_t)(uint32_t)r.y << 32) | (uint64_t)(uint32_t)r.x); };
     // this tile's own pixel inside the padded copy
     const char* tile_base = reinterpret_cast<const char*>(a.padded) + ((int64_t)tc.tile_y0 * a.Wp + tc.tile_x0) * BYTES;
-    StageLane n_sl = clip_lane<ROWS>(sl, plan.slab_bytes);  // staging map of the group being copied
+    StageLane n_sl = stage_lanes<BYTES, ROWS>(a, plan.cols, plan.slab_bytes);  // staging map of the group being copied
     {
         const ConstSlabPtr org = (ConstSlabPtr)(uintptr_t)(a.slabs + (size_t)chunk * T);
         const int n = min(plan.E, T);
@@ -236,7 +242,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             load_slab<BYTES, ROWS>(a, n_sl, tile_base + o, plan.slab_bytes, regs);
             write_slab<ROWS>(smem + e * plan.stride, plan.slab_bytes, regs);
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            copy_slab_tail<BYTES, ROWS>(a, sl, tile_base + o, plan.slab_bytes, smem + e * plan.stride, regs);
+            copy_slab_tail<BYTES, ROWS>(a, n_sl, tile_base + o, plan.slab_bytes, plan.cols, smem + e * plan.stride, regs);
         }
     }
     __syncthreads();
@@ -250,7 +256,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             n_t0 = 0;
             if (n_chunk < a.chunk_hi) {
                 n_plan = chunk_plan<BYTES, ROWS>(a, n_chunk);
-                n_sl = clip_lane<ROWS>(sl, n_plan.slab_bytes);
+                n_sl = stage_lanes<BYTES, ROWS>(a, n_plan.cols, n_plan.slab_bytes);
             }
         }
         const int n_next = (n_chunk < a.chunk_hi) ? min(n_plan.E, T - n_t0) : 0;
@@ -268,12 +274,12 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             write_slab<ROWS>(nb + e * n_plan.stride, n_plan.slab_bytes, regs);
             if (n_plan.slab_bytes > LDS_SLOTS * stage_round(ROWS)) {  // uniform, rare
                 __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-                copy_slab_tail<BYTES, ROWS>(a, sl, n_base, n_plan.slab_bytes, nb + e * n_plan.stride, regs);
+                copy_slab_tail<BYTES, ROWS>(a, n_sl, n_base, n_plan.slab_bytes, n_plan.cols, nb + e * n_plan.stride, regs);
             }
         };
 
         const ConstIntPtr offs = as_const_ints(a.lds_off + ((size_t)chunk * T + t0) * C);  // offsets for 8-byte pairs
-        const char* cb = smem + buf * lds_group_bytes(ROWS) + lane_b;
+        const char* cb = smem + buf * lds_group_bytes(ROWS) + (tc.wv * plan.cols + tc.lane) * BYTES;  // this lane's start pixel inside a slab
         const int n_cur = min(plan.E, T - t0);
         // C samples of one staged epoch with uniform shifts: slab offsets o[] (scalars) -> LDS reads -> sums
         auto no_hook = []() {};
@@ -516,23 +522,15 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
                           : reinterpret_cast<char*>(a.lists) +
                                     ((size_t)(tc.ty * a.tiles_x + tc.tx) * KS) * (ROWS * WAVE * TileLists<KS, LM>::SLOT_BYTES);
 
-    StageLane sl;
-#pragma unroll
-    for (int j = 0; j < LDS_SLOTS; ++j) {
-        const int p = 16 * ((int)threadIdx.x + (ROWS * WAVE) * j) / BYTES;  // first pixel of this thread's 16 bytes
-        const int r = p / LDS_COLS, c = p - r * LDS_COLS;
-        sl.goff[j] = (uint32_t)(r * a.Wp + c) * (uint32_t)BYTES;
-    }
-
     // Workgroup-uniform: can any sample of this tile be NO_DATA?
     const ConstIntPtr gb = as_const_ints(a.global_box);
     const bool fast = a.all_staged && as_const_ints(a.n_invalid)[0] == 0 && (tc.tile_x0 + gb[0] >= 0) &&
                       (tc.tile_x0 + WAVE + gb[1] <= a.W) && (tc.tile_y0 + gb[2] >= 0) &&
                       (tc.tile_y0 + ROWS + gb[3] <= a.H);
     if (fast) {
-        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, true>(a, tc, smem, sl, lists);
+        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, true>(a, tc, smem, lists);
     } else {
-        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, false>(a, tc, smem, sl, lists);
+        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, false>(a, tc, smem, lists);
     }
     if constexpr (!SIGMAG) {
         if constexpr (TileLists<KS, LM>::STORED) {
