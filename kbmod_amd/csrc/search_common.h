@@ -37,7 +37,7 @@ __host__ __device__ constexpr int stage_round(int rows) { return rows * WAVE * 1
 __host__ __device__ constexpr int lds_group_bytes(int rows) { return 5120 * rows; }   // one of the two group buffers
 
 // LDS staging (kb_search_lds): per (chunk, epoch) the workgroup stages a slab of
-// rows_max(chunk) x LDS_COLS raw pairs -- the union footprint of its 64 x ROWS tile
+// rows_max(chunk) x cols(chunk) raw pairs -- the union footprint of its 64 x ROWS tile
 // under the chunk's shifts -- from a padded HBM copy of the array into a ring of slab slots in LDS.
 #ifndef KB_LDS_COLS
 #define KB_LDS_COLS 88

@@ -18,10 +18,10 @@ namespace kb {
 
 constexpr int STAGE_DEPTH = KB_STAGE_DEPTH;  // staged slabs a wave holds in registers: 1, or 2 (eight more registers)
 
-// Staging map.  A slab (rows x LDS_COLS raw pairs, dense) is copied in workgroup-wide steps of
-// 4 KiB: in step j thread tid moves the 16 bytes at slab offset o = 16 * (tid + 256 j), i.e.
-// pixel p = o / BYTES = (row, col) = divmod(p, LDS_COLS) of the slab, from the padded array at
-// the slab origin plus (row * Wp + col) * BYTES.  The copy goes through registers
+// Staging map.  A slab (rows x cols raw pairs, dense; cols = the chunk's pitch) is copied in workgroup-wide
+// rounds of 16 * ROWS * 64 bytes: in round j thread tid moves the 16 bytes at slab offset
+// o = 16 * (tid + ROWS * 64 * j), i.e. pixel p = o / BYTES = (row, col) = divmod(p, cols) of the slab, from the
+// padded array at the slab origin plus (row * Wp + col) * BYTES (stage_lanes).  The copy goes through registers
 // (global_load_dwordx4 -> ds_write_b128): measured on MI355X the LDS-DMA form of the same copy
 // (global_load_lds_dwordx4) sustains only ~12 B/clk/CU and stalls the issuing wave.
 struct StageLane {
@@ -90,7 +90,7 @@ __device__ __forceinline__ void write_slab(char* dst, int slab_bytes, const Slab
     }
 }
 
-// Rounds after the first of a slab larger than LDS_SLOTS x 4 KiB (load, then write, no overlap).
+// Rounds after the first LDS_SLOTS of a larger slab (load, then write, no overlap).
 template <int BYTES, int ROWS>
 __device__ __forceinline__ void copy_slab_tail(const SearchArgs& a, const StageLane& sl, const char* base, int slab_bytes,
                                                int cols, char* dst, SlabRegs& regs) {
