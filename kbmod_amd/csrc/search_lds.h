@@ -283,7 +283,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
         const int n_cur = min(plan.E, T - t0);
         // C samples of one staged epoch with uniform shifts: slab offsets o[] (scalars) -> LDS reads -> sums
         auto no_hook = []() {};
-        auto sum_epoch = [&](const int (&o)[C], int e, auto between) {
+        auto sum_epoch = [&](const int (&o)[C], const char* rb, auto between) {  // rb: this lane's pixel in the epoch's slab
             // eight reads in flight at a time (a chunk of 16 goes in two halves: the registers of the samples
             // are the ones this kernel is short of)
             constexpr int HALF = 8;
@@ -293,7 +293,15 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
                 for (int c = 0; c < HALF; ++c) {
                     const int off = (BYTES == 8) ? o[c0 + c] : (o[c0 + c] >> 3) * BYTES;
-                    raw[c] = *reinterpret_cast<const typename R::type*>(cb + e * plan.stride + off);
+                    // (an LDS-typed pointer: through the generic one every read paid a scalar add of the aperture's zero)
+                    if constexpr (BYTES == 8) {
+                        typedef const __attribute__((address_space(3))) PairF* LdsPair;
+                        const PairF v = *(LdsPair)(uint32_t)(uintptr_t)(rb + off);
+                        raw[c].x = v.x;
+                        raw[c].y = v.y;
+                    } else {
+                        raw[c] = *reinterpret_cast<const typename R::type*>(rb + off);
+                    }
                 }
                 if (c0 == 0) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -351,6 +359,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             auto staged_run = [&](auto np_tag) {
                 constexpr int NP = decltype(np_tag)::value;
                 char* wdst = nb + 16 * (int)threadIdx.x;
+                const char* rptr = cb + e * plan.stride;  // this lane's pixel in the slab being summed
                 int64_t org_nxt = origin_of(n_org[1]);  // origin of the slab whose loads are issued next
                 auto load = [&](Piece (&v)[LDS_SLOTS], int64_t org) {
                     const char* base = tile_base + org;
@@ -369,7 +378,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     // and waited for together with them, i.e. BEFORE the slab is written.  The wait for a scalar
                     // load is a wait for every LDS operation of the wave; placed behind the write, as it was, it
                     // holds the next epoch's reads until that write has completed.
-                    sum_epoch(o_cur, e, [&]() {
+                    sum_epoch(o_cur, rptr, [&]() {
                         ConstIntPtr po = offs + (e + 1) * C;
                         ConstSlabPtr pg = n_org + (e + STAGE_DEPTH);
 #pragma unroll
@@ -386,6 +395,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
                     for (int j = 0; j < NP; ++j) *reinterpret_cast<Piece*>(wdst + stage_round(ROWS) * j) = v[j];
                     wdst += n_plan.stride;
+                    rptr += plan.stride;
                     ++e;
                 };
                 if constexpr (STAGE_DEPTH == 2) {
@@ -436,7 +446,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     n_base = tile_base + org_cur;
                     load_slab<BYTES, ROWS>(a, n_sl, n_base, n_plan.slab_bytes, regs);
                 }
-                sum_epoch(o_cur, e, no_hook);
+                sum_epoch(o_cur, cb + e * plan.stride, no_hook);
                 pin_sums();
                 ConstIntPtr po = offs + (e + 1) * C;
                 ConstSlabPtr pg = n_org + (e + 1);
@@ -454,7 +464,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
                 for (int c = 0; c < C; ++c) o[c] = offs[e * C + c];
                 if (o[0] >= 0) {
-                    sum_epoch(o, e, no_hook);
+                    sum_epoch(o, cb + e * plan.stride, no_hook);
                 } else {
                     special_epoch<C, SF, CANON>(a, tc, chunk, t0 + e, o[0] == LDS_OFF_PER_LANE,
                                                 smem + buf * lds_group_bytes(ROWS) + e * plan.stride, acc, cntp);
