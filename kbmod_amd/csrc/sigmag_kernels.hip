@@ -69,14 +69,15 @@ struct Samples {
 // Clip of ONE trajectory by the whole wavefront (T <= 64, all 64 lanes active).  Returns false when a
 // run of equal ratios mixes different (psi, phi) pairs: the exchange sort's own order then matters
 // and the caller runs the literal code for that lane.
+// *lh_out / *flux_out receive the two clipped SUMS (psi, phi); the caller divides (once per work item).
 __device__ __forceinline__ bool clip_wave(const ResolveArgs& a, int lane, const Samples s, float* lh_out, float* flux_out,
                                           int* obs_out) {
     const bool valid = __builtin_isfinite(s.psi) && __builtin_isfinite(s.phi);
     const int n = __popcll(__ballot(valid));
     *obs_out = n;
     if (n == 0) {  // kernels.cu:201: nothing to clip, the unclipped values stand
-        *lh_out = -1.0f;
-        *flux_out = -1.0f;
+        *lh_out = 0.0f;  // sums (0, 0): lh_from_sums / flux_from_sums give the -1 of kernels.cu:201
+        *flux_out = 0.0f;
         return true;
     }
     const float lc = valid ? ((s.phi != 0.0f) ? (s.psi / s.phi) : 0.0f) : 0.0f;
@@ -125,8 +126,8 @@ __device__ __forceinline__ bool clip_wave(const ResolveArgs& a, int lane, const 
         acc_phi = chain_add(acc_phi, sphi);
     }
     const float new_psi = lane_value(acc_psi, max_keep), new_phi = lane_value(acc_phi, max_keep);
-    *lh_out = lh_from_sums(new_psi, new_phi);
-    *flux_out = flux_from_sums(new_psi, new_phi);
+    *lh_out = new_psi;
+    *flux_out = new_phi;
     return true;
 }
 
@@ -158,8 +159,8 @@ __device__ __forceinline__ bool clip_wave_multi(const ResolveArgs& a, int lane, 
     }
     *obs_out = n;
     if (n == 0) {  // kernels.cu:201: nothing to clip, the unclipped values stand
-        *lh_out = -1.0f;
-        *flux_out = -1.0f;
+        *lh_out = 0.0f;  // sums (0, 0): lh_from_sums / flux_from_sums give the -1 of kernels.cu:201
+        *flux_out = 0.0f;
         return true;
     }
     wave_sort_multi<E>(key, src, lane);
@@ -241,8 +242,8 @@ __device__ __forceinline__ bool clip_wave_multi(const ResolveArgs& a, int lane, 
             sum_phi = lane_value(acc_phi, hi);
         }
     }
-    *lh_out = lh_from_sums(sum_psi, sum_phi);
-    *flux_out = flux_from_sums(sum_psi, sum_phi);
+    *lh_out = sum_psi;
+    *flux_out = sum_phi;
     return true;
 }
 
@@ -337,6 +338,13 @@ __global__ __launch_bounds__(CLIP_BLOCK) void kb_sigmag_clip_kernel(const Resolv
                 }
                 L = L_next;
             }
+        }
+        if (cooperative) {
+            // lh / flux of every clipped trajectory of the entry at once: until here lane L carried the two clipped
+            // sums of its trajectory (one correctly rounded sqrt and two divides per entry instead of per trajectory)
+            const float sum_psi = lh, sum_phi = flux;
+            lh = lh_from_sums(sum_psi, sum_phi);
+            flux = flux_from_sums(sum_psi, sum_phi);
         }
         n_literal += (unsigned long long)__popcll(literal);
         if ((literal >> lane) & 1) {  // kernels.cu:154-242 as written, one trajectory per lane
