@@ -1,0 +1,26 @@
+"""End-to-end time of StackSearch.search_all(on_gpu=True) at cfg2 (what a caller of the pybind surface sees: search,
+filter + sort in HBM, download of the survivors into the host list)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401  (first: two copies of the HIP runtime cannot both initialise)
+import kbmod_amd.search as kb
+from kbmod_amd import fake_data as fd
+
+rng = np.random.default_rng(1)
+T, H, W = 64, 512, 512
+sci = (rng.standard_normal((T, H, W)) * 2).astype(np.float32)
+var = np.full((T, H, W), 4.0, dtype=np.float32)
+psf = fd.make_gaussian_kernel(1.0)
+s = kb.StackSearch.from_image_stacks(sci, var, [psf] * T, list(np.arange(T) / T))
+s.preload_psi_phi_array()
+vx, vy = fd.kbmod_v1_candidates(32, 5.0, 40.0, 32, 0.0, 1.5)
+cands = [kb.Trajectory(0, 0, float(a), float(b)) for a, b in zip(vx, vy)]
+for min_lh in (0.0, 10.0):
+    s.set_min_lh(min_lh)
+    for rep in range(4):
+        t0 = time.perf_counter()
+        s.search_all(cands, True)
+        t1 = time.perf_counter()
+        n = s.get_number_total_results()
+        print(f"min_lh {min_lh}: search_all {1e3 * (t1 - t0):.2f} ms, {n} results kept, kernel {s.last_search_stats()['search_kernel_ms']:.2f} ms")
