@@ -492,6 +492,7 @@ __host__ __device__ constexpr size_t scratch_words_per_wave(int T) { return (siz
 void launch_search_direct(const SearchArgs& a, int fmt, bool sigmag, bool records, hipStream_t stream);
 void launch_search_large_k(const SearchArgs& a, bool sigmag, int blocks, hipStream_t stream);
 void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, int list_mode, hipStream_t stream);
+void launch_search_lds_canon_deep(const SearchArgs& a, int rows, bool sigmag, hipStream_t stream);  // search_lds_deep.hip
 void launch_search_lds_encoded(const SearchArgs& a, int rows, int fmt, bool sigmag, hipStream_t stream);
 
 int launch_sigmag_resolve(const SearchArgs& a, const SearchCold& cold, const ResultSink* prev, const ResultSink& next,

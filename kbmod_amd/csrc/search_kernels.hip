@@ -479,9 +479,11 @@ static SearchArgs with_tile_rows(SearchArgs a, int rows) {
 }
 
 // which: 0 = kb_search_direct, 1 = kb_search_lds on an encoded padded copy, 2 = kb_search_lds on canonical floats
-static void launch_search(const SearchArgs& a, int fmt, bool sigmag, int which, int lds_rows, int list_mode,
+static void launch_search(const SearchArgs& a, int fmt, bool sigmag, int which, int lds_rows, int list_mode, bool deep,
                           hipStream_t stream) {
-    if (which == 2) {
+    if (which == 2 && deep) {
+        launch_search_lds_canon_deep(with_tile_rows(a, lds_rows), lds_rows, sigmag, stream);
+    } else if (which == 2) {
         launch_search_lds_canon(with_tile_rows(a, lds_rows), lds_rows, sigmag, list_mode, stream);
     } else if (which == 1) {
         launch_search_lds_encoded(with_tile_rows(a, lds_rows), lds_rows, fmt, sigmag, stream);
@@ -635,6 +637,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     // load), the staged kernel reads each slab once per workgroup and sums out of LDS.
     int which = 0;
     int padded_reused = 0;
+    uint64_t padded_copy_bytes = 0;
     const bool want_lds = (flags & 2u) == 0 && (flags & 1u) == 0 && a.K <= 32 &&
                           (n_cands >= 8 || (flags & 4u) != 0);
     if (n_cands > 0) {
@@ -738,6 +741,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 if ((canon || encoded_instance) && (uint64_t)rows_cap * (uint64_t)Wp * pair_bytes <= 0x7fffffffull &&
                     frame <= 4ull * image + (8ull << 20) && room_for(padded_bytes) && try_workspace(2, padded_bytes, &padded)) {
                     a.padded = padded;
+                    padded_copy_bytes = padded_bytes;
                     a.Wp = (int)Wp;
                     cold.Hp = (int)Hp;
                     cold.px0 = (int)px0;
@@ -850,6 +854,12 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     // candidates; registers / ids cost an exact re-evaluation of every winner: K x T samples per pixel),
     // (likelihood, candidate) pairs in that store for lists of more than 8, registers otherwise.
     // KBMOD_LIST_MODE = 0 / 1 / 2 overrides where the pair (K, mode) exists (tests).
+    // Two staged slabs in flight per wave (search_lds_deep.hip) when the float copy does not fit the 256 MiB
+    // Infinity Cache: its loads then come from HBM.  Those instances keep their lists in the HBM store (records up to
+    // 8, pairs beyond).  KBMOD_STAGE_DEPTH = 1 / 2 overrides (tests).
+    bool deep = which == 2 && padded_copy_bytes > (256ull << 20);
+    if (const char* env = std::getenv("KBMOD_STAGE_DEPTH")) deep = which == 2 && std::atoi(env) == 2;
+    if (a.K > 32) deep = false;
     a.lists = nullptr;
     int list_mode = 0;
     if (!sigmag && a.K <= 32) {
@@ -864,6 +874,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 list_mode = want;
             }
         }
+        if (deep) list_mode = ks == 8 ? 2 : 1;
         if (which != 2 && list_mode == 3) list_mode = 0;
         if (which == 1 && list_mode != 0) list_mode = 0;  // encoded staging: registers (K <= 8)
         if (which == 2 && (list_mode == 1 || list_mode == 2)) {
@@ -874,6 +885,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 a.lists = reinterpret_cast<uint2*>(lists);
             } else if (ks == 8) {
                 list_mode = packable ? 3 : 0;  // no room for the store: lists of 8 fit the registers
+                deep = false;                  // (the one-deep instances)
             } else {
                 which = 0;  // ... longer ones do in kb_search_direct
             }
@@ -907,7 +919,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
             a.chunk_hi = std::min(a.n_chunks, a.chunk_lo + batch_chunks);
             KB_HIP_TRY(hipMemsetAsync(cold.sg.slots, 0, (size_t)n_rows * cold.sg.batch_cands * sizeof(uint32_t), stream));
             KB_HIP_TRY(hipMemsetAsync(cold.sg.n_entries, 0, sizeof(int), stream));
-            if (a.chunk_lo < a.chunk_hi) launch_search(a, fmt, true, which, lds_rows, 0, stream);  // the emitting instances keep no list
+            if (a.chunk_lo < a.chunk_hi) launch_search(a, fmt, true, which, lds_rows, 0, deep, stream);  // the emitting instances keep no list
             KB_HIP_TRY(hipGetLastError());
             const ResultSink* next = &bufs[(n_batches - 1 - b) % 2];
             if (launch_sigmag_resolve(a, cold, prev, *next, resolve_waves, stream)) return 1;
@@ -915,7 +927,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         }
         variant = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
     } else {
-        launch_search(a, fmt, false, which, lds_rows, list_mode, stream);
+        launch_search(a, fmt, false, which, lds_rows, list_mode, deep, stream);
         variant = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
     }
     KB_HIP_TRY(hipGetLastError());

@@ -10,13 +10,7 @@
 
 #pragma clang fp contract(off)
 
-#ifndef KB_STAGE_DEPTH
-#define KB_STAGE_DEPTH 1
-#endif
-
 namespace kb {
-
-constexpr int STAGE_DEPTH = KB_STAGE_DEPTH;  // staged slabs a wave holds in registers: 1, or 2 (eight more registers)
 
 // Staging map.  A slab (rows x cols raw pairs, dense; cols = the chunk's pitch) is copied in workgroup-wide
 // rounds of 16 * ROWS * 64 bytes: in round j thread tid moves the 16 bytes at slab offset
@@ -208,7 +202,7 @@ __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) 
 // the epoch's sums and written to LDS after them.
 // FAST: no sample of this tile can be NO_DATA (the tile stays inside the image under
 // every shift, the array has no NO_DATA pixel, every epoch is staged): obs_count is T.
-template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, bool FAST>
+template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, int STAGE_DEPTH, bool FAST>
 __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileCoords& tc, char* smem,
                                                 TileLists<KS, LM>& lists) {
     constexpr int SF = CANON ? 4 : NB;  // staged format
@@ -517,7 +511,10 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 }
 
 
-template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, int LM>
+// STAGE_DEPTH: staged slabs a wave holds in registers -- 1, or 2 (about 20 more registers) for arrays that do not
+// fit the Infinity Cache: the loads of a slab then have two epochs of sums to cover the latency of HBM (cfg5 2.80
+// -> 2.10 s, cfg4 share 51.3 -> 41.1 ms; nothing for the cache-resident cfg2 / cfg3).
+template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, int STAGE_DEPTH>
 // second launch bound = waves per SIMD: 16 waves per CU (one 64 x 16 or two 64 x 8 workgroups)
 __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // two group buffers
@@ -538,9 +535,9 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
                       (tc.tile_x0 + WAVE + gb[1] <= a.W) && (tc.tile_y0 + gb[2] >= 0) &&
                       (tc.tile_y0 + ROWS + gb[3] <= a.H);
     if (fast) {
-        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, true>(a, tc, smem, lists);
+        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH, true>(a, tc, smem, lists);
     } else {
-        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, false>(a, tc, smem, lists);
+        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH, false>(a, tc, smem, lists);
     }
     if constexpr (!SIGMAG) {
         if constexpr (TileLists<KS, LM>::STORED) {
@@ -555,12 +552,12 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
 }
 
 // Launch of one instance (two group buffers beyond the default 64 KiB of dynamic LDS need the attribute raised).
-template <int KS, int ROWS, int NB, bool CANON, bool SIGMAG, int LM>
+template <int KS, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, int STAGE_DEPTH = 1>
 static void launch_lds(const SearchArgs& a, hipStream_t stream) {
     constexpr size_t lds_bytes = 2 * lds_group_bytes(ROWS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb_search_lds<KS, CHUNK, ROWS, NB, CANON, SIGMAG, LM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb_search_lds<KS, CHUNK, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, ROWS, NB, CANON, SIGMAG, LM>), dim3(a.n_tiles), dim3(ROWS * WAVE), lds_bytes,
+    hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH>), dim3(a.n_tiles), dim3(ROWS * WAVE), lds_bytes,
                        stream, a);
 }
 

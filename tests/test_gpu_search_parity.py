@@ -200,6 +200,21 @@ def test_list_modes_agree_with_the_oracle(kb, orc, stack, cands, K, mode, kern, 
         assert len(got) > 100
 
 
+@pytest.mark.parametrize("cfg", [{"K": 4, "min_lh": -1e30}, {"K": 8, "min_obs": 9, "min_lh": 1.0}, {"K": 12, "min_lh": -1e30},
+                                 {"K": 32, "min_obs": 5}, {"sigmag": (0.25, 0.75, 0.7413, 5.0), "min_obs": 8},
+                                 {"K": 6, "xb": (-20, 130), "yb": (-15, 95), "min_lh": -1e30}])
+@pytest.mark.parametrize("num_bytes", [-1, 1])
+@pytest.mark.parametrize("tiles", ["lds", "lds_tall"])
+def test_two_slabs_in_flight(kb, orc, stack, lds_cands, cfg, num_bytes, tiles, monkeypatch):
+    # The instances the host launches for arrays beyond the Infinity Cache (two staged slabs in flight per wave,
+    # lists in the HBM store), pinned here on a small stack with KBMOD_STAGE_DEPTH.
+    monkeypatch.setenv("KBMOD_STAGE_DEPTH", "2")
+    got, exp, s = util.run_both(kb, orc, stack, *lds_cands, cfg, num_bytes=num_bytes, flags=KERNELS[tiles])
+    assert _variant(s) == 2
+    _check(got, exp)
+    assert len(got) > 50
+
+
 def test_repeated_searches_reuse_the_padded_copy(kb, orc, stack, cands):
     # A StackSearch with its array resident in HBM tells the library, from its second search on, that the array is
     # unchanged (flag 256): the padded copy of kb_search_lds is reused while the frame geometry stays the same,
