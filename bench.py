@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--verify", action="store_true",
                     help="after timing: size-independent checks of the last result buffer (both kernels agree bit for "
                          "bit, per-pixel lists sorted, a start window re-done with exact per-lane positions agrees)")
+    ap.add_argument("--reuse-padded-copy", action="store_true",
+                    help="from the second step on tell the library that the array is unchanged (flag 256), as a StackSearch "
+                         "with a resident array does: the decode-and-pad pass is then skipped (not the default: a step is a whole search)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the CPU baseline sample")
     args = ap.parse_args()
@@ -203,9 +206,10 @@ def main():
 
     def step(record):
         st = Stats()
-        # flag 256: the array has not changed since the previous search (what a StackSearch with a resident array
-        # passes from its second search on); the library then keeps the padded float copy of the last search
-        flags = args.flags | (256 if searched[0] else 0)
+        # Every step is a whole search: tables, decode-and-pad pass, search kernel.  --reuse-padded-copy adds flag 256
+        # from the second step on (the array has not changed since the previous search: what a StackSearch with a
+        # resident array passes), which lets the library keep the padded float copy of the last search.
+        flags = args.flags | (256 if (searched[0] and args.reuse_padded_copy) else 0)
         searched[0] = True
         if world > 1:
             check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), n_local,
