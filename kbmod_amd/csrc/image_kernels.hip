@@ -112,6 +112,54 @@ __device__ __forceinline__ float masked_correlate(const float* __restrict__ tile
     return (sum * ktot) / part;
 }
 
+// The same correlation where every tap is known to be valid (a tile that lies inside the image with its halo and
+// holds no NaN): the validity tests and the running sum of the taps' weights disappear -- that sum, taken in
+// the same row-major order from 0, IS ktot (image_utils_cpp.cpp:27-33 sums the kernel the same way), so the
+// result (sum * ktot) / ktot has the same bits.  DIM is a compile-time constant: the loops unroll, the samples are
+// read at immediate offsets, the weights sit in scalar registers.
+typedef const __attribute__((address_space(4))) float* ConstWeights;  // the kernel's weights in global memory, read by scalar loads
+template <int DIM>
+__device__ __forceinline__ float clean_correlate(const float* __restrict__ tile, int pitch, int lx, int ly,
+                                                 ConstWeights k, int tile_rad, float ktot, int empty_is_nan) {
+    constexpr int RAD = (DIM - 1) / 2;
+    const float* centre = tile + (ly + tile_rad) * pitch + lx + tile_rad;
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = -RAD; j <= RAD; ++j) {
+#pragma unroll
+        for (int i = -RAD; i <= RAD; ++i) {
+            const float kk = k[(j + RAD) * DIM + i + RAD];  // uniform address in the constant address space: a scalar load
+            sum += centre[j * pitch + i] * kk;
+        }
+    }
+    if (ktot == 0.0f) return empty_is_nan ? NAN : 0.0f;
+    return (sum * ktot) / ktot;
+}
+
+// Dispatch on the epoch's kernel size (uniform); sizes without an unrolled instance take the general loop, which
+// on a clean tile gives the same bits.
+__device__ __forceinline__ float clean_correlate_dim(const float* __restrict__ tile, int pitch, int lx, int ly,
+                                                     const float* __restrict__ k, const float* k_global, int dim, int rad,
+                                                     int tile_rad, float ktot, int empty_is_nan) {
+    const ConstWeights kg = (ConstWeights)(uintptr_t)k_global;
+    switch (dim) {
+        case 3:
+            return clean_correlate<3>(tile, pitch, lx, ly, kg, tile_rad, ktot, empty_is_nan);
+        case 5:
+            return clean_correlate<5>(tile, pitch, lx, ly, kg, tile_rad, ktot, empty_is_nan);
+        case 7:
+            return clean_correlate<7>(tile, pitch, lx, ly, kg, tile_rad, ktot, empty_is_nan);
+        case 9:
+            return clean_correlate<9>(tile, pitch, lx, ly, kg, tile_rad, ktot, empty_is_nan);
+        case 11:
+            return clean_correlate<11>(tile, pitch, lx, ly, kg, tile_rad, ktot, empty_is_nan);
+        case 13:
+            return clean_correlate<13>(tile, pitch, lx, ly, kg, tile_rad, ktot, empty_is_nan);
+        default:
+            return masked_correlate(tile, pitch, lx, ly, k, dim, rad, tile_rad, ktot, empty_is_nan);
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void kb_conv_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -133,6 +181,7 @@ __global__ __launch_bounds__(256) void kb_conv_kernel(const ConvArgs a) {
         k0[e] = a.psf[a.psf_off[t] + e];
         if (MODE == 1) k1[e] = a.psf[a.sq_base + a.psf_off[t] + e];
     }
+    bool all_finite = true;  // every value this thread staged (out-of-image taps are staged as NaN)
     for (int e = threadIdx.x; e < pitch * rows; e += 256) {
         const int ly = e / pitch, lx = e - ly * pitch;
         const int gx = x0 + lx - R, gy = y0 + ly - R;
@@ -152,16 +201,26 @@ __global__ __launch_bounds__(256) void kb_conv_kernel(const ConvArgs a) {
         }
         tile0[e] = v0;
         if (MODE == 1) tile1[e] = v1;
+        all_finite = all_finite && __builtin_isfinite(v0) && (MODE == 0 || __builtin_isfinite(v1));
     }
-    __syncthreads();
+    // (also the barrier between staging and correlation) a clean tile: inside the image with its halo, no NaN
+    const bool clean = __syncthreads_and(all_finite ? 1 : 0) != 0;
 
     const int lx = threadIdx.x % CONV_BX, ly = threadIdx.x / CONV_BX;
     const int gx = x0 + lx, gy = y0 + ly;
     const bool inside = gx < a.W && gy < a.H;
     float psi = NAN, phi = NAN;
-    if (inside) {
+    if (inside && clean) {  // clean is uniform, and a clean tile has every pixel inside
+        psi = clean_correlate_dim(tile0, pitch, lx, ly, k0, a.psf + a.psf_off[t], dim, rad, R, a.psf_tot[t], a.empty_is_nan);
+        if (MODE == 1) {
+            phi = clean_correlate_dim(tile1, pitch, lx, ly, k1, a.psf + a.sq_base + a.psf_off[t], dim, rad, R, a.psf_tot[a.T + t],
+                                      a.empty_is_nan);
+        }
+    } else if (inside) {
         psi = masked_correlate(tile0, pitch, lx, ly, k0, dim, rad, R, a.psf_tot[t], a.empty_is_nan);
         if (MODE == 1) phi = masked_correlate(tile1, pitch, lx, ly, k1, dim, rad, R, a.psf_tot[a.T + t], a.empty_is_nan);
+    }
+    if (inside) {
         const size_t p = img + (size_t)gy * a.W + gx;
         if (MODE == 0) {
             a.out_plain[p] = psi;
