@@ -849,11 +849,12 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     a.cold = reinterpret_cast<const SearchCold*>(cold_dev);
     KB_HIP_TRY(hipMemcpyAsync(cold_dev, &cold, sizeof(SearchCold), hipMemcpyHostToDevice, stream));
 
-    // Where kb_search_lds keeps its per-pixel lists (ListMode, search_lds.h): whole result records in the HBM store
-    // when the candidate list is short against the stack depth (the store is visited once per chunk of
-    // candidates; registers / ids cost an exact re-evaluation of every winner: K x T samples per pixel),
-    // (likelihood, candidate) pairs in that store for lists of more than 8, registers otherwise.
-    // KBMOD_LIST_MODE = 0 / 1 / 2 overrides where the pair (K, mode) exists (tests).
+    // Where kb_search_lds keeps its per-pixel lists (ListMode, search_lds.h): lists of up to 8 as packed result
+    // records in registers (3); longer ones, or candidate indices beyond 16 bits, as whole records in the HBM store
+    // when the candidate list is short against the stack depth (2: the store is visited once per chunk of
+    // candidates, the alternative costs an exact re-evaluation of every winner, K x T samples per pixel), else as
+    // (likelihood, candidate) pairs in that store (1, lists of more than 8) or in registers (0).
+    // KBMOD_LIST_MODE = 0 / 1 / 2 / 3 overrides where the pair (K, mode) exists (tests).
     // Two staged slabs in flight per wave (search_lds_deep.hip) when the float copy does not fit the 256 MiB
     // Infinity Cache: its loads then come from HBM.  Those instances keep their lists in the HBM store (records up to
     // 8, pairs beyond).  KBMOD_STAGE_DEPTH = 1 / 2 overrides (tests).
@@ -867,7 +868,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         const bool short_list = a.n_chunks <= a.T;
         // (3: packed records in registers, K <= 8 on the float-staged kernel; candidate index and count share a word)
         const bool packable = ks == 8 && which == 2 && a.n_cands < 65535 && a.T < 65535;
-        list_mode = ks == 32 ? 1 : (short_list ? 2 : (ks == 16 ? 1 : (packable ? 3 : 0)));
+        list_mode = ks == 32 ? 1 : (packable ? 3 : (short_list ? 2 : (ks == 16 ? 1 : 0)));
         if (const char* env = std::getenv("KBMOD_LIST_MODE")) {
             const int want = std::atoi(env);
             if ((ks == 8 && (want == 0 || want == 2 || (want == 3 && packable))) || (ks == 16 && (want == 1 || want == 2))) {
