@@ -855,10 +855,13 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     // candidates, the alternative costs an exact re-evaluation of every winner, K x T samples per pixel), else as
     // (likelihood, candidate) pairs in that store (1, lists of more than 8) or in registers (0).
     // KBMOD_LIST_MODE = 0 / 1 / 2 / 3 overrides where the pair (K, mode) exists (tests).
-    // Two staged slabs in flight per wave (search_lds_deep.hip) when the float copy does not fit the 256 MiB
-    // Infinity Cache: its loads then come from HBM.  Those instances keep their lists in the HBM store (records up to
-    // 8, pairs beyond).  KBMOD_STAGE_DEPTH = 1 / 2 overrides (tests).
-    bool deep = which == 2 && padded_copy_bytes > (256ull << 20);
+    // Two staged slabs in flight per wave (search_lds_deep.hip; those instances keep their lists in the HBM store:
+    // records up to 8, pairs beyond).  What decides is measured: the second slab pays from
+    // about a hundred epochs per stack on whatever the image size (512 x 512 x 128: -12 %, 2048 x 2048 x 256: -20 %),
+    // below that only for copies of several GiB (4096 x 4096 x 64: -4 %), and costs 6-8 % where it does not pay
+    // (512 x 512 x 96, 4096 x 4096 x 32).  KBMOD_STAGE_DEPTH = 1 / 2 overrides (tests).
+    bool deep = which == 2 && (a.T >= 128 || (a.T > 64 && padded_copy_bytes > (1ull << 30)) ||
+                               (a.T >= 64 && padded_copy_bytes > (4ull << 30)));
     if (const char* env = std::getenv("KBMOD_STAGE_DEPTH")) deep = which == 2 && std::atoi(env) == 2;
     if (a.K > 32) deep = false;
     a.lists = nullptr;

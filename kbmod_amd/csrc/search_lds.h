@@ -511,9 +511,9 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 }
 
 
-// STAGE_DEPTH: staged slabs a wave holds in registers -- 1, or 2 (about 20 more registers) for arrays that do not
-// fit the Infinity Cache: the loads of a slab then have two epochs of sums to cover the latency of HBM (cfg5 2.80
-// -> 2.10 s, cfg4 share 51.3 -> 41.1 ms; nothing for the cache-resident cfg2 / cfg3).
+// STAGE_DEPTH: staged slabs a wave holds in registers -- 1, or 2 (about 20 more registers) for deep stacks: the loads
+// of a slab then have two epochs of sums to land in (cfg5 2.80 -> 2.10 s, cfg4 share 51.3 -> 41.1 ms; nothing at 64
+// epochs, whatever the size of the array: DESIGN.md section 3.3).
 template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, int STAGE_DEPTH>
 // second launch bound = waves per SIMD: 16 waves per CU (one 64 x 16 or two 64 x 8 workgroups)
 __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs a) {

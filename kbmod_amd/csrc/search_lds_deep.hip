@@ -1,5 +1,5 @@
 // kb_search_lds with two staged slabs in flight per wave (search_lds.h, STAGE_DEPTH = 2): the instances the host
-// launches when the padded float copy does not fit the Infinity Cache.  They need about 20 registers more than the
+// launches for deep stacks (from about a hundred epochs on, search_kernels.hip).  They need about 20 registers more than the
 // one-deep ones, so they exist for the list modes that leave room: the sigma-G emit, lists of up to 8 as records in
 // the HBM store, longer lists as (likelihood, candidate) pairs there.
 #include "search_lds.h"
