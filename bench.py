@@ -346,6 +346,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lib, meta, arr, tcpu, vx[sl], vy[sl], args.cpu_seconds)
 
+    if os.environ.get("KBMOD_EXP_PROFILE") and hasattr(lib, "kb_exp_read_profile"):
+        prof = (C.c_ulonglong * 8)()
+        lib.kb_exp_read_profile(prof)
+        waves = max(1, prof[6])
+        print("phase ticks per wave:", [round(prof[i] / waves) for i in range(6)], "waves", prof[6], file=sys.stderr)
     if rank == 0:
         print(json.dumps(out))
     lib.kb_free_gpu_block(arr)

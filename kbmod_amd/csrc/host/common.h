@@ -72,34 +72,24 @@ struct Trajectory {
     inline int get_x_index(double time) const { return (int)floor(get_x_pos(time, true)); }
     inline int get_y_index(double time) const { return (int)floor(get_y_pos(time, true)); }
 
-    void clear() {
-        x = 0;
-        y = 0;
-        vx = 0.0f;
-        vy = 0.0f;
-        lh = 0.0f;
-        flux = 0.0f;
-        obs_count = 0;
-    }
+    void clear() { *this = Trajectory(); }
     const std::string to_string() const {
         return "lh: " + std::to_string(lh) + " flux: " + std::to_string(flux) + " x: " + std::to_string(x) +
                " y: " + std::to_string(y) + " vx: " + std::to_string(vx) + " vy: " + std::to_string(vy) +
                " obs_count: " + std::to_string(obs_count);
     }
+    // every float field finite and a non-negative count (what TrajectoryList::assert_valid checks per entry)
     bool is_valid() const {
-        return (std::isfinite(vx) && std::isfinite(vy) && std::isfinite(lh) && std::isfinite(flux) &&
-                (obs_count >= 0));
+        for (float f : {vx, vy, lh, flux})
+            if (!std::isfinite(f)) return false;
+        return obs_count >= 0;
     }
+    // the Python constructor's argument order (x, y, vx, vy, flux, lh, obs_count) differs from the field order
     static Trajectory make_trajectory(int x, int y, float vx, float vy, float flux, float lh, int obs_count) {
-        Trajectory trj;
-        trj.x = x;
-        trj.y = y;
-        trj.vx = vx;
-        trj.vy = vy;
-        trj.flux = flux;
-        trj.lh = lh;
-        trj.obs_count = obs_count;
-        return trj;
+        Trajectory t;
+        t.vx = vx, t.vy = vy, t.lh = lh, t.flux = flux;
+        t.x = x, t.y = y, t.obs_count = obs_count;
+        return t;
     }
 };
 static_assert(sizeof(Trajectory) == sizeof(kb_trajectory) && sizeof(Trajectory) == 28, "Trajectory must be 28 bytes");

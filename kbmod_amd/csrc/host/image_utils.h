@@ -7,6 +7,9 @@
 #ifndef KBH_IMAGE_UTILS_H_
 #define KBH_IMAGE_UTILS_H_
 
+#include <algorithm>
+#include <cstdio>
+
 #include "common.h"
 
 namespace search {
@@ -17,67 +20,78 @@ inline void print_cuda_stats() { kb_print_stats(); }
 inline size_t get_gpu_total_memory() { return kb_gpu_total_memory(); }
 inline size_t get_gpu_free_memory() { return kb_gpu_free_memory(); }
 inline std::string stat_gpu_memory_mb() {
-    double total_mb = (double)get_gpu_total_memory() / 1048576.0;
-    double free_mb = (double)get_gpu_free_memory() / 1048576.0;
-    return ("GPU: " + std::to_string(free_mb) + " MB free of " + std::to_string(total_mb) + " MB total.");
+    // same text as kernel_helpers.cpp:62-66 ("%f" is what std::to_string prints for a double)
+    char line[160];
+    std::snprintf(line, sizeof(line), "GPU: %f MB free of %f MB total.", (double)kb_gpu_free_memory() / 1048576.0,
+                  (double)kb_gpu_total_memory() / 1048576.0);
+    return std::string(line);
 }
 inline bool validate_gpu(size_t req_memory = 0) { return kb_check_gpu(req_memory) != 0; }
 
-// kernel_helpers.cpp:86-106 (runs the host instantiation; no device needed)
+// Test hook of the in-search sigma-G index computation (kernel_helpers.cpp:86-106): the original positions of the
+// values that survive the clip, in ascending value order.  Runs the host instantiation of the shared evaluator
+// (csrc/search_math.h) through the C ABI; no device needed.
 inline std::vector<int> sigmaGFilteredIndices(std::vector<float> values, float sgl0, float sgl1,
                                               float sigma_g_coeff, float width) {
-    int num_values = values.size();
-    std::vector<int> idx_array(num_values, 0);
-    int min_keep_idx = 0;
-    int max_keep_idx = num_values - 1;
-    kb_sigmag_filtered_indices(values.data(), num_values, sgl0, sgl1, sigma_g_coeff, width, idx_array.data(),
-                               &min_keep_idx, &max_keep_idx);
-    std::vector<int> result;
-    for (int i = min_keep_idx; i <= max_keep_idx; ++i) result.push_back(idx_array[i]);
-    return result;
+    const int n = (int)values.size();
+    std::vector<int> order(n, 0);
+    int first = 0, last = n - 1;
+    kb_sigmag_filtered_indices(values.data(), n, sgl0, sgl1, sigma_g_coeff, width, order.data(), &first, &last);
+    if (last < first) return {};
+    return std::vector<int>(order.begin() + first, order.begin() + last + 1);
 }
 
-// ---- image_utils_cpp.cpp:20-68 -------------------------------------------------
-inline Image convolve_image_cpu(const Image& img, const Image& psf) {
-    const int64_t img_height = img.rows;
-    const int64_t img_width = img.cols;
-    Image result(img_height, img_width);
-    const int psf_num_rows = (int)psf.rows;
-    const int psf_num_cols = (int)psf.cols;
-    const int psf_rad = (int)((psf_num_rows - 1) / 2);
+// ---- masked, renormalised correlation on flat row-major buffers ------------------------------------------
+// Semantics of image_utils_cpp.cpp:20-68: a non-finite centre passes through; otherwise the taps that fall
+// inside the image on finite pixels are summed row by row, left to right (no kernel flip), products and weights
+// in separate fp32 accumulators, and the result is (sum * kernel_total) / weight_seen -- NO_DATA when no tap
+// counted.  The loops below walk only the part of the kernel that overlaps the image (clipped tap ranges per
+// output row / column), which visits the surviving taps in the same order as a per-tap bounds test would, so
+// every rounding happens in the same place.  One routine serves the module's convolve_image_cpu and the host
+// builders of psi / phi.
+inline float kernel_total(const float* k, int64_t kh, int64_t kw) {
+    float total = 0.0f;
+    for (int64_t p = 0; p < kh * kw; ++p) total += k[p];  // row-major order
+    return total;
+}
 
-    float psf_total = 0.0f;
-    for (int r = 0; r < psf_num_rows; ++r)
-        for (int c = 0; c < psf_num_cols; ++c) psf_total += psf(r, c);
-
+inline void masked_correlate(const float* src, int64_t height, int64_t width, const float* k, int64_t kh, int64_t kw,
+                             float* dst) {
+    const int64_t reach = (kh - 1) / 2;  // the reference takes the radius from the row count for both axes
+    const float total = kernel_total(k, kh, kw);
 #pragma omp parallel for schedule(static)
-    for (int64_t y = 0; y < img_height; ++y) {
-        for (int64_t x = 0; x < img_width; ++x) {
-            if (!pixel_value_valid(img(y, x))) {
-                result(y, x) = img(y, x);
+    for (int64_t y = 0; y < height; ++y) {
+        const int64_t j_lo = std::max<int64_t>(-reach, -y), j_hi = std::min<int64_t>(reach, height - 1 - y);
+        const float* centre_row = src + y * width;
+        float* out_row = dst + y * width;
+        for (int64_t x = 0; x < width; ++x) {
+            const float centre = centre_row[x];
+            if (!std::isfinite(centre)) {
+                out_row[x] = centre;
                 continue;
             }
-            float sum = 0.0f;
-            float psf_portion = 0.0f;
-            for (int j = -psf_rad; j <= psf_rad; j++) {
-                for (int i = -psf_rad; i <= psf_rad; i++) {
-                    if ((x + i >= 0) && (x + i < img_width) && (y + j >= 0) && (y + j < img_height)) {
-                        float current_pixel = img(y + j, x + i);
-                        if (pixel_value_valid(current_pixel)) {
-                            float current_psf = psf(j + psf_rad, i + psf_rad);
-                            psf_portion += current_psf;
-                            sum += current_pixel * current_psf;
-                        }
+            const int64_t i_lo = std::max<int64_t>(-reach, -x), i_hi = std::min<int64_t>(reach, width - 1 - x);
+            float acc = 0.0f, seen = 0.0f;
+            for (int64_t j = j_lo; j <= j_hi; ++j) {
+                const float* px = centre_row + j * width + x;
+                const float* kr = k + (j + reach) * kw + reach;
+                for (int64_t i = i_lo; i <= i_hi; ++i) {
+                    const float v = px[i];
+                    if (std::isfinite(v)) {
+                        const float w = kr[i];
+                        seen += w;
+                        acc += v * w;
                     }
                 }
             }
-            if (psf_portion == 0) {
-                result(y, x) = NO_DATA;
-            } else {
-                result(y, x) = (sum * psf_total) / psf_portion;
-            }
+            out_row[x] = (seen == 0.0f) ? NO_DATA : (acc * total) / seen;
         }
     }
+}
+
+inline Image convolve_image_cpu(const Image& img, const Image& psf) {
+    Image result(img.rows, img.cols);
+    masked_correlate(img.data.data(), img.rows, img.cols, psf.data.data(), psf.rows, psf.cols, result.data.data());
     return result;
 }
 
@@ -114,33 +128,22 @@ inline void check_same_dims(const Image& sci, const Image& var) {
     }
 }
 
-// image_utils_cpp.cpp:142-149 (pixel preparation only)
+// Pixel preparation of image_utils_cpp.cpp:142-149 / :165-172: psi0 = sci / var (fp32 divide), phi0 = 1 / var
+// (a double divide rounded to float on store); NO_DATA where the variance is non-finite or zero, psi0 also where
+// the science pixel is non-finite.  A negative variance is not masked.
+inline bool variance_usable(float v) { return std::isfinite(v) && v != 0.0f; }
 inline Image prepare_psi(const Image& sci, const Image& var) {
-    Image result(sci.rows, sci.cols);
-    const size_t n = result.data.size();
-    for (size_t p = 0; p < n; ++p) {
-        float var_pix = var.data[p];
-        if (std::isfinite(var_pix) && var_pix != 0.0 && std::isfinite(sci.data[p])) {
-            result.data[p] = sci.data[p] / var_pix;
-        } else {
-            result.data[p] = NO_DATA;
-        }
-    }
-    return result;
+    Image out(sci.rows, sci.cols);
+    std::transform(sci.data.begin(), sci.data.end(), var.data.begin(), out.data.begin(), [](float s, float v) {
+        return (variance_usable(v) && std::isfinite(s)) ? s / v : NO_DATA;
+    });
+    return out;
 }
-// image_utils_cpp.cpp:165-172
 inline Image prepare_phi(const Image& var) {
-    Image result(var.rows, var.cols);
-    const size_t n = result.data.size();
-    for (size_t p = 0; p < n; ++p) {
-        float var_pix = var.data[p];
-        if (std::isfinite(var_pix) && var_pix != 0.0) {
-            result.data[p] = 1.0 / var_pix;  // double divide, stored to float
-        } else {
-            result.data[p] = NO_DATA;
-        }
-    }
-    return result;
+    Image out(var.rows, var.cols);
+    std::transform(var.data.begin(), var.data.end(), out.data.begin(),
+                   [](float v) { return variance_usable(v) ? (float)(1.0 / (double)v) : NO_DATA; });
+    return out;
 }
 
 inline Image generate_psi_cpu(const Image& sci, const Image& var, const Image& psf) {

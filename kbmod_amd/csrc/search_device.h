@@ -137,20 +137,55 @@ __device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chu
     ls.stored = 1;
 }
 
+// Screen of a finished candidate against the likelihood its list's last slot holds: true when the candidate
+// CANNOT enter, decided on an approximate likelihood (psi * rsq(phi): three instructions instead of the thirty of
+// the correctly rounded sqrt and divide).  The threshold is lowered by a relative 2^-18 and one smallest normal,
+// which no rounding of either computation bridges (v_rsq_f32 and the product are good to 2^-21 relative; the exact
+// value to 2^-22), so a candidate that fails the screen also fails `lh > threshold` with the exact likelihood;
+// everything else -- passes, NaN, a phi sum too small for v_rsq_f32 -- is left to the exact test.
+__device__ __forceinline__ float screen_floor(float threshold) {
+    return threshold - fabsf(threshold) * 3.814697265625e-06f - 1.17549435e-38f;  // -FLT_MAX -> -inf, NaN stays NaN
+}
+__device__ __forceinline__ bool screened_out(float psi_sum, float phi_sum, float floor_lh) {
+    const float approx = (phi_sum > 0.0f) ? psi_sum * __builtin_amdgcn_rsqf(phi_sum) : -1.0f;
+    const bool usable = !(phi_sum > 0.0f) || phi_sum >= 1.17549435e-38f;  // (a denormal sum is no argument for v_rsq_f32)
+    return usable && approx < floor_lh;
+}
+
 // finish_chunk / epilogue for packed records in registers (kb_search_lds, lists of up to 8, long candidate lists).
+// Two steps.  (1) Screen all C candidates (above): per lane a bit mask of those that may enter its list.  (2) While
+// any lane has a bit left, EVERY lane takes its own lowest candidate -- selected out of the C register sets --,
+// computes the exact likelihood and runs the reference's swap-down insertion (kernels.cu:318-330).  Each lane
+// still sees its candidates in list order, but the wave walks max-over-lanes(#passing) rounds per chunk (one or
+// two once the lists have filled) instead of one insertion round per candidate that passes in ANY lane (most of
+// the C): the insertion and the exact likelihoods were 0.68 of cfg2's 4.62 ms.
 template <int KS, int C>
 __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int chunk, const float (&ps)[C], const float (&ph)[C],
                                                     const int (&cnt)[C], TopKPacked<KS>& top) {
+    const float floor_lh = screen_floor(top.lh[KS - 1]);
+    uint32_t pending = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const int cand = chunk * C + c;
-        if (cand >= a.n_cands) break;  // uniform
-        float p = ps[c], f = ph[c];
-        asm volatile("" : "+v"(p), "+v"(f), "+v"(top.lh[KS - 1]));  // one candidate after the other (see finish_chunk)
-        const float lh = lh_from_sums(p, f);
-        if (!(cnt[c] < a.min_obs) && lh > top.lh[KS - 1]) {
-            top.insert(lh, flux_from_sums(p, f), (uint32_t)cand | ((uint32_t)cnt[c] << 16));
+        const bool real = (chunk * C + c) < a.n_cands;  // uniform
+        const bool out = !real || cnt[c] < a.min_obs || screened_out(ps[c], ph[c], floor_lh);
+        pending |= out ? 0u : (1u << c);
+    }
+    while (__ballot(pending != 0u) != 0ull) {  // uniform
+        const int c_sel = (int)__builtin_ctz(pending | 0x100u);  // (8: a lane with nothing left selects nothing)
+        float p = ps[0], f = ph[0];
+        int n = cnt[0];
+#pragma unroll
+        for (int c = 1; c < C; ++c) {
+            const bool pick = c_sel == c;
+            p = pick ? ps[c] : p;
+            f = pick ? ph[c] : f;
+            n = pick ? cnt[c] : n;
         }
+        const float lh = lh_from_sums(p, f);
+        if (pending != 0u && lh > top.lh[KS - 1]) {
+            top.insert(lh, flux_from_sums(p, f), (uint32_t)(chunk * C + c_sel) | ((uint32_t)n << 16));
+        }
+        pending &= pending - 1u;
     }
 }
 template <int KS>

@@ -12,6 +12,19 @@
 
 namespace kb {
 
+#ifdef KB_EXP_PROFILE
+// timing experiment: shader-clock ticks per phase, summed over waves (read by kb_exp_read_profile)
+__device__ unsigned long long kb_exp_prof[8];
+#define KB_PROF_MARK(slot)                                   \
+    {                                                        \
+        const uint64_t now_ = __builtin_amdgcn_s_memtime();  \
+        prof_acc[slot] += now_ - prof_t;                     \
+        prof_t = now_;                                       \
+    }
+#else
+#define KB_PROF_MARK(slot)
+#endif
+
 // Staging map.  A slab (rows x cols raw pairs, dense; cols = the chunk's pitch) is copied in workgroup-wide
 // rounds of 16 * ROWS * 64 bytes: in round j thread tid moves the 16 bytes at slab offset
 // o = 16 * (tid + ROWS * 64 * j), i.e. pixel p = o / BYTES = (row, col) = divmod(p, cols) of the slab, from the
@@ -219,6 +232,10 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
     for (int c = 0; c < C / 2; ++c) cntp[c] = 0u;
 
+#ifdef KB_EXP_PROFILE
+    uint64_t prof_acc[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t prof_t = __builtin_amdgcn_s_memtime();
+#endif
     int chunk = a.chunk_lo, t0 = 0, buf = 0;
     ChunkPlan plan = chunk_plan<BYTES, ROWS>(a, chunk);
     SlabRegs regs;
@@ -240,6 +257,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
         }
     }
     __syncthreads();
+    KB_PROF_MARK(0)
 
     while (chunk < a.chunk_hi) {
         // next group in flight during this group's arithmetic
@@ -333,6 +351,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
             for (int c = 0; c < C / 2; ++c) asm volatile("" : "+v"(cntp[c])::"memory");
         };
+        KB_PROF_MARK(1)
         if (plan.clean) {
             // A block alone on its CU is bound by the chain scalar table fetch -> LDS read -> adds -> slab
             // landed -> LDS write of one epoch (measured 4.9 ms with one block per CU against 7.4 ms with
@@ -356,6 +375,9 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 const char* rptr = cb + e * plan.stride;  // this lane's pixel in the slab being summed
                 int64_t org_nxt = origin_of(n_org[1]);  // origin of the slab whose loads are issued next
                 auto load = [&](Piece (&v)[LDS_SLOTS], int64_t org) {
+#ifdef KB_EXP_NO_STAGE
+                    return;
+#endif
                     const char* base = tile_base + org;
 #pragma unroll
                     for (int j = 0; j < NP; ++j) {
@@ -373,8 +395,13 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     // load is a wait for every LDS operation of the wave; placed behind the write, as it was, it
                     // holds the next epoch's reads until that write has completed.
                     sum_epoch(o_cur, rptr, [&]() {
+#if defined(KB_EXP_TABLE_HIT)  // timing experiment: every epoch re-reads one table entry (no scalar-cache misses, one slab)
+                        ConstIntPtr po = offs;
+                        ConstSlabPtr pg = n_org;
+#else
                         ConstIntPtr po = offs + (e + 1) * C;
                         ConstSlabPtr pg = n_org + (e + STAGE_DEPTH);
+#endif
 #pragma unroll
                         for (int c = 0; c < C; ++c) o_cur[c] = po[c];
                         org_nxt = origin_of(pg[0]);
@@ -386,8 +413,10 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #pragma unroll
                         for (int c = 0; c < C / 2; ++c) asm volatile("" : "+v"(cntp[c]));
                     }
+#ifndef KB_EXP_NO_STAGE
 #pragma unroll
                     for (int j = 0; j < NP; ++j) *reinterpret_cast<Piece*>(wdst + stage_round(ROWS) * j) = v[j];
+#endif
                     wdst += n_plan.stride;
                     rptr += plan.stride;
                     ++e;
@@ -421,7 +450,13 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     }
                 }
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-                org_cur = origin_of(n_org[e]);       // (for the loop below)
+                // origin of slab e (for the loop below, and for the next group when this one ends here): one deep, the
+                // last step's prefetch already holds it
+                if constexpr (STAGE_DEPTH == 1) {
+                    org_cur = org_nxt;
+                } else {
+                    org_cur = origin_of(n_org[e]);
+                }
             };
             if (n_both > 0) {
                 const int wave_piece = 1024 * tc.wv;
@@ -433,6 +468,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     staged_run(std::integral_constant<int, 0>{});
                 }
             }
+            KB_PROF_MARK(2)
             // what is left: sums of a group longer than the next one, slabs of more rounds
             for (; e < n_cur; ++e) {
                 const bool staging = e < n_next;
@@ -472,7 +508,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             if (next_load(e)) next_write(e);
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         }
-
+        KB_PROF_MARK(3)
         if (n_chunk != chunk) {  // chunk complete: likelihoods + top-K, while the next chunk's first group lands
             if (tc.row_active) {
                 float ps[C], ph[C];
@@ -483,6 +519,14 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     ph[c] = acc[c].y;
                     cnt[c] = FAST ? T : (int)((cntp[c >> 1] >> (16 * (c & 1))) & 0xffffu);
                 }
+#ifdef KB_EXP_NO_FINISH
+                if constexpr (TileLists<KS, LM>::PACKED) {
+                    float sink = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) sink += ps[c] + ph[c] + (float)cnt[c];
+                    lists.packed.lh[0] = fmaxf(lists.packed.lh[0], sink);
+                } else
+#endif
                 if constexpr (SIGMAG) {
                     TopK<KS> none;  // (the emitting instances keep no list)
                     finish_chunk<KS, C, true>(a, tc, chunk, ps, ph, cnt, none);
@@ -502,12 +546,22 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 cntp[c >> 1] = 0u;
             }
         }
+        KB_PROF_MARK(4)
+#ifndef KB_EXP_NO_BARRIER
         __syncthreads();
+#endif
+        KB_PROF_MARK(5)
         buf = 1 - buf;
         chunk = n_chunk;
         t0 = n_t0;
         plan = n_plan;
     }
+#ifdef KB_EXP_PROFILE
+    if (tc.lane == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&kb_exp_prof[i], (unsigned long long)prof_acc[i]);
+        atomicAdd(&kb_exp_prof[6], 1ull);
+    }
+#endif
 }
 
 

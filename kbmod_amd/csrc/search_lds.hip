@@ -44,3 +44,11 @@ void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, int lis
 }
 
 }  // namespace kb
+
+#ifdef KB_EXP_PROFILE
+extern "C" int kb_exp_read_profile(unsigned long long* out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(kb::kb_exp_prof), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(kb::kb_exp_prof), zero, sizeof(zero)) != hipSuccess;
+}
+#endif
