@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--reuse-padded-copy", action="store_true",
                     help="from the second step on tell the library that the array is unchanged (flag 256), as a StackSearch "
                          "with a resident array does: the decode-and-pad pass is then skipped (not the default: a step is a whole search)")
+    ap.add_argument("--plain-ties", action="store_true",
+                    help="multi-GPU: exchange K records per pixel and break ties by candidate index (the default exchanges "
+                         "2 K records built by stable insertion and reproduces the single-GPU result exactly, ties included)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the CPU baseline sample")
     args = ap.parse_args()
@@ -148,11 +151,20 @@ def main():
         raise RuntimeError("bench.py needs a GPU: the search has no CPU fallback")
     if world != args.gpus:
         raise RuntimeError(f"WORLD_SIZE={world} but --gpus {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # KBMOD_DIST_BACKEND=gloo (default nccl = RCCL): the N > 1 path end to end where there are fewer GPUs than ranks --
+    # ranks share the devices round-robin and the gather goes through host memory (tests/test_gpu_multi.py runs two
+    # ranks on one GPU this way; RCCL itself refuses two ranks on one device).  Not a measurement configuration.
+    backend = os.environ.get("KBMOD_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     lib = load_lib()
     T, H, W = args.frames, args.size, args.size
@@ -193,9 +205,15 @@ def main():
     else:
         params = Params(0, 0.0 if args.min_lh is None else args.min_lh, 0, 0.25, 0.75, -1.0, nb_param, ins, W - ins, ins,
                         H - ins, K, 0)
+    # multi-GPU: tie-exact exchange -- every rank keeps 2 K records per pixel by stable insertion (flag 512), the merge
+    # on rank 0 replays the reference's insertion (kbmod_amd/distributed.py); K > 16 or --plain-ties: K records, ties by index
+    exact_ties = world > 1 and not args.plain_ties and K <= 16
+    list_len = 2 * K if exact_ties else K
     if world > 1:
-        records = torch.empty((S * K, 4), dtype=torch.int32, device=dev)  # kb_compact_result per slot
-        gathered = torch.empty((world, S * K, 4), dtype=torch.int32, device=dev) if rank == 0 else None
+        rank_params = Params.from_buffer_copy(params)
+        rank_params.results_per_pixel = list_len
+        records = torch.empty((S * list_len, 4), dtype=torch.int32, device=dev)  # kb_compact_result per slot
+        gathered = torch.empty((world, S * list_len, 4), dtype=torch.int32, device=dev) if rank == 0 else None
         results = torch.empty((S * K, 7), dtype=torch.float32, device=dev) if rank == 0 else None
     else:
         results = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
@@ -212,11 +230,11 @@ def main():
         flags = args.flags | (256 if (searched[0] and args.reuse_padded_copy) else 0)
         searched[0] = True
         if world > 1:
-            check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), n_local,
-                                                    rank * n_local, records.data_ptr(), S * K, flags, stream,
-                                                    C.byref(st)))
+            check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), rank_params, cands.data_ptr(),
+                                                    n_local, rank * n_local, records.data_ptr(), S * list_len,
+                                                    flags | (512 if exact_ties else 0), stream, C.byref(st)))
             kdist.gather_and_merge_compact(records, (ins, W - ins), (ins, H - ins), K, all_cands, gathered=gathered,
-                                           out=results)
+                                           out=results, list_len=list_len)
         else:
             check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), n_local,
                                                    results.data_ptr(), S * K, flags, stream, C.byref(st)))
@@ -240,7 +258,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -306,8 +324,9 @@ def main():
                         f"sigma-G {'on, min_obs %d' % (T // 2) if args.sigmag else 'off'}"
                         + (f", {args.mask_fraction:g} of the science pixels masked" if args.mask_fraction > 0 else ""),
             "frames": T, "height": H, "width": W, "candidates_per_gpu": n_local, "results_per_pixel": K,
-            "sharding": "candidates (v,theta) by rank; psi/phi replicated; one RCCL gather of 16-byte records to rank 0 "
-                        "+ per-pixel merge" if world > 1 else "none",
+            "sharding": ("candidates (v,theta) by rank; psi/phi replicated; one RCCL gather of 16-byte records to rank 0 "
+                         f"({list_len} per pixel) + per-pixel merge, " + ("tie-exact" if exact_ties else "ties by candidate index"))
+                        if world > 1 else "none",
             "psi_phi_build_ms": build_ms,
         },
         "roofline": {
@@ -342,6 +361,17 @@ def main():
 
     if args.verify and world == 1:
         out["verify"] = verify(lib, torch, meta, arr, times, params, cands, n_local, results, S, K, ins, W, H, last, stream)
+    if args.verify and world > 1 and rank == 0:
+        # the merged lists of the job against ONE search over the job-wide candidate list on this rank's device
+        single = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
+        st1 = Stats()
+        check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, all_cands.data_ptr(),
+                                               n_local * world, single.data_ptr(), S * K, args.flags, stream, C.byref(st1)))
+        torch.cuda.synchronize()
+        same = torch.equal(results.view(torch.int32), single.view(torch.int32))
+        lh_same = torch.equal(results[:, 2].contiguous().view(torch.int32), single[:, 2].contiguous().view(torch.int32))
+        out["verify"] = {"merged_equals_single_device_ok": bool(same) if exact_ties else bool(lh_same),
+                         "merged_likelihoods_equal_ok": bool(lh_same), "tie_exact": bool(exact_ties), "backend": backend}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lib, meta, arr, tcpu, vx[sl], vy[sl], args.cpu_seconds)
@@ -354,7 +384,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     lib.kb_free_gpu_block(arr)
-    if args.verify and world == 1 and not all(v for k, v in out["verify"].items() if k.endswith("_ok")):
+    if args.verify and rank == 0 and not all(v for k, v in out["verify"].items() if k.endswith("_ok")):
         sys.exit(3)
     if world > 1:
         dist.destroy_process_group()

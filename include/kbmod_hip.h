@@ -165,6 +165,9 @@ int kb_generate_psi_phi_host(const float* sci_host, const float* var_host, int w
  * 256  the caller vouches that the array at psi_phi_dev has not changed since its previous search on this
  *      device: the padded copy of that search is reused when array, meta data and frame geometry are the same
  *      (a StackSearch owns its array and sets this from its second search on; cfg4: 7 ms of 60 per search).
+ * 512  (changes the result under ties) per-pixel lists by stable insertion -- the top K by (likelihood descending,
+ *      candidate ascending) instead of the reference's swap-down order: the per-device half of the tie-exact
+ *      multi-GPU exchange (kb_merge_compact_exact), not a search result of its own.
  * The library keeps its workspaces (shift tables, sigma-G scratch, padded copy) between
  * calls; kb_release_workspaces() returns them. */
 int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
@@ -249,9 +252,22 @@ int kb_merge_topk(const kb_trajectory* lists_dev, int32_t n_lists, uint64_t n_pi
 /* Same merge on the compact records of kb_device_search_compact, gathered to one GPU as
  * lists_dev = [n_lists][n_pixels][K]; writes full trajectories (x, y from the slot and the start bounds of
  * params, vx / vy from all_cands_dev, the job-wide candidate list the records index).  The output equals
- * what one GPU produces on the whole candidate list, ties included (lower list = lower candidate index). */
+ * where a pixel's K + 1 best likelihoods are distinct the output equals what one GPU produces on the whole
+ * candidate list; among EQUAL likelihoods it keeps the lower list = lower candidate index, whereas the
+ * reference's swap-down insertion (kernels.cu:323-330) may keep another member of the tie
+ * (kb_merge_compact_exact reproduces that too). */
 int kb_merge_compact(const kb_compact_result* lists_dev, int32_t n_lists, kb_search_params params,
                      const kb_trajectory* all_cands_dev, uint64_t n_all_cands, kb_trajectory* out_dev, void* stream);
+/* Tie-exact merge (new): the output equals what ONE device produces on the whole candidate list, ties included.
+ * Every device searches its candidates with flag 512 (per-pixel lists by STABLE insertion: the top list_len by
+ * likelihood descending, candidate ascending) and list_len = 2 * params.results_per_pixel slots per pixel
+ * (params.results_per_pixel of ITS search = list_len); lists_dev = [n_lists][n_pixels][list_len] gathered on one
+ * device, params.results_per_pixel here = the K of the job.  The lists merge exactly under that total order, and the
+ * reference's insertion is then replayed per pixel over the only candidates its order-dependence can reach (all above
+ * the K-th likelihood + the first K equal to it).  list_len <= 32, i.e. K <= 16; any candidate partition works
+ * (contiguous slices or interleaved). */
+int kb_merge_compact_exact(const kb_compact_result* lists_dev, int32_t n_lists, int32_t list_len, kb_search_params params,
+                           const kb_trajectory* all_cands_dev, uint64_t n_all_cands, kb_trajectory* out_dev, void* stream);
 
 /* ---- host instantiations of the device functions ------------------------- */
 /* kernels.cu:154-242 evaluateTrajectory called with host pointers

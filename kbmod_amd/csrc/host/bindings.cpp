@@ -325,6 +325,24 @@ PYBIND11_MODULE(search, m) {
               return res;
           });
 
+    m.def("merge_compact_exact_host",
+          [](py::array_t<uint8_t, py::array::c_style> raw, int n_lists, int list_len, int K, int x_min, int x_max, int y_min,
+             int y_max, const std::vector<Trajectory>& all_cands) {
+              if (x_max <= x_min || y_max <= y_min) throw std::runtime_error("merge_compact_exact_host: invalid search bounds");
+              const uint64_t n_pixels = (uint64_t)(x_max - x_min) * (uint64_t)(y_max - y_min);
+              if ((uint64_t)raw.size() != (uint64_t)n_lists * n_pixels * list_len * sizeof(kb_compact_result)) {
+                  throw std::runtime_error("merge_compact_exact_host: buffer size does not match n_lists * n_pixels * list_len * 16");
+              }
+              std::vector<Trajectory> out = merge_compact_exact_host(
+                      reinterpret_cast<const kb_compact_result*>(raw.data()), n_lists, n_pixels, list_len, K, x_max - x_min,
+                      x_min, y_min, all_cands.data(), all_cands.size());
+              py::array_t<uint8_t> res((py::ssize_t)(out.size() * sizeof(Trajectory)));
+              if (!out.empty()) std::memcpy(res.mutable_data(), out.data(), out.size() * sizeof(Trajectory));
+              return res;
+          },
+          "Host twin of kb_merge_compact_exact: per-device lists of `list_len` 16-byte records per pixel, built by stable\n"
+          "insertion, merged into the K results per pixel a single device would produce (ties included).");
+
     // ---- near-duplicate grid filter on the device (filters/clustering_grid.py:152-175) ----
     m.def(
             "grid_filter_indices",

@@ -56,6 +56,11 @@ struct DeviceBlock {
     T* as() const {
         return reinterpret_cast<T*>(ptr);
     }
+    void* release() {  // the caller takes the block over
+        void* p = ptr;
+        ptr = nullptr;
+        return p;
+    }
 };
 
 }  // namespace detail
@@ -329,7 +334,14 @@ public:
             // The result slots are written by the kernels themselves; nothing is uploaded (the reference
             // uploads S*K*28 bytes of zeros here).
             detail::DeviceBlock raw(max_results * sizeof(Trajectory)), kept(max_results * sizeof(Trajectory));
-            const bool fan_out = search_devices.size() > 1 && params.results_per_pixel <= 32 && !search_list.empty();
+            bool fan_out = search_devices.size() > 1 && !search_list.empty();
+            if (fan_out && params.results_per_pixel > 32) {
+                // (the 16-byte exchange records and the merge kernels cover lists of up to 32 per pixel)
+                rs_logger->warning("results_per_pixel = " + std::to_string(params.results_per_pixel) +
+                                   " > 32: the search runs on one device instead of the " +
+                                   std::to_string(search_devices.size()) + " set by set_search_devices.");
+                fan_out = false;
+            }
             if (fan_out) {
                 search_on_devices(candidate_list, raw.as<kb_trajectory>(), max_results);
             } else {
@@ -464,30 +476,46 @@ protected:
         for (const Replica& r : replicas) {
             if (r.device == device) return r;
         }
-        Replica r;
-        r.device = device;
         const uint64_t bytes = psi_phi_array.get_total_array_size(), tbytes = (uint64_t)num_imgs * sizeof(double);
         check_status(kb_set_device(device));
-        check_status(kb_allocate_gpu_block(bytes, &r.array));
-        check_status(kb_allocate_gpu_block(tbytes, &r.times));
-        check_status(kb_copy_block_between_gpus(r.array, device, psi_phi_array.get_gpu_array_ptr(), home, bytes));
-        check_status(kb_copy_block_between_gpus(r.times, device, psi_phi_array.get_gpu_time_array_ptr(), home, tbytes));
+        // (DeviceBlock frees what was allocated if a later step throws; the replica takes the blocks over at the end)
+        detail::DeviceBlock array(bytes), times(tbytes);
+        check_status(kb_copy_block_between_gpus(array.ptr, device, psi_phi_array.get_gpu_array_ptr(), home, bytes));
+        check_status(kb_copy_block_between_gpus(times.ptr, device, psi_phi_array.get_gpu_time_array_ptr(), home, tbytes));
+        Replica r;
+        r.device = device;
+        r.array = array.release();
+        r.times = times.release();
         replicas.push_back(r);
         return replicas.back();
     }
 
     // contiguous candidate slices, one host thread per slice on its device, 16-byte records
     // copied to the home device, per-pixel merge there.  `merged` (home device) receives the per-pixel lists.
+    // Lists of up to 16 results take the tie-exact exchange: every device keeps 2 K records per pixel by stable
+    // insertion (flag 512) and kb_merge_compact_exact replays the reference's insertion -- the result equals the
+    // single-device search, ties included.  Longer lists (17 .. 32) take the plain merge (ties to the lower
+    // candidate index: same likelihoods per slot, possibly another member of a tie), which is logged.
     void search_on_devices(TrajectoryList& candidates, kb_trajectory* merged, uint64_t max_results) {
         const int home = kb_get_device();
         const int n_parts = (int)search_devices.size();
         const std::vector<Trajectory>& cands = candidates.get_list();
         const uint64_t n = cands.size();
+        const bool exact = params.results_per_pixel <= 16;
+        if (!exact) {
+            rs_logger->warning("results_per_pixel = " + std::to_string(params.results_per_pixel) +
+                               " > 16: the multi-device merge breaks ties by candidate index (a tie may keep another "
+                               "member than a single-device search).");
+        }
+        SearchParameters part_params = params;
+        if (exact) part_params.results_per_pixel = 2 * params.results_per_pixel;
+        const uint64_t part_results = max_results / params.results_per_pixel * part_params.results_per_pixel;
+        const uint32_t part_flags = search_flags | (exact ? 512u : 0u);
         for (int d : search_devices) {  // replicas are made here, one after the other, before the threads start
             if (d != home) (void)replica_on(d, home);
         }
         check_status(kb_set_device(home));
-        detail::DeviceBlock gathered((uint64_t)n_parts * max_results * sizeof(kb_compact_result));
+        detail::DeviceBlock gathered((uint64_t)n_parts * part_results * sizeof(kb_compact_result));
         detail::DeviceBlock all_cands(n * sizeof(Trajectory));
         check_status(kb_copy_block_to_gpu(cands.data(), all_cands.ptr, n * sizeof(Trajectory)));
 
@@ -508,14 +536,17 @@ protected:
                         }
                     }
                 }
-                detail::DeviceBlock slice((hi - lo) * sizeof(Trajectory)), records(max_results * sizeof(kb_compact_result));
+                detail::DeviceBlock slice((hi - lo) * sizeof(Trajectory)), records(part_results * sizeof(kb_compact_result));
                 if (hi > lo) check_status(kb_copy_block_to_gpu(cands.data() + lo, slice.ptr, (hi - lo) * sizeof(Trajectory)));
-                check_status(kb_device_search_compact(&psi_phi_array.get_meta_data(), array, times, params,
+                check_status(kb_device_search_compact(&psi_phi_array.get_meta_data(), array, times, part_params,
                                                       slice.as<const kb_trajectory>(), hi - lo, (int32_t)lo,
-                                                      records.as<kb_compact_result>(), max_results, search_flags, nullptr,
+                                                      records.as<kb_compact_result>(), part_results, part_flags, nullptr,
                                                       &part_stats[part]));
-                check_status(kb_copy_block_between_gpus(gathered.as<kb_compact_result>() + (uint64_t)part * max_results, home,
-                                                        records.ptr, device, max_results * sizeof(kb_compact_result)));
+                // (the stats path returns without a final stream synchronisation: a fault inside the kernels must
+                // surface here, on the device it happened on, not in a later call)
+                check_status(kb_device_synchronize());
+                check_status(kb_copy_block_between_gpus(gathered.as<kb_compact_result>() + (uint64_t)part * part_results, home,
+                                                        records.ptr, device, part_results * sizeof(kb_compact_result)));
             } catch (const std::exception& e) {
                 errors[part] = e.what();
             }
@@ -526,8 +557,14 @@ protected:
         for (std::thread& w : workers) w.join();
         check_status(kb_set_device(home));
         for (const std::string& e : errors) detail::require(e.empty(), e);
-        check_status(kb_merge_compact(gathered.as<const kb_compact_result>(), n_parts, params,
-                                      all_cands.as<const kb_trajectory>(), n, merged, nullptr));
+        if (exact) {
+            check_status(kb_merge_compact_exact(gathered.as<const kb_compact_result>(), n_parts,
+                                                (int32_t)part_params.results_per_pixel, params,
+                                                all_cands.as<const kb_trajectory>(), n, merged, nullptr));
+        } else {
+            check_status(kb_merge_compact(gathered.as<const kb_compact_result>(), n_parts, params,
+                                          all_cands.as<const kb_trajectory>(), n, merged, nullptr));
+        }
         check_status(kb_device_synchronize());
         last_stats = part_stats[0];
         for (int part = 1; part < n_parts; ++part) {
@@ -536,6 +573,8 @@ protected:
             last_stats.search_kernel_ms = std::max(last_stats.search_kernel_ms, part_stats[part].search_kernel_ms);
             last_stats.num_search_launches += part_stats[part].num_search_launches;
         }
+        // replicas are whole copies of the array: they go when the home array leaves the device with this search
+        if (!psi_phi_preloaded) drop_replicas();
     }
 
     SearchParameters params;

@@ -10,6 +10,7 @@
 #endif
 
 #include "common.h"
+#include "../search_math.h"
 #include "image_utils.h"
 
 namespace search {
@@ -224,6 +225,47 @@ inline std::vector<Trajectory> merge_compact_host(const kb_compact_result* lists
                 t.lh = rec.lh;
                 t.flux = rec.flux;
                 t.obs_count = rec.obs_count;
+            }
+            out[pix * K + s] = t;
+        }
+    }
+    return out;
+}
+
+// Host twin of kb_merge_compact_exact: per-device lists of list_len records per pixel built by stable insertion
+// (flag 512) -> the K results per pixel that ONE device produces on the whole candidate list, ties included
+// (kb::merge_exact_pixel of search_math.h, the routine the device kernel runs).
+inline std::vector<Trajectory> merge_compact_exact_host(const kb_compact_result* lists, int n_lists, uint64_t n_pixels,
+                                                        int list_len, int K, int sw, int x_min, int y_min,
+                                                        const Trajectory* all_cands, uint64_t n_all_cands) {
+    if (K <= 0 || list_len < K || list_len > kb::MERGE_EXACT_MAX_K2) {
+        throw std::runtime_error("merge_compact_exact: need K <= list length <= 32");
+    }
+    std::vector<Trajectory> out(n_pixels * (uint64_t)K);
+    const uint64_t stride = n_pixels * (uint64_t)list_len;
+    std::vector<int> heads(n_lists);
+    kb::MergedEntry merged[kb::MERGE_EXACT_MAX_K2];
+    int slots[kb::MERGE_EXACT_MAX_K2];
+    for (uint64_t pix = 0; pix < n_pixels; ++pix) {
+        const kb_compact_result* mine = lists + pix * (uint64_t)list_len;
+        auto read = [&](int r, int pos) { return mine[(uint64_t)r * stride + pos]; };
+        const int n_out = kb::merge_exact_pixel(read, n_lists, list_len, K, merged, heads.data(), slots);
+        const int y_i = (int)(pix / (uint64_t)sw), x_i = (int)(pix % (uint64_t)sw);
+        for (int s = 0; s < K; ++s) {
+            Trajectory t;
+            t.x = x_i + x_min;
+            t.y = y_i + y_min;
+            t.lh = -FLT_MAX;
+            if (s < n_out && slots[s] >= 0) {
+                const uint32_t at = merged[slots[s]].at;
+                const kb_compact_result rec = read((int)(at / (uint32_t)list_len), (int)(at % (uint32_t)list_len));
+                if ((uint64_t)rec.cand < n_all_cands) {
+                    t.vx = all_cands[rec.cand].vx;
+                    t.vy = all_cands[rec.cand].vy;
+                    t.lh = rec.lh;
+                    t.flux = rec.flux;
+                    t.obs_count = rec.obs_count;
+                }
             }
             out[pix * K + s] = t;
         }

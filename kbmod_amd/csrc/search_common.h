@@ -178,6 +178,7 @@ struct SearchArgs {
     float min_lh;
     int all_staged;            // every (chunk, epoch) is staged through LDS
     int force_exact;
+    int stable_lists;          // per-pixel lists by stable insertion (flag 512: the tie-exact exchange between devices)
     float psi_scale, psi_min_val, phi_scale, phi_min_val;  // decode of encoded samples
 };
 
@@ -338,14 +339,19 @@ struct TopK {
                     make_uint2(__float_as_uint(lh[s]), (uint32_t)id[s]);
         }
     }
-    // kernels.cu:323-330: strict '>' swap-down, reproduced slot by slot.
-    __device__ __forceinline__ void insert(float cand_lh, int cand) {
+    // kernels.cu:323-330: strict '>' swap-down, reproduced slot by slot.  `stable` (uniform; the tie-exact
+    // exchange between devices, kb_merge_compact_exact): once the candidate has found its slot everything below
+    // shifts down by one whatever its value, i.e. the list is the top K by (likelihood descending, candidate
+    // ascending) -- a total order, which lists of several devices can be merged under.
+    __device__ __forceinline__ void insert(float cand_lh, int cand, bool stable = false) {
         if (cand_lh > lh[KS - 1]) {
             float cl = cand_lh;
             int cid = cand;
+            bool placed = false;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bool g = cl > lh[s];
+                const bool g = (cl > lh[s]) || (stable && placed);
+                placed = placed || g;
                 const float tl = lh[s];
                 const int ti = id[s];
                 lh[s] = g ? cl : tl;
@@ -397,14 +403,16 @@ struct TopKRecords {
                     make_uint4(__float_as_uint(lh[s]), (uint32_t)id[s], __float_as_uint(flux[s]), (uint32_t)obs[s]);
         }
     }
-    // kernels.cu:323-330: strict '>' swap-down, the whole record travels
-    __device__ __forceinline__ void insert(float cand_lh, int cand, float cand_flux, int cand_obs) {
+    // kernels.cu:323-330: strict '>' swap-down, the whole record travels (`stable`: see TopK::insert)
+    __device__ __forceinline__ void insert(float cand_lh, int cand, float cand_flux, int cand_obs, bool stable = false) {
         if (cand_lh > lh[KS - 1]) {
             float cl = cand_lh, cf = cand_flux;
             int cid = cand, co = cand_obs;
+            bool placed = false;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bool g = cl > lh[s];
+                const bool g = (cl > lh[s]) || (stable && placed);
+                placed = placed || g;
                 const float tl = lh[s], tf = flux[s];
                 const int ti = id[s], to = obs[s];
                 lh[s] = g ? cl : tl;
@@ -437,13 +445,15 @@ struct TopKPacked {
             io[s] = EMPTY;
         }
     }
-    // kernels.cu:323-330: strict '>' swap-down
-    __device__ __forceinline__ void insert(float cand_lh, float cand_flux, uint32_t cand_io) {
+    // kernels.cu:323-330: strict '>' swap-down (`stable`: see TopK::insert)
+    __device__ __forceinline__ void insert(float cand_lh, float cand_flux, uint32_t cand_io, bool stable = false) {
         float cl = cand_lh, cf = cand_flux;
         uint32_t ci = cand_io;
+        bool placed = false;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bool g = cl > lh[s];
+            const bool g = (cl > lh[s]) || (stable && placed);
+            placed = placed || g;
             const float tl = lh[s], tf = flux[s];
             const uint32_t ti = io[s];
             lh[s] = g ? cl : tl;

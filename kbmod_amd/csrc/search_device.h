@@ -82,7 +82,7 @@ __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoor
             float p = ps[c], f = ph[c];
             asm volatile("" : "+v"(p), "+v"(f), "+v"(top.lh[KS - 1]));
             const float lh = lh_from_sums(p, f);
-            if (!(cnt[c] < a.min_obs)) top.insert(lh, cand);
+            if (!(cnt[c] < a.min_obs)) top.insert(lh, cand, a.stable_lists != 0);
         }
     }
 }
@@ -119,7 +119,7 @@ __device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chu
             top.init();
         }
 #pragma unroll
-        for (int c = 0; c < C; ++c) top.insert(ps[c], chunk * C + c, ph[c], cnt[c]);
+        for (int c = 0; c < C; ++c) top.insert(ps[c], chunk * C + c, ph[c], cnt[c], a.stable_lists != 0);
         top.store(tile_list, lane_off, stride_bytes);
         ls.threshold = top.lh[KS - 1];
     } else {
@@ -130,7 +130,7 @@ __device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chu
             top.init();
         }
 #pragma unroll
-        for (int c = 0; c < C; ++c) top.insert(ps[c], chunk * C + c);
+        for (int c = 0; c < C; ++c) top.insert(ps[c], chunk * C + c, a.stable_lists != 0);
         top.store(tile_list, lane_off, stride_bytes);
         ls.threshold = top.lh[KS - 1];
     }
@@ -183,7 +183,7 @@ __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int chu
         }
         const float lh = lh_from_sums(p, f);
         if (pending != 0u && lh > top.lh[KS - 1]) {
-            top.insert(lh, flux_from_sums(p, f), (uint32_t)(chunk * C + c_sel) | ((uint32_t)n << 16));
+            top.insert(lh, flux_from_sums(p, f), (uint32_t)(chunk * C + c_sel) | ((uint32_t)n << 16), a.stable_lists != 0);
         }
         pending &= pending - 1u;
     }
@@ -222,7 +222,7 @@ __device__ __forceinline__ void finish_chunk_records(const SearchArgs& a, int ch
         float p = ps[c], f = ph[c];
         asm volatile("" : "+v"(p), "+v"(f), "+v"(top.lh[KS - 1]));  // one candidate after the other (see finish_chunk)
         const float lh = lh_from_sums(p, f);
-        if (!(cnt[c] < a.min_obs) && lh > top.lh[KS - 1]) top.insert(lh, cand, flux_from_sums(p, f), cnt[c]);
+        if (!(cnt[c] < a.min_obs) && lh > top.lh[KS - 1]) top.insert(lh, cand, flux_from_sums(p, f), cnt[c], a.stable_lists != 0);
     }
 }
 template <int KS>

@@ -93,11 +93,13 @@ __global__ __launch_bounds__(DIRECT_ROWS * WAVE) void kb_search_large_k(const Se
             if ((cur.obs_count < a.min_obs) || (a.cold->params.do_sigmag_filter && cur.lh < a.min_lh))
                 continue;  // kernels.cu:318-320
             if (!(cur.lh > slots[a.K - 1].lh)) continue;  // cannot displace anything
-            for (int s = 0; s < a.K; ++s) {  // kernels.cu:323-330
+            bool placed = false;
+            for (int s = 0; s < a.K; ++s) {  // kernels.cu:323-330 (stable lists: TopK::insert)
                 const kb_trajectory t = slots[s];
-                if (cur.lh > t.lh) {
+                if (cur.lh > t.lh || (a.stable_lists != 0 && placed)) {
                     slots[s] = cur;
                     cur = t;
+                    placed = true;
                 }
             }
         }

@@ -383,6 +383,51 @@ __global__ __launch_bounds__(256) void kb_merge_compact_kernel(const kb_compact_
     }
 }
 
+// Tie-exact merge (kb_merge_compact_exact).  The reference's insertion (kernels.cu:323-330) is not a stable
+// shift: a run of equal likelihoods rotates whenever something is inserted in front of it, and loses its first
+// member when it sits at the end of a full list, so which members of a tie a pixel keeps depends on the order of
+// ALL candidates.  What that order can influence is bounded, though.  With v = the K-th largest likelihood of the
+// pixel, the final list is the result of the reference's insertion over just
+//     G = { candidates with lh > v }  +  { the first K candidates, by index, with lh == v },
+// in candidate order: smaller values never touch the part of the list at or above v; every candidate above v
+// enters (there are fewer than K); and a candidate equal to v enters only while fewer than K candidates >= v have
+// arrived, so only the first K of them can (search_kernels.hip; brute-force check in
+// tests/test_tie_exact_merge.py).  G lies inside the first 2K - 1 entries of the per-pixel list ordered by
+// (lh descending, candidate ascending) -- a total order, under which the per-device lists (built by STABLE
+// insertion, flag 512, 2K slots each) merge exactly.  So: merge the first K2 entries of that order, then replay G.
+// Where the first K + 1 merged values are strictly decreasing nothing can rotate and the merged prefix is the answer.
+// (merge_exact_pixel: search_math.h, shared with the host twin)
+__global__ __launch_bounds__(64) void kb_merge_compact_exact_kernel(const kb_compact_result* __restrict__ lists, int n_lists,
+                                                                    uint64_t n_pixels, int K2, int K, int sw, int x_min,
+                                                                    int y_min, const kb_trajectory* __restrict__ all_cands,
+                                                                    uint64_t n_all_cands, kb_trajectory* __restrict__ out) {
+    const uint64_t pix = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (pix >= n_pixels) return;
+    const uint64_t list_stride = n_pixels * (uint64_t)K2;
+    const kb_compact_result* mine = lists + pix * (uint64_t)K2;
+    auto read = [&](int r, int pos) { return mine[(uint64_t)r * list_stride + pos]; };
+    MergedEntry merged[MERGE_EXACT_MAX_K2];
+    int heads[MERGE_MAX_LISTS];
+    int slots[MERGE_EXACT_MAX_K2];
+    const int n_out = merge_exact_pixel(read, n_lists, K2, K, merged, heads, slots);
+    const int y_i = (int)(pix / (uint64_t)sw), x_i = (int)(pix - (uint64_t)y_i * (uint64_t)sw);
+    for (int s = 0; s < K; ++s) {
+        kb_trajectory res = placeholder_result(x_i + x_min, y_i + y_min);
+        if (s < n_out && slots[s] >= 0) {
+            const uint32_t at = merged[slots[s]].at;
+            const kb_compact_result rec = read((int)(at / (uint32_t)K2), (int)(at % (uint32_t)K2));
+            if ((uint64_t)rec.cand < n_all_cands) {
+                res.vx = all_cands[rec.cand].vx;
+                res.vy = all_cands[rec.cand].vy;
+                res.lh = rec.lh;
+                res.flux = rec.flux;
+                res.obs_count = rec.obs_count;
+            }
+        }
+        out[pix * (uint64_t)K + s] = res;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -615,6 +660,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     a.n_tiles = a.tiles_x * a.tiles_y;
     a.K = (int)params.results_per_pixel;
     a.force_exact = (flags & 1u) ? 1 : 0;
+    a.stable_lists = (flags & 512u) ? 1 : 0;  // per-pixel lists as stable top-K (kb_merge_compact_exact)
     cold.fast_decode = 0;
     if (meta->num_bytes != 4 && (flags & 8u) == 0) {  // bit 3: force the double-precision decode
         cold.fast_decode = (verify_fast_decode(meta->psi_scale, meta->psi_min_val, meta->num_bytes) &&
@@ -1051,6 +1097,30 @@ int kb_merge_compact(const kb_compact_result* lists_dev, int32_t n_lists, kb_sea
         hipLaunchKernelGGL(kb_merge_compact_kernel<MERGE_MAX_LISTS>, dim3(blocks), dim3(256), 0, stream, lists_dev, n_lists,
                            n_pixels, K, (int)sw, params.x_start_min, params.y_start_min, all_cands_dev, n_all_cands, out_dev);
     }
+    KB_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int kb_merge_compact_exact(const kb_compact_result* lists_dev, int32_t n_lists, int32_t list_len, kb_search_params params,
+                           const kb_trajectory* all_cands_dev, uint64_t n_all_cands, kb_trajectory* out_dev, void* stream_v) {
+    using namespace kb;
+    if (lists_dev == nullptr || out_dev == nullptr || all_cands_dev == nullptr) return fail("merge_compact_exact: null pointer");
+    if (n_lists <= 0 || n_lists > MERGE_MAX_LISTS) return fail("merge_compact_exact: unsupported number of lists");
+    const int64_t sw = (int64_t)params.x_start_max - params.x_start_min;
+    const int64_t sh = (int64_t)params.y_start_max - params.y_start_min;
+    const int K = (int)params.results_per_pixel;
+    if (sw <= 0 || sh <= 0) return fail("merge_compact_exact: invalid search bounds");
+    if (K <= 0 || list_len < K || list_len > MERGE_EXACT_MAX_K2) {
+        return fail("merge_compact_exact: lists of " + std::to_string(list_len) + " records per pixel for " + std::to_string(K) +
+                    " results (need K <= list length <= 32; exact from 2 K - 1 on)");
+    }
+    KB_REQUIRE_DEVICE("the list merge.");
+    (void)hipGetLastError();
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    const uint64_t n_pixels = (uint64_t)sw * (uint64_t)sh;
+    hipLaunchKernelGGL(kb_merge_compact_exact_kernel, dim3((unsigned)((n_pixels + 63) / 64)), dim3(64), 0, stream, lists_dev,
+                       n_lists, n_pixels, (int)list_len, K, (int)sw, params.x_start_min, params.y_start_min, all_cands_dev,
+                       n_all_cands, out_dev);
     KB_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -303,5 +303,96 @@ KB_HD void evaluate_trajectory_full(const kb_psi_phi_meta& m, const void* arr, c
     c->flux = flux_from_sums(new_psi, new_phi);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tie-exact merge of per-device lists (kb_merge_compact_exact and its host twin; see search_kernels.hip).
+// read(list, position) -> kb_compact_result of this pixel; merged / heads / slots: caller's scratch of
+// MERGE_EXACT_MAX_K2 / n_lists / MERGE_EXACT_MAX_K2 entries.  On return slots[0 .. n) index `merged`: the pixel's
+// final list.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int MERGE_EXACT_MAX_K2 = 32;
+struct MergedEntry {
+    float lh;
+    int cand;
+    uint32_t at;  // list * K2 + position: where the record sits
+};
+
+template <typename ReadRecord>
+KB_HD int merge_exact_pixel(const ReadRecord& read, int n_lists, int K2, int K, MergedEntry* merged,
+                                                 int* heads, int* slots) {
+    // (1) first K2 entries of the union by (lh descending, candidate ascending); every list is in that order
+    for (int r = 0; r < n_lists; ++r) heads[r] = 0;
+    int n = 0;
+    while (n < K2) {
+        int best = -1;
+        float best_lh = 0.0f;
+        int best_cand = 0;
+        for (int r = 0; r < n_lists; ++r) {
+            if (heads[r] >= K2) continue;
+            const kb_compact_result rec = read(r, heads[r]);
+            if (rec.cand < 0) {  // placeholders close a list
+                heads[r] = K2;
+                continue;
+            }
+            if (best < 0 || rec.lh > best_lh || (rec.lh == best_lh && rec.cand < best_cand)) {
+                best = r;
+                best_lh = rec.lh;
+                best_cand = rec.cand;
+            }
+        }
+        if (best < 0) break;
+        merged[n].lh = best_lh;
+        merged[n].cand = best_cand;
+        merged[n].at = (uint32_t)(best * K2 + heads[best]);
+        heads[best] += 1;
+        n += 1;
+    }
+    // (2) nothing equal among the first K + 1: the prefix is the list
+    bool strict = true;
+    for (int i = 0; i + 1 < n && i < K; ++i) strict = strict && (merged[i].lh > merged[i + 1].lh);
+    const int n_out = n < K ? n : K;
+    if (strict) {
+        for (int s = 0; s < n_out; ++s) slots[s] = s;
+        return n_out;
+    }
+    // (3) replay G in candidate order with the reference's insertion
+    const bool full = n >= K;
+    const float v = full ? merged[K - 1].lh : 0.0f;
+    int n_equal = 0;
+    uint32_t in_g = 0;  // bit i: merged[i] belongs to G (K2 <= 32)
+    for (int i = 0; i < n; ++i) {
+        bool take = true;
+        if (full) {
+            if (merged[i].lh == v) {
+                take = n_equal < K;
+                n_equal += 1;
+            } else {
+                take = merged[i].lh > v;
+            }
+        }
+        if (take) in_g |= 1u << i;
+    }
+    int filled = 0;
+    for (int s = 0; s < K; ++s) slots[s] = -1;
+    while (in_g != 0u) {
+        int pick = -1;
+        for (int i = 0; i < n; ++i) {
+            if (((in_g >> i) & 1u) && (pick < 0 || merged[i].cand < merged[pick].cand)) pick = i;
+        }
+        in_g &= ~(1u << pick);
+        int cur = pick;
+        for (int s = 0; s < K; ++s) {  // kernels.cu:323-330: strict '>' against a slot, an empty slot loses
+            if (slots[s] < 0 || merged[cur].lh > merged[slots[s]].lh) {
+                const int t = slots[s];
+                slots[s] = cur;
+                cur = t;
+                if (cur < 0) break;
+            }
+        }
+        if (filled < K) filled += 1;
+    }
+    return filled < n_out ? filled : n_out;
+}
+
+
 }  // namespace kb
 #endif

@@ -47,6 +47,7 @@ struct ResolveArgs {
     ResultSink next;  // per-pixel lists after this batch
     int T, K, sw, sh, tiles_x;
     int n_rows;
+    int stable_lists;  // SearchArgs::stable_lists
 };
 
 // Monotone 32-bit key of a ratio: -0 and +0 share a key, like the comparison they replace.
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256) void kb_sigmag_select_kernel(const ResolveArgs
 #pragma unroll
             for (int k = 0; k < AHEAD; ++k) {
                 // kernels.cu:318-320 on the clipped value (obs_count was tested before the clip and is unchanged)
-                if (e[k] >= 0 && ((mask[k] >> lane) & 1) && !(lh[k] < a.params.min_lh)) top.insert(lh[k], e[k]);
+                if (e[k] >= 0 && ((mask[k] >> lane) & 1) && !(lh[k] < a.params.min_lh)) top.insert(lh[k], e[k], a.stable_lists != 0);
             }
         }
     }
@@ -487,6 +488,7 @@ int launch_sigmag_resolve(const SearchArgs& s, const SearchCold& cold, const Res
     a.sh = s.sh;
     a.tiles_x = s.tiles_x;
     a.n_rows = s.tiles_x * s.sh;
+    a.stable_lists = s.stable_lists;
     const int clip_blocks = std::max(1, scratch_waves / (CLIP_BLOCK / WAVE));
     if (a.T <= WAVE || a.T > 4 * WAVE) {  // beyond 256 epochs: the literal code only
         hipLaunchKernelGGL(kb_sigmag_clip_kernel<1>, dim3(clip_blocks), dim3(CLIP_BLOCK), 0, stream, a);

@@ -4,15 +4,23 @@ The product side of ``kbmod.filters.sigma_g_filter.SigmaGClipping`` (src/kbmod/f
 19-168): the object carries the same parameters, and ``compute_clipped_sigma_g_matrix`` -- what
 ``SearchRunner.load_and_filter_results`` calls on up to S*K likelihood curves (run_search.py:251-337) -- runs
 ``kb_sigma_g_clip_matrix`` through the C ABI.  Like the rest of the product it raises ``RuntimeError`` without
-a GPU.  The reference's single-curve numpy helper is host-only code with nothing to accelerate; its behaviour is
-pinned in oracle/post_search.py and is not duplicated here.
+a GPU.  The single-curve form (``compute_clipped_sigma_g``) and the quantile helper (``invert_gauss_cdf``) are a
+few lines of host numpy, kept because callers of the reference use them.
 """
 
-from statistics import NormalDist
+import math
 
 import numpy as np
+from scipy.special import erfinv
 
 from . import search as _search
+
+
+def invert_gauss_cdf(z):
+    """Standard normal quantile of probability ``z`` through the inverse error function, the reference's formulation
+    (sigma_g_filter.py:85-92): -inf / +inf at 0 / 1, so that percentile bounds on the edge give a coefficient of 0."""
+    side = -1.0 if z < 0.5 else 1.0
+    return float(side * math.sqrt(2.0) * erfinv(side * (2.0 * z - 1.0)))
 
 
 def sigma_g_coefficient(low_pct, high_pct):
@@ -20,8 +28,7 @@ def sigma_g_coefficient(low_pct, high_pct):
     inter-percentile range into a standard deviation (0.7413 for [25, 75]; sigma_g_filter.py:49-83)."""
     if not (0 <= low_pct < high_pct <= 100):
         raise ValueError(f"Invalid percentiles for sigma G coefficient [{low_pct}, {high_pct}]")
-    z = NormalDist().inv_cdf
-    return 1.0 / (z(high_pct / 100.0) - z(low_pct / 100.0))
+    return 1.0 / (invert_gauss_cdf(high_pct / 100.0) - invert_gauss_cdf(low_pct / 100.0))
 
 
 class SigmaGClipping:
@@ -39,6 +46,20 @@ class SigmaGClipping:
         self.coeff = sigma_g_coefficient(low_bnd, high_bnd)
 
     find_sigma_g_coeff = staticmethod(sigma_g_coefficient)
+    invert_gauss_cdf = staticmethod(invert_gauss_cdf)
+
+    def compute_clipped_sigma_g(self, lh):
+        """Indices of ONE likelihood curve that lie strictly within ``n_sigma`` sigma-G of its median
+        (sigma_g_filter.py:94-123): percentiles by numpy's linear interpolation over all points -- over the positive
+        ones with ``clip_negative``, and nothing survives a curve without any --, the inter-percentile range floored
+        at 1e-8.  Host numpy: one curve is not device work; batches go through ``compute_clipped_sigma_g_matrix``."""
+        curve = np.asarray(lh)
+        basis = curve[curve > 0] if self.clip_negative else curve
+        if basis.size == 0:
+            return np.array([])
+        low, middle, high = np.percentile(basis, [self.low_bnd, 50, self.high_bnd])
+        reach = self.n_sigma * self.coeff * max(high - low, 1e-8)
+        return np.flatnonzero((curve > middle - reach) & (curve < middle + reach))
 
     def compute_clipped_sigma_g_matrix(self, lh):
         """N x T curves -> N x T bool matrix (True = kept), computed on the device."""

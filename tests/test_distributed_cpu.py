@@ -29,6 +29,52 @@ def _free_port():
     return p
 
 
+def _exact_worker(rank, world, port, out_dir):
+    """Tie-exact exchange: every rank keeps the top 2 K of ITS candidates by (likelihood descending, candidate
+    ascending) -- what the device search leaves with flag 512; here the oracle evaluates every candidate and the
+    order is imposed with a stable sort -- and rank 0 merges with kb_merge_compact_exact's host twin."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kbmod_amd import distributed as kdist
+        from kbmod_amd import fake_data as fd
+        from oracle import oracle as orc
+        from tests import util
+
+        st = util.make_stack(12, 24, 40, seed=21, objects=[(8, 6, 14.0, 9.0, 200.0)], mask_fraction=0.02)
+        vx, vy = fd.kbmod_v1_candidates(7, 1.0, 40.0, 5, 0.0, 1.5)  # 35 candidates: uneven split, slow ones that coincide
+        K, S = 4, 24 * 40
+        pp = orc.PsiPhi.from_images(st.sci, st.var, st.psfs, st.zeroed_times)
+        lo, hi = kdist.shard_bounds(len(vx), rank, world)
+        n_local = hi - lo
+        every = pp.search_kernel_semantics(orc.make_candidates(vx[lo:hi], vy[lo:hi]),
+                                           pp.default_params(results_per_pixel=n_local)).reshape(S, n_local)
+        index = {(float(a), float(b)): i for i, (a, b) in enumerate(zip(vx, vy))}
+        rec = np.zeros((S, 2 * K), dtype=[("lh", "<f4"), ("flux", "<f4"), ("cand", "<i4"), ("obs_count", "<i4")])
+        rec["lh"], rec["cand"] = np.float32(-3.4028234663852886e38), -1
+        for p in range(S):
+            rows = [(r["lh"], index[(float(r["vx"]), float(r["vy"]))], r["flux"], r["obs_count"]) for r in every[p]
+                    if r["lh"] != np.float32(-3.4028234663852886e38)]
+            rows.sort(key=lambda r: (-r[0], r[1]))
+            for s, r in enumerate(rows[:2 * K]):
+                rec[p, s] = (r[0], r[2], r[1], r[3])
+        local_t = torch.from_numpy(rec.reshape(-1).view(np.int32).reshape(S * 2 * K, 4).copy())
+        all_cands = np.zeros((len(vx), 7), dtype=np.float32)
+        all_cands[:, 0], all_cands[:, 1] = vx, vy
+        merged = kdist.gather_and_merge_compact(local_t, (0, 40), (0, 24), K, torch.from_numpy(all_cands), list_len=2 * K)
+        assert (merged is None) == (rank != 0)
+        if rank == 0:
+            full = pp.search_kernel_semantics(orc.make_candidates(vx, vy), pp.default_params(results_per_pixel=K))
+            np.save(os.path.join(out_dir, "got.npy"), merged.numpy().reshape(-1).view(orc.TRJ_DTYPE))
+            np.save(os.path.join(out_dir, "full.npy"), full)
+            more = pp.search_kernel_semantics(orc.make_candidates(vx, vy), pp.default_params(results_per_pixel=K + 1))
+            np.save(os.path.join(out_dir, "more_lh.npy"), more["lh"].reshape(S, K + 1))
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -105,3 +151,13 @@ def test_two_rank_gather_and_merge(tmp_path, orc, kb):
     # the competing candidates sample the same pixels -- but possibly another member of the tie
     for name in ("flux", "obs_count"):
         assert np.array_equal(g[name][tied], f[name][tied]), name
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tie_exact_gather_and_merge(tmp_path, orc, kb, world):
+    mp.spawn(_exact_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "got.npy")
+    full = np.load(tmp_path / "full.npy")
+    assert got.tobytes() == full.tobytes()  # every field of every slot, ties included
+    more = np.load(tmp_path / "more_lh.npy")
+    assert ((more[:, :-1] == more[:, 1:]) & (more[:, :-1] > np.float32(-3.0e38))).any()  # and there were ties to get right

@@ -128,3 +128,70 @@ def test_search_all_over_several_search_devices(kb, orc, devices, cfg):
     exp = util.as_table(orc.filter_sort(pp.search_kernel_semantics(orc.make_candidates(vx, vy), params), params.min_lh,
                                         params.min_observations))
     assert np.array_equal(b, exp)
+
+
+def _slots(search):
+    """Per-pixel result slots of the last search (before the global sort), as the set of result rows: the final sort
+    is by likelihood only, so equal likelihoods may come out in another order -- compare as sorted row lists."""
+    rows = search.results_to_numpy()
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+@pytest.mark.parametrize("K", [8, 16])
+def test_fan_out_is_tie_exact_over_the_whole_image(kb, orc, K):
+    """Start pixels at the image border, slow candidates that share samples, masked pixels: likelihood ties among the
+    best of a pixel.  With up to 16 results per pixel the fan-out uses 2 K stable lists + kb_merge_compact_exact, so
+    the rows equal the single-device rows (and the oracle's), ties included."""
+    st = util.make_stack(12, 40, 90, seed=3, noise=3.0, objects=[(30, 20, 9.0, 4.0, 260.0)], mask_fraction=0.03)
+    vx, vy = fd.kbmod_v1_candidates(9, 1.0, 25.0, 8, 0.0, 1.5)  # slow ones included: duplicates of each other on the grid
+    cands = util.trajectories(kb, vx, vy)
+    cfg = {"K": K}
+    one = kb.StackSearch(st.sci, st.var, st.psfs, st.zeroed_times)
+    util.configure(one, cfg)
+    one.search_all(cands, True)
+    many = kb.StackSearch(st.sci, st.var, st.psfs, st.zeroed_times)
+    util.configure(many, cfg)
+    many.set_search_devices([0, 0, 0])
+    many.search_all(cands, True)
+    a, b = _slots(one), _slots(many)
+    assert a.shape == b.shape and np.array_equal(a, b)
+    pp = orc.PsiPhi.from_images(st.sci, st.var, st.psfs, st.zeroed_times)
+    params = util.oracle_params(pp, cfg)
+    every = pp.search_kernel_semantics(orc.make_candidates(vx, vy), util.oracle_params(pp, {"K": K + 1}))
+    lh = every["lh"].reshape(-1, K + 1)
+    assert (lh[:, :-1] == lh[:, 1:]).any()  # ties among the K + 1 best of some pixel
+    exp = util.as_table(orc.filter_sort(pp.search_kernel_semantics(orc.make_candidates(vx, vy), params), params.min_lh,
+                                        params.min_observations))
+    assert np.array_equal(b, exp[np.lexsort(exp.T[::-1])])
+
+
+def test_fan_out_falls_back_loudly_for_long_lists(kb):
+    """results_per_pixel > 32 is outside the exchange format: the search runs on one device and SAYS so."""
+    import logging
+
+    st = util.make_stack(6, 20, 70, seed=4, noise=3.0)
+    vx, vy = fd.kbmod_v1_candidates(6, 2.0, 20.0, 8, 0.0, 1.2)
+    cands = util.trajectories(kb, vx, vy)
+    messages = []
+
+    class Sink(logging.Handler):
+        def emit(self, record):
+            messages.append((record.levelname, record.getMessage()))
+
+    lg = logging.getLogger("kbmod.search.run_search")
+    handler = Sink()
+    lg.addHandler(handler)
+    lg.setLevel(logging.DEBUG)
+    try:
+        kb.Logging.registerLogger(lg)
+        one = kb.StackSearch(st.sci, st.var, st.psfs, st.zeroed_times)
+        one.set_results_per_pixel(40)
+        one.search_all(cands, True)
+        many = kb.StackSearch(st.sci, st.var, st.psfs, st.zeroed_times)
+        many.set_results_per_pixel(40)
+        many.set_search_devices([0, 0])
+        many.search_all(cands, True)
+    finally:
+        lg.removeHandler(handler)
+    assert np.array_equal(one.results_to_numpy(), many.results_to_numpy())
+    assert any(level == "WARNING" and "one device" in text for level, text in messages), messages

@@ -93,6 +93,79 @@ def test_sharded_search_equals_unsharded(kb, ds, grid, world, cfg):
         assert np.array_equal(g[name][~tied], f[name][~tied]), name
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("cfg", [dict(K=8), dict(K=3, min_obs=5, min_lh=1.0), dict(K=16),
+                                 dict(K=4, min_obs=8, sigmag=(0.25, 0.75, 0.7413, 3.0))])
+def test_tie_exact_sharded_search_equals_unsharded(kb, ds, grid, world, cfg):
+    """Every slice searched with 2 K stable lists (flag 512), merged by kb_merge_compact_exact: the result IS the
+    unsharded search, field for field, at every pixel -- including the border pixels whose trajectories leave the
+    image over the same samples and tie (the plain merge above only promises their likelihoods)."""
+    from kbmod_amd import distributed as kdist
+
+    vx, vy = grid
+    all_cands = ds.candidates(vx, vy)
+    p = ds.params(**cfg)
+    K = p.results_per_pixel
+    p2 = ds.params(**{**cfg, "K": 2 * K})
+    parts = []
+    for r in range(world):
+        lo, hi = kdist.shard_bounds(len(vx), r, world)
+        rec, _ = ds.search_compact(p2, all_cands[lo:hi], lo, 512)
+        parts.append(rec)
+    gathered = ds.torch.stack(parts)
+    merged = kdist.merge_compact_exact(gathered, (0, ds.W), (0, ds.H), K, 2 * K, all_cands)
+    ds.torch.cuda.synchronize()
+    host = kdist.merge_compact_exact(gathered.cpu(), (0, ds.W), (0, ds.H), K, 2 * K, all_cands.cpu())
+    assert ds.torch.equal(merged.cpu().view(ds.torch.int32), host.view(ds.torch.int32))  # kernel == host twin
+    full, _ = ds.search(p, all_cands, 0)
+    assert ds.torch.equal(merged.view(ds.torch.int32), full.view(ds.torch.int32))
+    # the test means something: some pixels do hold ties among their K + 1 best (where the plain merge may differ)
+    every, _ = ds.search(ds.params(**{**cfg, "K": 32}), all_cands, 0)
+    e = util.as_records(every).reshape(-1, 32)["lh"][:, :K + 1]
+    assert ((e[:, :-1] == e[:, 1:]) & (e[:, :-1] != EMPTY)).any()
+
+
+def test_stable_lists_are_the_top_by_likelihood_then_candidate(ds, grid):
+    """Flag 512 alone: the per-pixel list is the first K of the candidates ordered by (likelihood descending, index
+    ascending) -- checked against a list long enough to hold every candidate."""
+    vx, vy = grid
+    cands = ds.candidates(vx, vy)
+    K = 8
+    for flags in (512 | 2, 512 | 4):
+        got, _ = ds.search_compact(ds.params(K=K), cands, 0, flags)
+        g = util.as_records(got, util.COMPACT_DTYPE).reshape(-1, K)
+        every, _ = ds.search_compact(ds.params(K=32), cands, 0, flags)  # 132 candidates > 32: compare values only ...
+        e = util.as_records(every, util.COMPACT_DTYPE).reshape(-1, 32)
+        assert np.array_equal(g["lh"], e["lh"][:, :K]) and np.array_equal(g["cand"], e["cand"][:, :K])
+        filled = g["cand"] >= 0
+        lh_a, lh_b, c_a, c_b = g["lh"][:, :-1], g["lh"][:, 1:], g["cand"][:, :-1], g["cand"][:, 1:]
+        both = filled[:, :-1] & filled[:, 1:]
+        assert ((lh_a > lh_b) | ((lh_a == lh_b) & (c_a < c_b)))[both].all()
+        assert ((lh_a == lh_b) & both).any()  # ties are present in this stack
+
+
+def test_two_ranks_on_one_gpu_through_gloo(tmp_path):
+    """bench.py --gpus 2 end to end on this box's single GPU: two processes, the gloo backend carrying the records
+    through host memory (KBMOD_DIST_BACKEND; RCCL refuses two ranks on one device), tie-exact merge on rank 0,
+    verified against one search over the job-wide candidate list."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KBMOD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "16",
+           "--size", "128", "--vel-steps", "8", "--ang-steps", "4", "--verify", "--no-cpu-baseline"]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["verify"] == {"merged_equals_single_device_ok": True, "merged_likelihoods_equal_ok": True, "tie_exact": True,
+                              "backend": "gloo"}
+    assert line["config"]["candidates_per_gpu"] == 32
+
+
 @pytest.mark.parametrize("world", [2, 5])
 def test_merge_topk_kernel_equals_host_twin(kb, ds, grid, world):
     from kbmod_amd import distributed as kdist

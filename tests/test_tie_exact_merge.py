@@ -1,0 +1,94 @@
+"""Tie-exact merge of per-device result lists (kb_merge_compact_exact; host twin here, device kernel in
+tests/test_gpu_multi.py).  The claim (csrc/search_kernels.hip): per-device lists of 2K entries
+built by STABLE insertion, merged under (likelihood descending, candidate ascending) and replayed over the
+candidates above the K-th value plus the first K equal to it, reproduce the reference's sequential swap-down
+insertion over the whole candidate list -- for any partition of the candidates.  Checked by brute force on
+likelihoods drawn from a handful of levels (ties everywhere)."""
+
+import numpy as np
+import pytest
+
+EMPTY_LH = np.float32(-3.4028234663852886e38)
+REC = np.dtype([("lh", "<f4"), ("flux", "<f4"), ("cand", "<i4"), ("obs", "<i4")])
+
+
+def swap_down(seq, K):
+    """kernels.cu:323-330 over (lh, cand) pairs in list order."""
+    slots = [(EMPTY_LH, -1)] * K
+    for item in seq:
+        cur = item
+        for s in range(K):
+            if cur[0] > slots[s][0]:
+                cur, slots[s] = slots[s], cur
+    return slots
+
+
+def stable_top(seq, n):
+    """What a device's search leaves with flag 512: the top n by (lh descending, candidate ascending)."""
+    slots = [(EMPTY_LH, -1)] * n
+    for item in seq:
+        cur, placed = item, False
+        for s in range(n):
+            if placed or cur[0] > slots[s][0]:
+                cur, slots[s] = slots[s], cur
+                placed = True
+    return slots
+
+
+@pytest.fixture(scope="module")
+def kb():
+    import kbmod_amd.search as kb
+
+    return kb
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 8, 16])
+def test_merge_reproduces_sequential_insertion(kb, K):
+    rng = np.random.default_rng(100 + K)
+    n_pixels, n_cands = 300, 70
+    K2 = 2 * K
+    for n_lists, interleaved, levels in [(1, False, 3), (2, False, 2), (3, True, 4), (8, False, 3), (8, True, 60), (5, False, 1)]:
+        lh = rng.integers(0, levels + 1, (n_pixels, n_cands)).astype(np.float32)
+        lh[rng.random((n_pixels, n_cands)) < 0.1] = -1.0  # the value of a trajectory without data
+        keep = rng.random((n_pixels, n_cands)) < 0.9       # candidates the thresholds drop never reach a list
+        if interleaved:
+            owner = np.arange(n_cands) % n_lists
+        else:
+            cuts = np.sort(rng.choice(np.arange(1, n_cands), n_lists - 1, replace=False)) if n_lists > 1 else []
+            owner = np.searchsorted(cuts, np.arange(n_cands), side="right")
+        lists = np.zeros((n_lists, n_pixels, K2), dtype=REC)
+        truth = []
+        for p in range(n_pixels):
+            seq = [(lh[p, c], c) for c in range(n_cands) if keep[p, c]]
+            truth.append(swap_down(seq, K))
+            for r in range(n_lists):
+                top = stable_top([it for it in seq if owner[it[1]] == r], K2)
+                lists[r, p]["lh"] = [t[0] for t in top]
+                lists[r, p]["cand"] = [t[1] for t in top]
+                lists[r, p]["flux"] = [0.5 * t[1] for t in top]
+                lists[r, p]["obs"] = [t[1] + 1 if t[1] >= 0 else 0 for t in top]
+        cands = [kb.Trajectory(vx=float(c), vy=float(-c)) for c in range(n_cands)]
+        raw = np.ascontiguousarray(lists).view(np.uint8).reshape(-1)
+        out = kb.merge_compact_exact_host(raw, n_lists, K2, K, 0, n_pixels, 0, 1, cands)
+        out = out.view(np.dtype([("vx", "<f4"), ("vy", "<f4"), ("lh", "<f4"), ("flux", "<f4"), ("x", "<i4"), ("y", "<i4"),
+                                 ("obs", "<i4")])).reshape(n_pixels, K)
+        for p in range(n_pixels):
+            for s in range(K):
+                t_lh, t_c = truth[p][s]
+                got = out[p, s]
+                assert got["x"] == p and got["y"] == 0
+                if t_c < 0:
+                    assert got["lh"] == EMPTY_LH and got["obs"] == 0 and got["vx"] == 0.0
+                else:
+                    assert (got["lh"], got["vx"], got["vy"], got["flux"], got["obs"]) == (t_lh, t_c, -t_c, np.float32(0.5 * t_c), t_c + 1), \
+                        (K, n_lists, interleaved, p, s, truth[p], out[p])
+
+
+def test_merge_argument_checks(kb):
+    cands = [kb.Trajectory()]
+    with pytest.raises(RuntimeError):
+        kb.merge_compact_exact_host(np.zeros(16 * 4, np.uint8), 1, 4, 5, 0, 1, 0, 1, cands)  # K > list length
+    with pytest.raises(RuntimeError):
+        kb.merge_compact_exact_host(np.zeros(16 * 3, np.uint8), 1, 4, 2, 0, 1, 0, 1, cands)  # wrong buffer size
+    with pytest.raises(RuntimeError):
+        kb.merge_compact_exact_host(np.zeros(16 * 40, np.uint8), 1, 40, 2, 0, 1, 0, 1, cands)  # list length > 32
