@@ -41,8 +41,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-LDS_PEAK_GBPS = 150000.0  # aggregate ds_read_b64 rate with every CU streaming (MI355X_MICROARCH.md, LDS section)
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBPS = 6300.0  # what a float4 streaming copy reaches on this part (same guide; measured again in every run)
+LDS_PEAK_GBPS = 157000.0      # 256 B / clk / CU x 256 CUs x 2.4 GHz for ds_read_b64 (same guide, LDS table)
+INFINITY_CACHE_BYTES = 256 << 20
 
 from kbmod_amd.capi import Meta, Params, Stats, load_lib  # noqa: E402
 
@@ -183,6 +185,18 @@ def main():
                                                 T, H, W, args.num_bytes, C.byref(meta), C.byref(arr), stream))
     torch.cuda.synchronize()
     build_ms = (time.perf_counter() - t0) * 1e3
+    # the builder again, device time only (events on the stream it runs on): correlation + range scan + encode
+    build_kernel_ms = None
+    if rank == 0 and T * H * W * 16 < (8 << 30):
+        meta2, arr2 = Meta(), C.c_void_p()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib, lib.kb_build_psi_phi_from_device(sci.data_ptr(), var.data_ptr(), psf_all.ctypes.data, psf_dims.ctypes.data,
+                                                    T, H, W, args.num_bytes, C.byref(meta2), C.byref(arr2), stream))
+        e1.record()
+        torch.cuda.synchronize()
+        build_kernel_ms = e0.elapsed_time(e1)
+        lib.kb_free_gpu_block(arr2)
     del sci, var
 
     # ---- candidates: KBMODV1Search(32, 5, 40, 32, 0, 1.5) = 1024 per GPU; rank r
@@ -274,36 +288,51 @@ def main():
     # measured HBM peak: a streaming device copy (4 GiB each way) timed with HIP events in this run
     copy_gbps = C.c_double(0.0)
     check(lib, lib.kb_measure_copy_bandwidth(4 << 30, 10, stream, C.byref(copy_gbps)))
-    # ... and what a read-only stream over a block of the array's size reaches (no write traffic; for cfg2's 134 MB
-    # this is the rate at which the Infinity Cache feeds the L2s): the ceiling of the search's fabric traffic,
-    # which is 99 % reads
+    # ... what a read-only stream over a block of the array's size reaches (no write traffic; for cfg2's 134 MB this is
+    # the rate at which the Infinity Cache feeds the L2s): the ceiling of the search's fabric traffic, which is 99 % reads
     read_gbps = C.c_double(0.0)
     check(lib, lib.kb_measure_read_bandwidth(min(int(T) * H * W * 8, 4 << 30), 20, stream, C.byref(read_gbps)))
+    # ... and the aggregate LDS read rate (ds_read_b64 on every CU): the yardstick of the sums' LDS traffic
+    lds_gbps = C.c_double(0.0)
+    check(lib, lib.kb_measure_lds_bandwidth(4096, stream, C.byref(lds_gbps)))
 
-    # fabric-side traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (it cannot be
-    # read from inside this process); attached when the workload matches a profiled configuration.
-    traffic = traffic_source = None
+    # fabric-side traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (it cannot be read from
+    # inside this process); attached only when workload AND kernel instance are those of the profiled run.
+    instance = last.kernel_name.decode()
+    traffic = traffic_source = traffic_rejected = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             table = json.load(fh)
-        key = f"{dtype}:{T}x{H}x{W}:{n_local}:{kernel_name}" + (":sigmag" if args.sigmag else "")
-        if key in table:
-            traffic, traffic_source = table[key]["bytes"], table[key]["source"]
+        key = f"{dtype}:{T}x{H}x{W}:{n_local}" + (":sigmag" if args.sigmag else "")
+        entry = table.get(key)
+        if entry is not None and entry.get("kernel_instance") == instance:
+            traffic, traffic_source = entry["bytes"], entry["source"]
+        elif entry is not None:
+            traffic_rejected = f"profiles/traffic.json[{key}] was measured on {entry.get('kernel_instance')}, this run launched {instance}"
     except (OSError, ValueError):
         pass
 
-    # The binding resource.  kb_search_lds sums out of LDS: every evaluation is one 8-byte ds_read_b64
-    # lane read.  When the array (and its padded float copy) exceeds the 256 MiB Infinity Cache the
-    # fabric-side bytes are HBM bytes and the HBM line is the one to read.
+    # Three fractions that must not be confused:
+    #  frac_algorithmic  SURVEY 8(d): 2 * block_size bytes per evaluation / kernel time / 8 TB/s.  Above 1 whenever the
+    #                    array is cache-resident or staged once for several candidates (each staged pixel serves 8
+    #                    candidates and neighbouring tiles): those "bytes" are LDS reads, not HBM bytes.
+    #  frac              bytes the fabric moved (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of the same instance) / kernel
+    #                    time / 8 TB/s -- HBM traffic when the working set exceeds the Infinity Cache, cache hits
+    #                    included when it does not (said in `note`); without a matching profile: the algorithmic rate.
+    #  frac_lds          LDS bytes the sums read / kernel time / the LDS read rate measured in this run.
+    padded_guess = int(meta.total_array_size) * (8 // int(meta.block_size * 2) if meta.num_bytes != 4 else 1)
+    cache_resident = padded_guess <= INFINITY_CACHE_BYTES
     lds_rate = float(last.lds_read_bytes) / (k_ms * 1e-3) / 1e9
-    candidates = []
-    if last.lds_read_bytes:
-        candidates.append(("lds", lds_rate, LDS_PEAK_GBPS))
-    if traffic is not None:
-        candidates.append(("hbm", traffic / (k_ms * 1e-3) / 1e9, HBM_PEAK_GBPS))
-    if not candidates:  # kb_search_direct without a profile: the algorithmic rate is all there is
-        candidates.append(("hbm", alg_rate, HBM_PEAK_GBPS))
-    bound, achieved, peak = max(candidates, key=lambda c: c[1] / c[2])
+    achieved = alg_rate if traffic is None else traffic / (k_ms * 1e-3) / 1e9
+    note = []
+    if traffic is None:
+        note.append("no PMC profile of this workload and kernel instance under profiles/: achieved = algorithmic bytes / kernel "
+                    "time (can exceed the peak: staged pixels are reused out of LDS)")
+    else:
+        note.append("achieved = fabric bytes of the profiled instance / this run's kernel time")
+    if cache_resident:
+        note.append(f"the array's float copy ({padded_guess >> 20} MiB) fits the 256 MiB Infinity Cache: fabric bytes are "
+                    "cache hits, not DRAM traffic; the kernel is bound by LDS reads and instruction issue (frac_lds)")
 
     out = {
         "metric": "trajectory-epoch evals/sec",
@@ -330,31 +359,40 @@ def main():
             "psi_phi_build_ms": build_ms,
         },
         "roofline": {
-            "bound": bound,
+            "bound": "hbm",
             "achieved": achieved,
-            "peak": peak,
+            "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
-            "frac": achieved / peak,
+            "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
             "traffic_source": traffic_source,
-            "kernel": kernel_name,
+            "traffic_rejected": traffic_rejected,
+            "note": "; ".join(note),
+            "kernel": instance,
             "kernel_ms": k_ms,
             "kernel_evals_per_s": evals_per_step_rank / (k_ms * 1e-3),
-            "lds_read_bytes_per_launch": int(last.lds_read_bytes),
-            "lds_read_GBps": lds_rate,
-            "lds_peak_GBps": LDS_PEAK_GBPS,
+            "frac_algorithmic": alg_rate / HBM_PEAK_GBPS,
             "algorithmic_bytes_per_launch": int(last.algorithmic_bytes),
             "algorithmic_GBps": alg_rate,
-            "algorithmic_vs_hbm_peak": alg_rate / HBM_PEAK_GBPS,
-            "hbm_peak_nominal_GBps": HBM_PEAK_GBPS,
-            "hbm_measured_peak": float(copy_gbps.value),
-            "fabric_GBps": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9,
-            "fabric_frac_of_measured_peak": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9 / copy_gbps.value,
-            "read_measured_peak": float(read_gbps.value),
-            "fabric_frac_of_read_peak": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9 / read_gbps.value,
+            "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBPS,
+            "hbm_achievable_GBps": HBM_ACHIEVABLE_GBPS,
+            "hbm_measured_copy_GBps": float(copy_gbps.value),
+            "hbm_measured_read_GBps": float(read_gbps.value),
+            "frac_of_measured_copy": achieved / float(copy_gbps.value),
+            "frac_lds": None if not last.lds_read_bytes else lds_rate / float(lds_gbps.value),
+            "lds_read_bytes_per_launch": int(last.lds_read_bytes),
+            "lds_read_GBps": lds_rate,
+            "lds_measured_peak_GBps": float(lds_gbps.value),
+            "lds_guide_peak_GBps": LDS_PEAK_GBPS,
             "psi_phi_bytes": int(meta.total_array_size),
+            "cache_resident": bool(cache_resident),
         },
     }
+    if build_kernel_ms is not None:
+        in_out = float(T) * H * W * 8 + float(meta.total_array_size)  # sci + var in, the array out
+        out["psi_phi_build"] = {"device_ms": build_kernel_ms, "bytes_in_plus_out": in_out,
+                                "GBps": in_out / (build_kernel_ms * 1e-3) / 1e9,
+                                "frac_of_achievable": in_out / (build_kernel_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBPS}
     if args.sigmag:
         out["config"]["sigmag_work_items"] = int(last.sigmag_work_items)
         out["config"]["sigmag_trajectories_clipped"] = int(last.sigmag_trajectories)

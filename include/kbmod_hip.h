@@ -66,6 +66,10 @@ typedef struct kb_search_stats {
     uint64_t lds_read_bytes;      /* kb_search_lds: bytes the sums read out of LDS (num_evals x staged pair size), else 0 */
     uint64_t sigmag_literal;      /* ... of the clipped trajectories, those that took the literal per-lane exchange sort
                                      (equal ratios from different (psi, phi) pairs, stacks deeper than 256 epochs) */
+    char kernel_name[96];         /* the search kernel instance that ran, spelled as rocprofv3 prints it
+                                     (e.g. "kb::kb_search_lds<8, 8, 16, 4, true, false, 3, 1>") */
+    int32_t padded_copy_reused;   /* flag 256 was honoured: no decode-and-pad pass in this search */
+    int32_t reserved_;
 } kb_search_stats;
 
 const char* kb_last_error(void);
@@ -95,6 +99,10 @@ int kb_measure_copy_bandwidth(uint64_t bytes, int32_t iters, void* stream, doubl
  * Infinity Cache this is the rate at which that cache feeds the L2s (the ceiling of the cfg2 search, whose 134 MB
  * array stays resident there). */
 int kb_measure_read_bandwidth(uint64_t bytes, int32_t iters, void* stream, double* gbps_out);
+/* Aggregate LDS read rate of the device (new): every CU streams ds_read_b64 -- the read mix of kb_search_lds's summing
+ * loop -- for `iters` rounds of eight reads per wave; *gbps_out = bytes read out of LDS / time.  The yardstick of the
+ * search kernel's LDS traffic in bench.py's roofline block. */
+int kb_measure_lds_bandwidth(int32_t iters, void* stream, double* gbps_out);
 
 /* ---- PSF convolution: kernels/image_kernels.cu:68-108 (deviceConvolve) --- */
 /* Host image in, host image out, one image.  empty_is_nan = 0 reproduces the

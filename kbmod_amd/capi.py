@@ -31,7 +31,8 @@ class Stats(C.Structure):
     _fields_ = [("search_kernel_ms", C.c_float), ("table_kernel_ms", C.c_float), ("num_evals", C.c_uint64),
                 ("algorithmic_bytes", C.c_uint64), ("kernel_variant", C.c_int32), ("num_search_launches", C.c_int32),
                 ("sigmag_work_items", C.c_uint64), ("sigmag_trajectories", C.c_uint64), ("lds_read_bytes", C.c_uint64),
-                ("sigmag_literal", C.c_uint64)]
+                ("sigmag_literal", C.c_uint64), ("kernel_name", C.c_char * 96), ("padded_copy_reused", C.c_int32),
+                ("reserved_", C.c_int32)]
 
 
 def lib_path():
@@ -66,6 +67,7 @@ def load_lib():
     lib.kb_copy_block_to_gpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.kb_measure_copy_bandwidth.argtypes = [C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]
     lib.kb_measure_read_bandwidth.argtypes = [C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]
+    lib.kb_measure_lds_bandwidth.argtypes = [C.c_int32, C.c_void_p, C.POINTER(C.c_double)]
     lib.kb_debug_wave_ops.argtypes = [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]
     _lib = lib
     return lib

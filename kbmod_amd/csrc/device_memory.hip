@@ -12,40 +12,65 @@ int fail(const std::string& msg) {
     set_error(msg);
     return 1;
 }
-// Streaming copy used to measure what HBM delivers on this device (the "measured peak" next to the
-// nominal 8 TB/s in the roofline report): 16 bytes per lane, grid-stride.
-__global__ __launch_bounds__(256) void kb_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
-    // four independent 16-byte loads in flight per lane before the first store
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a;
-        dst[i + stride] = b;
-        dst[i + 2 * stride] = c;
-        dst[i + 3 * stride] = d;
-    }
-    for (; i < n; i += stride) dst[i] = src[i];
+// Streaming copy used to measure what HBM delivers on this device (the "measured peak" next to the nominal 8 TB/s
+// in the roofline report).  One 16-byte element per thread, no loop, the store non-temporal: of the forms swept on
+// MI355X (tools/ubench/copybench.hip: grid-stride loops of 4 .. 64 Ki workgroups, contiguous spans per workgroup,
+// 256 / 1024 threads, non-temporal loads and / or stores, hipMemcpyAsync) this is the one that reaches the rate the
+// hardware guide documents for a float4 copy -- 6.3-6.4 TB/s on 4 GiB each way, where the grid-stride loop of 4096
+// workgroups this probe used before stops at 4.9.
+typedef uint32_t Quad __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void kb_copy_kernel(const Quad* __restrict__ src, Quad* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) __builtin_nontemporal_store(src[i], dst + i);
 }
 
 // Read-only stream over the same block: what the fabric delivers to the L2s without any write traffic (for a
-// block smaller than the Infinity Cache: the rate at which that cache feeds the XCDs).
-__global__ __launch_bounds__(256) void kb_read_kernel(const uint4* __restrict__ src, size_t n, uint32_t* __restrict__ sink) {
+// block smaller than the Infinity Cache: the rate at which that cache feeds the XCDs).  Four non-temporal 16-byte
+// loads in flight per lane, the grid sized so that they cover the block exactly (6.9 TB/s on 4 GiB).
+constexpr int READ_PROBE_LOADS = 4;
+__global__ __launch_bounds__(256) void kb_read_kernel(const Quad* __restrict__ src, size_t n, uint32_t* __restrict__ sink) {
     const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t acc = 0;
-    for (; i + 7 * stride < n; i += 8 * stride) {
-        uint4 v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = src[i + k * stride];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
-    }
-    for (; i < n; i += stride) {
-        const uint4 v = src[i];
-        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    for (int k = 0; k < READ_PROBE_LOADS; ++k) {
+        if (i + k * stride < n) {
+            const Quad v = __builtin_nontemporal_load(src + i + k * stride);
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
     }
     if (acc == 0x9e3779b9u) sink[0] = acc;  // never true for the memset pattern; keeps the loads alive
+}
+
+// LDS read rate with every CU streaming: each wave of a 1024-thread workgroup issues `iters` rounds of eight
+// conflict-free ds_read_b64 (512 bytes per wave-instruction) -- the read mix of kb_search_lds's summing loop without
+// its adds.  The figure the roofline block of bench.py holds the search kernel's LDS traffic against.
+struct LdsProbeOffsets {
+    int o[8];  // byte offsets of the eight reads: runtime values, like the table words of the search kernel (constants
+               // would let the compiler fuse pairs of reads into ds_read2_b64, another instruction with another rate)
+};
+__global__ __launch_bounds__(1024) void kb_lds_read_kernel(int iters, int stride, LdsProbeOffsets offs, uint32_t* __restrict__ sink) {
+    __shared__ __attribute__((aligned(16))) float2 slab[8192];  // 64 KiB
+    for (int i = threadIdx.x; i < 8192; i += 1024) slab[i] = make_float2((float)i, 1.0f);
+    __syncthreads();
+    typedef float Pair __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(3))) Pair* LdsPair;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t base0 = (uint32_t)(uintptr_t)slab + (wave * 72 + lane) * 8;
+    uint32_t base = base0;
+    Pair acc = Pair{0.0f, 0.0f};
+    for (int it = 0; it < iters; ++it) {
+        Pair v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = *(LdsPair)(uintptr_t)(base + offs.o[c]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) asm volatile("" ::"v"(v[c]));
+        base += stride;
+        if ((it & 3) == 3) base = base0;
+        if (it == iters - 1) acc = v[0];
+    }
+    if (acc.x == -1.0f) sink[0] = 1u;
 }
 }  // namespace kb
 
@@ -150,16 +175,16 @@ int kb_measure_copy_bandwidth(uint64_t bytes, int32_t iters, void* stream_v, dou
         return fail("measure_copy_bandwidth: out of device memory");
     }
     (void)hipMemsetAsync(src, 1, n * 16, stream);
-    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
     float ms = 0.0f;
     {
         EventTimer timer(stream, true);
-        hipLaunchKernelGGL(kb_copy_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4*>(src),
-                           reinterpret_cast<uint4*>(dst), n);
+        hipLaunchKernelGGL(kb_copy_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const Quad*>(src),
+                           reinterpret_cast<Quad*>(dst), n);
         timer.begin();
         for (int i = 0; i < iters; ++i) {
-            hipLaunchKernelGGL(kb_copy_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4*>(src),
-                               reinterpret_cast<uint4*>(dst), n);
+            hipLaunchKernelGGL(kb_copy_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const Quad*>(src),
+                               reinterpret_cast<Quad*>(dst), n);
         }
         ms = timer.end();
     }
@@ -182,14 +207,14 @@ int kb_measure_read_bandwidth(uint64_t bytes, int32_t iters, void* stream_v, dou
     KB_HIP_TRY(hipMalloc(&src, n * 16 + 16));
     (void)hipMemsetAsync(src, 1, n * 16 + 16, stream);
     uint32_t* sink = reinterpret_cast<uint32_t*>(static_cast<char*>(src) + n * 16);
-    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+    const unsigned blocks = (unsigned)((n + 256 * READ_PROBE_LOADS - 1) / (256 * READ_PROBE_LOADS));
     float ms = 0.0f;
     {
         EventTimer timer(stream, true);
-        hipLaunchKernelGGL(kb_read_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4*>(src), n, sink);
+        hipLaunchKernelGGL(kb_read_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const Quad*>(src), n, sink);
         timer.begin();
         for (int i = 0; i < iters; ++i) {
-            hipLaunchKernelGGL(kb_read_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4*>(src), n,
+            hipLaunchKernelGGL(kb_read_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const Quad*>(src), n,
                                sink);
         }
         ms = timer.end();
@@ -198,6 +223,35 @@ int kb_measure_read_bandwidth(uint64_t bytes, int32_t iters, void* stream_v, dou
     KB_HIP_TRY(hipGetLastError());
     if (!(ms > 0.0f)) return fail("measure_read_bandwidth: no time measured");
     *gbps_out = (double)(n * 16) * iters / ((double)ms * 1e-3) / 1e9;
+    return 0;
+}
+
+// Aggregate LDS read rate (ds_read_b64, every CU busy): bytes = workgroups x 16 waves x iters x 8 x 512.
+int kb_measure_lds_bandwidth(int32_t iters, void* stream_v, double* gbps_out) {
+    using namespace kb;
+    if (gbps_out == nullptr || iters <= 0) return fail("measure_lds_bandwidth: bad argument");
+    KB_REQUIRE_DEVICE("the LDS-bandwidth probe.");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    int dev = 0, cus = 256;
+    KB_HIP_TRY(hipGetDevice(&dev));
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    uint32_t* sink = nullptr;
+    KB_HIP_TRY(hipMalloc(&sink, 64));
+    const unsigned blocks = (unsigned)std::max(cus, 1) * 2;  // two rounds of one workgroup per CU
+    float ms = 0.0f;
+    {
+        EventTimer timer(stream, true);
+        LdsProbeOffsets offs;
+        for (int c = 0; c < 8; ++c) offs.o[c] = c * 584;
+        hipLaunchKernelGGL(kb_lds_read_kernel, dim3(blocks), dim3(1024), 0, stream, 64, 576, offs, sink);
+        timer.begin();
+        hipLaunchKernelGGL(kb_lds_read_kernel, dim3(blocks), dim3(1024), 0, stream, (int)iters, 576, offs, sink);
+        ms = timer.end();
+    }
+    (void)hipFree(sink);
+    KB_HIP_TRY(hipGetLastError());
+    if (!(ms > 0.0f)) return fail("measure_lds_bandwidth: no time measured");
+    *gbps_out = (double)blocks * 16.0 * (double)iters * 8.0 * 512.0 / ((double)ms * 1e-3) / 1e9;
     return 0;
 }
 

@@ -502,6 +502,7 @@ PYBIND11_MODULE(search, m) {
                 d["sigmag_work_items"] = st.sigmag_work_items;
                 d["sigmag_trajectories"] = st.sigmag_trajectories;
                 d["sigmag_literal"] = st.sigmag_literal;
+                d["kernel_name"] = std::string(st.kernel_name);
                 return d;
             });
 

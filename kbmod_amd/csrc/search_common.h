@@ -505,6 +505,9 @@ void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, int lis
 void launch_search_lds_canon_deep(const SearchArgs& a, int rows, bool sigmag, hipStream_t stream);  // search_lds_deep.hip
 void launch_search_lds_encoded(const SearchArgs& a, int rows, int fmt, bool sigmag, hipStream_t stream);
 
+// The launchers record which template instance they started, spelled as rocprofv3 prints it (kb_search_stats::kernel_name).
+void note_kernel_instance(const char* name);
+
 int launch_sigmag_resolve(const SearchArgs& a, const SearchCold& cold, const ResultSink* prev, const ResultSink& next,
                           int scratch_waves, hipStream_t stream);
 

@@ -1,6 +1,8 @@
 // Fallback search kernels of libkbmod_hip.so: kb_search_direct (every sample a wave-wide load from
 // the array itself; few candidates, scattered candidate lists, shifts the table could not prove) and
 // kb_search_large_k (results_per_pixel > 32).  See search_kernels.hip for the overall design.
+#include <cstdio>
+
 #include "search_device.h"
 
 #pragma clang fp contract(off)
@@ -113,6 +115,13 @@ __global__ __launch_bounds__(DIRECT_ROWS * WAVE) void kb_search_large_k(const Se
 template <int KS, int NB>
 static void launch_direct_fmt(const SearchArgs& a, bool sigmag, bool records, hipStream_t stream) {
     const dim3 grid(a.n_tiles), block(DIRECT_ROWS * WAVE);
+    {
+        const bool rec = !sigmag && records && KS <= 16;
+        char name[96];
+        std::snprintf(name, sizeof(name), "kb::kb_search_direct<%d, %d, %d, %s, %s>", sigmag ? 8 : KS, CHUNK, NB, sigmag ? "true" : "false",
+                      rec ? "true" : "false");
+        note_kernel_instance(name);
+    }
     if (sigmag) {
         // the emitting instances keep no list: one set (KS = 8) serves every K
         if constexpr (KS == 8) hipLaunchKernelGGL((kb_search_direct<8, CHUNK, NB, true, false>), grid, block, 0, stream, a);
@@ -155,6 +164,7 @@ void launch_search_direct(const SearchArgs& a, int fmt, bool sigmag, bool record
 }
 
 void launch_search_large_k(const SearchArgs& a, bool sigmag, int blocks, hipStream_t stream) {
+    note_kernel_instance(sigmag ? "kb::kb_search_large_k<true>" : "kb::kb_search_large_k<false>");
     if (sigmag) {
         hipLaunchKernelGGL((kb_search_large_k<true>), dim3(blocks), dim3(DIRECT_ROWS * WAVE), 0, stream, a);
     } else {

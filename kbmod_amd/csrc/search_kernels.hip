@@ -431,6 +431,11 @@ __global__ __launch_bounds__(64) void kb_merge_compact_exact_kernel(const kb_com
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+static thread_local char g_kernel_instance[96] = "";
+void note_kernel_instance(const char* name) {
+    std::snprintf(g_kernel_instance, sizeof(g_kernel_instance), "%s", name);
+}
+
 struct Workspace {
     void* ptr = nullptr;
     size_t bytes = 0;
@@ -942,6 +947,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         }
     }
 
+    g_kernel_instance[0] = 0;
     search_timer.begin();
     int variant;
     if (a.K > 32) {
@@ -1004,6 +1010,8 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         stats_out->sigmag_work_items = 0;
         stats_out->sigmag_trajectories = 0;
         stats_out->sigmag_literal = 0;
+        std::snprintf(stats_out->kernel_name, sizeof(stats_out->kernel_name), "%s", g_kernel_instance);
+        stats_out->padded_copy_reused = padded_reused;
         if (cold.sg.totals != nullptr) {
             unsigned long long totals[3] = {0, 0, 0};
             KB_HIP_TRY(hipMemcpyAsync(totals, cold.sg.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));

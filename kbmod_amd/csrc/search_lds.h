@@ -4,6 +4,7 @@
 #ifndef KB_SEARCH_LDS_H_
 #define KB_SEARCH_LDS_H_
 
+#include <cstdio>
 #include <type_traits>
 
 #include "search_device.h"
@@ -613,6 +614,10 @@ static void launch_lds(const SearchArgs& a, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH>), dim3(a.n_tiles), dim3(ROWS * WAVE), lds_bytes,
                        stream, a);
+    char name[96];
+    std::snprintf(name, sizeof(name), "kb::kb_search_lds<%d, %d, %d, %d, %s, %s, %d, %d>", KS, CHUNK, ROWS, NB, CANON ? "true" : "false",
+                  SIGMAG ? "true" : "false", LM, STAGE_DEPTH);
+    note_kernel_instance(name);
 }
 
 }  // namespace kb
