@@ -130,8 +130,10 @@ int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, con
  *                           that does not factor takes the 2-D kernel;
  *   KB_BUILD_EMPTY_IS_ZERO  a valid centre whose PSF footprint holds no valid pixel gives 0.0, as the reference's own
  *                           device builder does (image_kernels.cu:61); default NaN, the reference CPU value
- *                           (image_utils_cpp.cpp:60-61), which the CPU StackSearch and the parity tests assume. */
-enum { KB_BUILD_SEPARABLE = 1, KB_BUILD_EMPTY_IS_ZERO = 2 };
+ *                           (image_utils_cpp.cpp:60-61), which the CPU StackSearch and the parity tests assume.
+ *   KB_BUILD_GENERAL_TILES  (diagnostic) always take the general 32 x 8 tile kernel (mixed kernel sizes, sizes beyond
+ *                           9 x 9) instead of the strip kernel that stacks with one kernel size 3 .. 9 get; same bits. */
+enum { KB_BUILD_SEPARABLE = 1, KB_BUILD_EMPTY_IS_ZERO = 2, KB_BUILD_GENERAL_TILES = 4 };
 int kb_build_psi_phi_from_device_ex(const float* sci_dev, const float* var_dev, const float* psf_host,
                                     const int32_t* psf_dims, int32_t num_times, int32_t height, int32_t width,
                                     int32_t num_bytes, uint32_t build_flags, kb_psi_phi_meta* meta_out,

@@ -54,6 +54,9 @@ def load_lib():
     lib.kb_last_error.restype = C.c_char_p
     lib.kb_build_psi_phi_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                                  C.c_int32, C.c_int32, C.POINTER(Meta), C.POINTER(C.c_void_p), C.c_void_p]
+    lib.kb_build_psi_phi_from_device_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                                    C.c_int32, C.c_int32, C.c_uint32, C.POINTER(Meta), C.POINTER(C.c_void_p),
+                                                    C.c_void_p]
     lib.kb_device_search_filter.argtypes = [C.POINTER(Meta), C.c_void_p, C.c_void_p, Params, C.c_void_p, C.c_uint64,
                                             C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
     lib.kb_device_search_compact.argtypes = [C.POINTER(Meta), C.c_void_p, C.c_void_p, Params, C.c_void_p, C.c_uint64,

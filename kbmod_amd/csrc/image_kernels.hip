@@ -19,6 +19,7 @@
 #include <cmath>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "kb_common.h"
@@ -36,6 +37,7 @@ struct ConvArgs {
     float* out_plain;  // MODE 0: convolved image
     float* out_pairs;  // MODE 1: interleaved [T][H][W][2] float32 (final array or staging)
     const float* psf;      // all kernels, concatenated (MODE 1: followed by their squares)
+    const float* psf_pairs;  // MODE 1: the same kernels as (k, k^2) pairs, [2 * psf_off[t] ...] (the strip kernel's packed weights)
     const int* psf_off;    // [T] offset of kernel t in psf
     const int* psf_dim;    // [T]
     const float* psf_tot;  // [T] sum of kernel t ; MODE 1: [T..2T) sums of the squared kernels
@@ -62,11 +64,9 @@ static inline float key_float(unsigned k) {
     return f;
 }
 
-// psi_phi_array.cpp:223-232: min/max over the finite values of every image, as ordered keys.
-__device__ __forceinline__ void reduce_value_range(unsigned* minmax, bool inside, float psi, float phi) {
-    unsigned kmin0 = 0xffffffffu, kmax0 = 0u, kmin1 = 0xffffffffu, kmax1 = 0u;
-    if (inside && __builtin_isfinite(psi)) kmin0 = kmax0 = float_key(psi);
-    if (inside && __builtin_isfinite(phi)) kmin1 = kmax1 = float_key(phi);
+// psi_phi_array.cpp:223-232: min/max over the finite values of every image, as ordered keys (per-thread extrema in,
+// wave reduction, one atomic per wave and bound that can still move the global value).
+__device__ __forceinline__ void reduce_key_range(unsigned* minmax, unsigned kmin0, unsigned kmax0, unsigned kmin1, unsigned kmax1) {
     for (int o = 32; o > 0; o >>= 1) {
         kmin0 = min(kmin0, (unsigned)__shfl_xor((int)kmin0, o));
         kmax0 = max(kmax0, (unsigned)__shfl_xor((int)kmax0, o));
@@ -87,6 +87,12 @@ __device__ __forceinline__ void reduce_value_range(unsigned* minmax, bool inside
             if (kmax1 > mm[3]) atomicMax(&minmax[3], kmax1);
         }
     }
+}
+__device__ __forceinline__ void reduce_value_range(unsigned* minmax, bool inside, float psi, float phi) {
+    unsigned kmin0 = 0xffffffffu, kmax0 = 0u, kmin1 = 0xffffffffu, kmax1 = 0u;
+    if (inside && __builtin_isfinite(psi)) kmin0 = kmax0 = float_key(psi);
+    if (inside && __builtin_isfinite(phi)) kmin1 = kmax1 = float_key(phi);
+    reduce_key_range(minmax, kmin0, kmax0, kmin1, kmax1);
 }
 
 // One masked correlation at LDS tile position (lx, ly) (tile pitch = pitch).
@@ -232,13 +238,362 @@ __global__ __launch_bounds__(256) void kb_conv_kernel(const ConvArgs a) {
     if (MODE == 1 && a.minmax != nullptr) reduce_value_range(a.minmax, inside, psi, phi);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The psi/phi build proper (all epochs share one kernel size 3 .. 9: the PSFs of a survey's stack): 64 x 32 outputs per
+// 256-thread workgroup, each thread a COLUMN STRIP of eight outputs.
+//  * halo over-fetch (64 + 2r) x (32 + 2r) / (64 x 32) = 1.30 for 7 x 7 kernels, against 2.08 of the 32 x 8 tiles of
+//    kb_conv_kernel (which stays for single images and mixed kernel sizes);
+//  * an input row of the strip is read from LDS once (2r + 1 values) and feeds every output of the strip it is a tap
+//    row of: 12 LDS reads per output and quantity instead of 49; the weights sit in scalar registers for the whole pass;
+//  * each output still receives its products in the reference's order -- kernel rows top to bottom (= input rows in
+//    the order the strip walks them), columns left to right, separate multiply and add (image_utils_cpp.cpp:45-58) --,
+//    so the bits are those of kb_conv_kernel and of the oracle;
+//  * a tile with NO_DATA inside or a halo off the image takes the masked form: every sample read becomes the pair
+//    (value or 0, 1 or 0) once and every tap adds value x weight and mask x weight unconditionally -- a masked tap adds
+//    +-0 to sums that started at +0, which changes no bit, so there is no branch per tap (2 x the arithmetic of a
+//    clean tile instead of a compare-and-skip chain);
+//  * phi0 = (float)(1.0 / (double)var) of the reference is computed as the correctly rounded float quotient 1.0f / var:
+//    the double quotient is correctly rounded to 53 >= 2 x 24 + 2 bits, so rounding it again to 24 bits cannot differ
+//    from rounding the exact quotient once (innocuous double rounding); pinned bit for bit against the oracle's
+//    double division over 24 decades of variances, denormal quotients included (tests/test_gpu_builder_and_api.py).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int STRIP_BX = 64, STRIP_BY = 32, STRIP_OUT = 8;
+
+__device__ __forceinline__ void prepare_pixel(float sci, float var, float* psi0, float* phi0) {
+    // image_utils_cpp.cpp:142-149 and :165-172
+    const bool var_ok = __builtin_isfinite(var) && var != 0.0f;
+    *psi0 = (var_ok && __builtin_isfinite(sci)) ? (sci / var) : NAN;
+    *phi0 = var_ok ? (1.0f / var) : NAN;
+}
+
+// Both quantities of one strip, as pairs: (psi0, phi0) samples x (k, k^2) weights are packed multiplies and adds
+// (v_pk_mul_f32 / v_pk_add_f32 -- a plain VALU instruction occupies the SIMD for a quad-cycle, so the packed form is
+// what halves the arithmetic time; each half is the IEEE operation of the scalar form, there is no FMA).
+// tile: this thread's top-left tap in the staged tile of pairs (pitch pairs per row; NO_DATA is staged as what it is,
+// NaN or an infinity).  MASKED: every sample read becomes (value or 0, 1 or 0) once, for all the outputs it is a tap of.
+typedef float Pair2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) Pair2* ConstWeightPairs;  // (k, k^2) pairs in global memory: scalar loads
+template <int DIM, bool MASKED>
+__device__ __forceinline__ void strip_pass(const Pair2* tile, int pitch,  // (no __restrict__: the row fence below must order the reads)
+                                           ConstWeightPairs k, Pair2 (&acc)[STRIP_OUT], Pair2 (&part)[STRIP_OUT]) {
+#pragma unroll
+    for (int r = 0; r < STRIP_OUT; ++r) {
+        acc[r] = Pair2{0.0f, 0.0f};
+        part[r] = Pair2{0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int yy = 0; yy < STRIP_OUT + DIM - 1; ++yy) {
+        Pair2 v[DIM], m[DIM];
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) {
+            v[i] = tile[yy * pitch + i];
+            if (MASKED) {
+                const bool d0 = __builtin_isfinite(v[i].x), d1 = __builtin_isfinite(v[i].y);
+                m[i] = Pair2{d0 ? 1.0f : 0.0f, d1 ? 1.0f : 0.0f};
+                v[i] = Pair2{d0 ? v[i].x : 0.0f, d1 ? v[i].y : 0.0f};
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < STRIP_OUT; ++r) {
+            const int j = yy - r;  // kernel row of input row yy for output r
+            if (j >= 0 && j < DIM) {
+#pragma unroll
+                for (int i = 0; i < DIM; ++i) {
+                    const Pair2 kk = k[j * DIM + i];  // compile-time index into the constant address space: a scalar register pair
+                    if (MASKED) part[r] += m[i] * kk;
+                    acc[r] += v[i] * kk;
+                }
+            }
+        }
+        // one input row at a time: left alone the compiler issues the LDS reads of every row up front and the strip's
+        // (8 + 2r) x (2r + 1) samples cost the kernel its occupancy
+#pragma unroll
+        for (int r = 0; r < STRIP_OUT; ++r) {
+            asm volatile("" : "+v"(acc[r])::"memory");  // (the sums of this row are due here, in front of the next row's reads)
+            if (MASKED) asm volatile("" : "+v"(part[r]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Tile bookkeeping and staging shared by the two strip kernels: which tile this workgroup owns, and the staged frame of
+// (psi0, phi0) pairs in LDS.  Returns false for the workgroups past the last tile; *clean = the frame lies inside the
+// image and holds no NO_DATA.
+struct StripTile {
+    int t, x0, y0;
+    size_t img;
+};
+template <int DIM>
+struct StripGeometry {
+    static constexpr int R = (DIM - 1) / 2;
+    static_assert(R <= 4, "the staged rows start 4 columns left of the tile (16-byte aligned quads)");
+    static constexpr int APRON = 4;                     // columns staged left and right of the tile
+    static constexpr int PITCH = STRIP_BX + 2 * APRON;  // 72 pairs per staged row
+    static constexpr int ROWS = STRIP_BY + 2 * R;
+    static constexpr int QUADS_PER_ROW = PITCH / 4, N_QUADS = QUADS_PER_ROW * ROWS;
+};
+template <int DIM>
+__device__ __forceinline__ bool stage_strip_tile(const ConvArgs& a, int tiles_x, int tiles_y, int n_tiles, Pair2* tile,
+                                                 StripTile* out, bool* clean_out) {
+    using G = StripGeometry<DIM>;
+    constexpr int R = G::R, APRON = G::APRON, QUADS_PER_ROW = G::QUADS_PER_ROW, N_QUADS = G::N_QUADS;
+
+    // XCD-aware tile order: workgroup b runs on XCD b % 8; every XCD walks a contiguous run of the (epoch, tile row,
+    // tile column) order, so that the halo rows and columns a tile shares with its neighbours are hits in that XCD's L2
+    // (dealt round-robin, neighbouring tiles sit on eight different L2s and every halo line is fetched from the fabric again)
+    const int b = blockIdx.x;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int linear = (b & 7) * per_xcd + (b >> 3);
+    if (linear >= n_tiles) return false;  // whole workgroup
+    const int per_epoch = tiles_x * tiles_y;
+    const int tz = linear / per_epoch, in_epoch = linear - tz * per_epoch;
+    const int tyi = in_epoch / tiles_x, txi = in_epoch - tyi * tiles_x;
+    const int t = tz + a.t0;
+    const int x0 = txi * STRIP_BX, y0 = tyi * STRIP_BY;
+    const size_t img = (size_t)t * a.W * a.H;
+
+    // Staging.  Rows are fetched as 16-byte quads from 4 columns left of the tile on (tile origins are multiples of 64
+    // columns: aligned whenever the image width is a multiple of 4); a quad that straddles the image edge, or any quad
+    // of an image whose rows are not 16-byte aligned, is fetched element by element.  Every load of the thread is issued
+    // before the first quotient (a rolled loop of load -> divide -> store runs one memory latency per element).
+    constexpr int N_STAGE = (N_QUADS + 255) / 256;
+    typedef float Quad4 __attribute__((ext_vector_type(4)));
+    Quad4 s_in[N_STAGE], v_in[N_STAGE];
+    const bool rows_aligned = (a.W & 3) == 0;
+#pragma unroll
+    for (int it = 0; it < N_STAGE; ++it) {
+        const int q = (int)threadIdx.x + 256 * it;
+        const int ly = q / QUADS_PER_ROW, lq = q - ly * QUADS_PER_ROW;
+        const int gx = x0 - APRON + 4 * lq, gy = y0 + ly - R;
+        const bool row_in = q < N_QUADS && gy >= 0 && gy < a.H;
+        const size_t row = img + (size_t)(row_in ? gy : 0) * a.W;
+        Quad4 sv = Quad4{NAN, NAN, NAN, NAN}, vv = sv;
+        if (row_in && rows_aligned && gx >= 0 && gx + 3 < a.W) {
+            sv = *reinterpret_cast<const Quad4*>(a.in0 + row + gx);
+            vv = *reinterpret_cast<const Quad4*>(a.in1 + row + gx);
+        } else if (row_in) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (gx + c >= 0 && gx + c < a.W) {
+                    sv[c] = a.in0[row + gx + c];
+                    vv[c] = a.in1[row + gx + c];
+                }
+            }
+        }
+        s_in[it] = sv;
+        v_in[it] = vv;
+    }
+    bool all_data = true;
+#pragma unroll
+    for (int it = 0; it < N_STAGE; ++it) {
+        const int q = (int)threadIdx.x + 256 * it;
+        if (q < N_QUADS) {
+            Pair2 out[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float p0, p1;
+                prepare_pixel(s_in[it][c], v_in[it][c], &p0, &p1);  // (NaN variance -> NO_DATA: what an off-image tap is)
+                out[c] = Pair2{p0, p1};
+                all_data = all_data && __builtin_isfinite(p0) && __builtin_isfinite(p1);
+            }
+            typedef float Oct8 __attribute__((ext_vector_type(8)));
+            *reinterpret_cast<Oct8*>(tile + 4 * q) = Oct8{out[0].x, out[0].y, out[1].x, out[1].y, out[2].x, out[2].y, out[3].x, out[3].y};
+        }
+    }
+    // (a tile counts as clean only with its whole staged frame in the image and free of NO_DATA: the unused apron
+    // columns beyond the kernel's reach included -- a slightly stricter test than needed, same results)
+    *clean_out = __syncthreads_and(all_data ? 1 : 0) != 0;  // (also the barrier behind the staging)
+    out->t = t;
+    out->x0 = x0;
+    out->y0 = y0;
+    out->img = img;
+    return true;
+}
+
+
+template <int DIM>
+// (second launch bound = waves per SIMD: four 4-wave workgroups per CU, 128 registers a lane)
+__global__ __launch_bounds__(256, 4) void kb_psi_phi_strip_kernel(const ConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using G = StripGeometry<DIM>;
+    constexpr int R = G::R, APRON = G::APRON, PITCH = G::PITCH;
+    Pair2* tile = reinterpret_cast<Pair2*>(smem);  // [ROWS][PITCH] (psi0, phi0)
+    StripTile where;
+    bool clean;
+    if (!stage_strip_tile<DIM>(a, tiles_x, tiles_y, n_tiles, tile, &where, &clean)) return;
+    const int t = where.t, x0 = where.x0, y0 = where.y0;
+    const size_t img = where.img;
+
+    const int tx = threadIdx.x & (STRIP_BX - 1), ty = threadIdx.x / STRIP_BX;
+    const int corner = (ty * STRIP_OUT) * PITCH + tx + (APRON - R);  // the strip's top-left tap
+    const ConstWeightPairs k = (ConstWeightPairs)(uintptr_t)(a.psf_pairs + 2 * (size_t)a.psf_off[t]);
+    const float tot0 = a.psf_tot[t], tot1 = a.psf_tot[a.T + t];
+    const float empty = a.empty_is_nan ? NAN : 0.0f;
+    float psi[STRIP_OUT], phi[STRIP_OUT];
+    Pair2 acc[STRIP_OUT], part[STRIP_OUT];
+    if (clean) {
+        // every tap counts: the weights seen add up, in this very order, to the kernel total (kb_conv_kernel's clean path)
+        strip_pass<DIM, false>(tile + corner, PITCH, k, acc, part);
+#pragma unroll
+        for (int r = 0; r < STRIP_OUT; ++r) {
+            psi[r] = (tot0 == 0.0f) ? empty : (acc[r].x * tot0) / tot0;
+            phi[r] = (tot1 == 0.0f) ? empty : (acc[r].y * tot1) / tot1;
+        }
+    } else {
+        strip_pass<DIM, true>(tile + corner, PITCH, k, acc, part);
+#pragma unroll
+        for (int r = 0; r < STRIP_OUT; ++r) {
+            psi[r] = (part[r].x == 0.0f) ? empty : (acc[r].x * tot0) / part[r].x;
+            phi[r] = (part[r].y == 0.0f) ? empty : (acc[r].y * tot1) / part[r].y;
+        }
+    }
+
+    const int gx = x0 + tx;
+    unsigned kmin0 = 0xffffffffu, kmax0 = 0u, kmin1 = 0xffffffffu, kmax1 = 0u;
+#pragma unroll
+    for (int r = 0; r < STRIP_OUT; ++r) {
+        const int gy = y0 + ty * STRIP_OUT + r;
+        if (gx < a.W && gy < a.H) {
+            if (!clean) {
+                // an invalid centre passes through unchanged (image_utils_cpp.cpp:41-44): NaN, or the infinity it was
+                const Pair2 centre = tile[(ty * STRIP_OUT + r + R) * PITCH + tx + APRON];
+                if (!__builtin_isfinite(centre.x)) psi[r] = centre.x;
+                if (!__builtin_isfinite(centre.y)) phi[r] = centre.y;
+            }
+            reinterpret_cast<float2*>(a.out_pairs)[img + (size_t)gy * a.W + gx] = make_float2(psi[r], phi[r]);
+            if (a.minmax != nullptr) {  // uniform: the value range is only wanted for encoded arrays
+                if (__builtin_isfinite(psi[r])) {
+                    kmin0 = min(kmin0, float_key(psi[r]));
+                    kmax0 = max(kmax0, float_key(psi[r]));
+                }
+                if (__builtin_isfinite(phi[r])) {
+                    kmin1 = min(kmin1, float_key(phi[r]));
+                    kmax1 = max(kmax1, float_key(phi[r]));
+                }
+            }
+        }
+    }
+    if (a.minmax != nullptr) reduce_key_range(a.minmax, kmin0, kmax0, kmin1, kmax1);
+}
+
+// Separable form of the strip kernel (KB_BUILD_SEPARABLE; rank-1 kernels K[j][i] = u[j] * w[i]: every Gaussian PSF,
+// core/psf.py:49-74).  Each thread first reduces an input row of its strip to one pair of row sums (2r + 1 packed
+// multiply-adds, mask sums beside them in a masked tile) and then feeds that pair to every output it is a tap row of:
+// (2r + 1) + (2r + 1) products per output instead of (2r + 1)^2 -- no second LDS pass, no barrier.  The summation order
+// is not the reference's tap loop, so the result agrees with it to rounding (<= 1e-4 relative, same NO_DATA pattern:
+// tests/test_gpu_boundaries.py against the oracle), not bit for bit: opt-in.  sep_pairs: per epoch (u_j, u_j^2)[DIM]
+// then (w_i, w_i^2)[DIM] -- the squared kernel of phi factors as u^2 x w^2 (image_utils_cpp.cpp:110-120).
+template <int DIM, bool MASKED>
+__device__ __forceinline__ void strip_pass_separable(const Pair2* tile, int pitch, ConstWeightPairs u, ConstWeightPairs w,
+                                                     Pair2 (&acc)[STRIP_OUT], Pair2 (&part)[STRIP_OUT]) {
+#pragma unroll
+    for (int r = 0; r < STRIP_OUT; ++r) {
+        acc[r] = Pair2{0.0f, 0.0f};
+        part[r] = Pair2{0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int yy = 0; yy < STRIP_OUT + DIM - 1; ++yy) {
+        Pair2 h = Pair2{0.0f, 0.0f}, hm = Pair2{0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) {
+            Pair2 v = tile[yy * pitch + i];
+            if (MASKED) {
+                const bool d0 = __builtin_isfinite(v.x), d1 = __builtin_isfinite(v.y);
+                hm += Pair2{d0 ? 1.0f : 0.0f, d1 ? 1.0f : 0.0f} * w[i];
+                v = Pair2{d0 ? v.x : 0.0f, d1 ? v.y : 0.0f};
+            }
+            h += v * w[i];
+        }
+#pragma unroll
+        for (int r = 0; r < STRIP_OUT; ++r) {
+            const int j = yy - r;
+            if (j >= 0 && j < DIM) {
+                acc[r] += h * u[j];
+                if (MASKED) part[r] += hm * u[j];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < STRIP_OUT; ++r) {
+            asm volatile("" : "+v"(acc[r])::"memory");
+            if (MASKED) asm volatile("" : "+v"(part[r]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256, 4) void kb_psi_phi_strip_sep_kernel(const ConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using G = StripGeometry<DIM>;
+    constexpr int R = G::R, APRON = G::APRON, PITCH = G::PITCH;
+    Pair2* tile = reinterpret_cast<Pair2*>(smem);
+    StripTile where;
+    bool clean;
+    if (!stage_strip_tile<DIM>(a, tiles_x, tiles_y, n_tiles, tile, &where, &clean)) return;
+    const int t = where.t, x0 = where.x0, y0 = where.y0;
+    const size_t img = where.img;
+
+    const int tx = threadIdx.x & (STRIP_BX - 1), ty = threadIdx.x / STRIP_BX;
+    const int corner = (ty * STRIP_OUT) * PITCH + tx + (APRON - R);
+    const ConstWeightPairs u = (ConstWeightPairs)(uintptr_t)(a.sep + (size_t)t * 4 * DIM);
+    const ConstWeightPairs w = u + DIM;
+    const float tot0 = a.psf_tot[t], tot1 = a.psf_tot[a.T + t];
+    const float empty = a.empty_is_nan ? NAN : 0.0f;
+    float psi[STRIP_OUT], phi[STRIP_OUT];
+    Pair2 acc[STRIP_OUT], part[STRIP_OUT];
+    if (clean) {
+        strip_pass_separable<DIM, false>(tile + corner, PITCH, u, w, acc, part);
+        // the weight every output has seen: the sums the masked form takes with every mask at 1, in its order
+        Pair2 hm = Pair2{0.0f, 0.0f}, seen = Pair2{0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) hm += Pair2{1.0f, 1.0f} * w[i];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) seen += hm * u[j];
+#pragma unroll
+        for (int r = 0; r < STRIP_OUT; ++r) part[r] = seen;
+    } else {
+        strip_pass_separable<DIM, true>(tile + corner, PITCH, u, w, acc, part);
+    }
+#pragma unroll
+    for (int r = 0; r < STRIP_OUT; ++r) {
+        psi[r] = (part[r].x == 0.0f) ? empty : (acc[r].x * tot0) / part[r].x;
+        phi[r] = (part[r].y == 0.0f) ? empty : (acc[r].y * tot1) / part[r].y;
+    }
+    const int gx = x0 + tx;
+    unsigned kmin0 = 0xffffffffu, kmax0 = 0u, kmin1 = 0xffffffffu, kmax1 = 0u;
+#pragma unroll
+    for (int r = 0; r < STRIP_OUT; ++r) {
+        const int gy = y0 + ty * STRIP_OUT + r;
+        if (gx < a.W && gy < a.H) {
+            if (!clean) {  // an invalid centre passes through unchanged (image_utils_cpp.cpp:41-44)
+                const Pair2 centre = tile[(ty * STRIP_OUT + r + R) * PITCH + tx + APRON];
+                if (!__builtin_isfinite(centre.x)) psi[r] = centre.x;
+                if (!__builtin_isfinite(centre.y)) phi[r] = centre.y;
+            }
+            reinterpret_cast<float2*>(a.out_pairs)[img + (size_t)gy * a.W + gx] = make_float2(psi[r], phi[r]);
+            if (a.minmax != nullptr) {
+                if (__builtin_isfinite(psi[r])) {
+                    kmin0 = min(kmin0, float_key(psi[r]));
+                    kmax0 = max(kmax0, float_key(psi[r]));
+                }
+                if (__builtin_isfinite(phi[r])) {
+                    kmin1 = min(kmin1, float_key(phi[r]));
+                    kmax1 = max(kmax1, float_key(phi[r]));
+                }
+            }
+        }
+    }
+    if (a.minmax != nullptr) reduce_key_range(a.minmax, kmin0, kmax0, kmin1, kmax1);
+}
+
 // Separable variant of the MODE 1 build for rank-1 kernels K[j][i] = u[j] * w[i] (every Gaussian PSF,
 // the reference default: core/psf.py:49-74).  The masked correlation (sum over valid taps of v * K) * sum(K)
 // / (sum over valid taps of K) splits into a row pass and a column pass over two planes per quantity,
 // the masked values m * v and the mask m itself: 4 * (2r + 1) multiply-adds per pixel and quantity
 // instead of 2 * (2r + 1)^2.  The summation order differs from the reference's row-major tap loop, so
 // the result agrees to rounding (tested to 1e-4 relative against the reference twin's vectors), not
-// bit for bit: opt-in (KB_BUILD_SEPARABLE), the 2-D kernel stays the default.
+// bit for bit: opt-in (KB_BUILD_SEPARABLE), the 2-D kernel stays the default.  This 32 x 8 tile form serves mixed
+// kernel sizes and sizes beyond 9 x 9; stacks with one kernel size 3 .. 9 take kb_psi_phi_strip_sep_kernel.
 __global__ __launch_bounds__(256) void kb_conv_sep_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = blockIdx.z + a.t0;
@@ -518,12 +873,18 @@ static int build_psi_phi(const float* sci_dev, const float* var_dev, const float
                                       &factors[(size_t)t * 2 * DM + DM]);
         }
     }
+    // one kernel size 3 .. 9 for every epoch (the rule): the strip kernels; else the general 32 x 8 tile kernels
+    int strip_dim = psf_dims[0];
+    for (int t = 1; t < num_times; ++t) {
+        if (psf_dims[t] != strip_dim) strip_dim = 0;
+    }
+    if (strip_dim < 3 || strip_dim > 9 || (build_flags & KB_BUILD_GENERAL_TILES) != 0) strip_dim = 0;
     const int pitch = CONV_BX + 2 * max_radius, rows = CONV_BY + 2 * max_radius;
     const size_t lds = separable ? sizeof(float) * ((size_t)4 * pitch * rows + (size_t)4 * rows * CONV_BX + 4 * DM)
                                  : conv_lds_bytes(max_radius, true);
     if (lds > 160 * 1024) return fail("PSF radius too large for the LDS-tiled convolution.");
 
-    DeviceBuffer d_psf, d_off, d_dim, d_tot, d_stage, d_minmax, d_sep, d_sci, d_var;
+    DeviceBuffer d_psf, d_off, d_dim, d_tot, d_stage, d_minmax, d_sep, d_sci, d_var, d_pairs;
     KB_HIP_TRY(hipMalloc(&d_psf.p, packed.size() * sizeof(float)));
     KB_HIP_TRY(hipMalloc(&d_off.p, offs.size() * sizeof(int)));
     KB_HIP_TRY(hipMalloc(&d_dim.p, (size_t)num_times * sizeof(int)));
@@ -532,6 +893,27 @@ static int build_psi_phi(const float* sci_dev, const float* var_dev, const float
     KB_HIP_TRY(hipMemcpyAsync(d_off.p, offs.data(), offs.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     KB_HIP_TRY(hipMemcpyAsync(d_dim.p, psf_dims, (size_t)num_times * sizeof(int), hipMemcpyHostToDevice, stream));
     KB_HIP_TRY(hipMemcpyAsync(d_tot.p, totals.data(), totals.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    {   // (k, k^2) pairs for the strip kernel's packed multiplies
+        std::vector<float> pairs_host(2 * (size_t)sq_base);
+        for (int e = 0; e < sq_base; ++e) {
+            pairs_host[2 * (size_t)e] = packed[e];
+            pairs_host[2 * (size_t)e + 1] = packed[(size_t)sq_base + e];
+        }
+        KB_HIP_TRY(hipMalloc(&d_pairs.p, pairs_host.size() * sizeof(float)));
+        KB_HIP_TRY(hipMemcpy(d_pairs.p, pairs_host.data(), pairs_host.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (separable && strip_dim != 0) {
+        // the strip kernel's layout: per epoch (u_j, u_j^2)[dim] then (w_i, w_i^2)[dim]  (DM == dim here)
+        std::vector<float> fp((size_t)num_times * 4 * DM);
+        for (int t = 0; t < num_times; ++t) {
+            for (int e = 0; e < 2 * DM; ++e) {
+                const float f = factors[(size_t)t * 2 * DM + e];
+                fp[(size_t)t * 4 * DM + 2 * (size_t)e] = f;
+                fp[(size_t)t * 4 * DM + 2 * (size_t)e + 1] = f * f;
+            }
+        }
+        factors.swap(fp);
+    }
     if (separable) {
         KB_HIP_TRY(hipMalloc(&d_sep.p, factors.size() * sizeof(float)));
         KB_HIP_TRY(hipMemcpyAsync(d_sep.p, factors.data(), factors.size() * sizeof(float), hipMemcpyHostToDevice, stream));
@@ -563,6 +945,7 @@ static int build_psi_phi(const float* sci_dev, const float* var_dev, const float
     a.out_plain = nullptr;
     a.out_pairs = pairs;
     a.psf = reinterpret_cast<const float*>(d_psf.p);
+    a.psf_pairs = reinterpret_cast<const float*>(d_pairs.p);
     a.psf_off = reinterpret_cast<const int*>(d_off.p);
     a.psf_dim = reinterpret_cast<const int*>(d_dim.p);
     a.psf_tot = reinterpret_cast<const float*>(d_tot.p);
@@ -583,9 +966,41 @@ static int build_psi_phi(const float* sci_dev, const float* var_dev, const float
                                                  : reinterpret_cast<const void*>(&kb_conv_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
+    const size_t strip_lds = sizeof(float) * 2 * (size_t)(STRIP_BX + 8) * (STRIP_BY + strip_dim - 1);
+    auto launch_strip = [&](int nt, hipStream_t s, const ConvArgs& c) {
+        const int tiles_x = (width + STRIP_BX - 1) / STRIP_BX, tiles_y = (height + STRIP_BY - 1) / STRIP_BY;
+        const int n_tiles = tiles_x * tiles_y * nt;
+        const dim3 grid((unsigned)(((n_tiles + 7) / 8) * 8));  // (whole rounds of the eight XCDs)
+        auto go = [&](auto dim_tag) {
+            constexpr int D = decltype(dim_tag)::value;
+            if (separable) {
+                hipLaunchKernelGGL(kb_psi_phi_strip_sep_kernel<D>, grid, dim3(256), strip_lds, s, c, tiles_x, tiles_y, n_tiles);
+            } else {
+                hipLaunchKernelGGL(kb_psi_phi_strip_kernel<D>, grid, dim3(256), strip_lds, s, c, tiles_x, tiles_y, n_tiles);
+            }
+        };
+        switch (strip_dim) {
+            case 3:
+                go(std::integral_constant<int, 3>{});
+                break;
+            case 5:
+                go(std::integral_constant<int, 5>{});
+                break;
+            case 7:
+                go(std::integral_constant<int, 7>{});
+                break;
+            default:
+                go(std::integral_constant<int, 9>{});
+                break;
+        }
+    };
     auto launch_epochs = [&](int t0, int nt, hipStream_t s) {
         ConvArgs c = a;
         c.t0 = t0;
+        if (strip_dim != 0) {
+            launch_strip(nt, s, c);
+            return;
+        }
         const dim3 grid((width + CONV_BX - 1) / CONV_BX, (height + CONV_BY - 1) / CONV_BY, nt);
         if (separable) {
             hipLaunchKernelGGL(kb_conv_sep_kernel, grid, dim3(256), lds, s, c);
@@ -789,6 +1204,7 @@ int kb_device_convolve(const float* src_host, float* dst_host, int width, int he
     a.out_plain = reinterpret_cast<float*>(d_dst.p);
     a.out_pairs = nullptr;
     a.psf = reinterpret_cast<const float*>(d_psf.p);
+    a.psf_pairs = nullptr;
     a.psf_off = reinterpret_cast<const int*>(d_meta.p);
     a.psf_dim = reinterpret_cast<const int*>(d_meta.p) + 1;
     a.psf_tot = reinterpret_cast<const float*>(reinterpret_cast<char*>(d_meta.p) + 8);

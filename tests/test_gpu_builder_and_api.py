@@ -47,6 +47,61 @@ def test_device_builder_per_epoch_psfs(kb, orc):
     assert np.array_equal(s.get_psi_phi_array().encoded_array().view(np.uint32), pp.array.view(np.uint32))
 
 
+def _device_build(sci, var, psf, num_bytes, build_flags):
+    """kb_build_psi_phi_from_device_ex on [T][H][W] stacks -> (meta, host copy of the array bytes)."""
+    import ctypes as C
+
+    import torch
+
+    from kbmod_amd import capi
+
+    lib = capi.load_lib()
+    T, H, W = sci.shape
+    d_sci, d_var = torch.from_numpy(sci).cuda(), torch.from_numpy(var).cuda()
+    psf_all = np.ascontiguousarray(np.tile(np.asarray(psf, np.float32).ravel(), T))
+    dims = np.full(T, psf.shape[0], dtype=np.int32)
+    meta, arr = capi.Meta(), C.c_void_p()
+    capi.check(lib.kb_build_psi_phi_from_device_ex(d_sci.data_ptr(), d_var.data_ptr(), psf_all.ctypes.data, dims.ctypes.data, T, H,
+                                                   W, num_bytes, build_flags, C.byref(meta), C.byref(arr),
+                                                   torch.cuda.current_stream().cuda_stream))
+    host = np.empty(int(meta.total_array_size), dtype=np.uint8)
+    capi.check(lib.kb_copy_block_to_cpu(host.ctypes.data, arr, meta.total_array_size))
+    lib.kb_free_gpu_block(arr)
+    return meta, host
+
+
+@pytest.mark.parametrize("sigma", [0.5, 1.0, 1.4])  # 3 x 3, 7 x 7, 9 x 9 kernels: the strip kernel's sizes
+@pytest.mark.parametrize("num_bytes", [-1, 2])
+def test_strip_builder_variances_over_many_decades(orc, sigma, num_bytes):
+    """The strip kernel (64 x 32 tiles, default for one kernel size 3 .. 9) against the oracle AND against the general
+    tile kernel, byte for byte, on a stack whose variances span 24 decades -- denormal reciprocals, overflowing
+    sci / var quotients, negative and zero variances, NaN and infinities included: phi0 = (float)(1.0 / (double)var)
+    of the reference is computed there as the correctly rounded float quotient (innocuous double rounding), and
+    masked taps add +-0 instead of being skipped.  Sizes that are no multiple of the tile, tiles with and without
+    NO_DATA."""
+    rng = np.random.default_rng(int(sigma * 10) + 7)
+    T, H, W = 5, 75, 150  # (clean interior tiles exist: 64 x 32 blocks with their halo inside and unmasked)
+    sci = rng.normal(0, 3, (T, H, W)).astype(np.float32)
+    var = (10.0 ** rng.uniform(-12, 12, (T, H, W))).astype(np.float32)
+    var[0, :40, :140] = 4.0                       # a clean region (plain survey values)
+    var[1] = (10.0 ** rng.uniform(36, 38.5, (H, W))).astype(np.float32)   # reciprocals in the denormal range
+    var[2, 50:, :] = (10.0 ** rng.uniform(-44, -38, (H - 50, W))).astype(np.float32)  # denormal variances: infinite quotients
+    sci[3, 5:9, 70:80] = np.nan
+    sci[3, 60, 100] = np.inf
+    var[3, 20, 20], var[3, 21, 20], var[3, 22, 22] = 0.0, -3.0, np.inf
+    var[4, ::7, ::5] = np.nan
+    psf = fd.make_gaussian_kernel(sigma)
+    times = np.arange(T, dtype=np.float64)
+    pp = orc.PsiPhi.from_images([s for s in sci], [v for v in var], [psf] * T, times, 4 if num_bytes == -1 else num_bytes)
+    meta_s, strip = _device_build(sci, var, psf, num_bytes, 0)
+    meta_g, general = _device_build(sci, var, psf, num_bytes, 4)  # KB_BUILD_GENERAL_TILES
+    assert np.array_equal(strip, general)
+    assert np.array_equal(strip, pp.array.view(np.uint8).ravel())
+    for name in ("psi_min_val", "psi_max_val", "psi_scale", "phi_min_val", "phi_max_val", "phi_scale"):
+        assert np.float32(getattr(meta_s, name)).tobytes() == np.float32(getattr(pp.meta, name)).tobytes(), name
+        assert np.float32(getattr(meta_s, name)).tobytes() == np.float32(getattr(meta_g, name)).tobytes(), name
+
+
 def test_all_nan_stack_is_an_error_when_encoding(kb):
     st = util.make_stack(3, 8, 9, seed=1)
     for im in st.sci:
