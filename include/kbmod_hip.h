@@ -132,8 +132,12 @@ int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, con
  *                           device builder does (image_kernels.cu:61); default NaN, the reference CPU value
  *                           (image_utils_cpp.cpp:60-61), which the CPU StackSearch and the parity tests assume.
  *   KB_BUILD_GENERAL_TILES  (diagnostic) always take the general 32 x 8 tile kernel (mixed kernel sizes, sizes beyond
- *                           9 x 9) instead of the strip kernel that stacks with one kernel size 3 .. 9 get; same bits. */
-enum { KB_BUILD_SEPARABLE = 1, KB_BUILD_EMPTY_IS_ZERO = 2, KB_BUILD_GENERAL_TILES = 4 };
+ *                           9 x 9) instead of the strip kernel that stacks with one kernel size 3 .. 9 get; same bits.
+ *   KB_BUILD_REGISTER_HOST  (kb_build_psi_phi_from_host_stack) page-lock the caller's stacks for the duration of the
+ *                           build (hipHostRegister) so that every chunk is one DMA out of the caller's memory; stacks
+ *                           that already are page-locked (pinned allocations) are sent that way without the flag,
+ *                           pageable ones otherwise go through two internal pinned buffers. */
+enum { KB_BUILD_SEPARABLE = 1, KB_BUILD_EMPTY_IS_ZERO = 2, KB_BUILD_GENERAL_TILES = 4, KB_BUILD_REGISTER_HOST = 8 };
 int kb_build_psi_phi_from_device_ex(const float* sci_dev, const float* var_dev, const float* psf_host,
                                     const int32_t* psf_dims, int32_t num_times, int32_t height, int32_t width,
                                     int32_t num_bytes, uint32_t build_flags, kb_psi_phi_meta* meta_out,

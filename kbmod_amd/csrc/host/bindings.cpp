@@ -423,7 +423,7 @@ PYBIND11_MODULE(search, m) {
                     [](py::array_t<float, py::array::c_style | py::array::forcecast> sci,
                        py::array_t<float, py::array::c_style | py::array::forcecast> var,
                        const std::vector<conv_array>& psfs, std::vector<double> times, int num_bytes, bool separable_psf,
-                       bool empty_footprint_is_zero) {
+                       bool empty_footprint_is_zero, bool register_host_memory) {
                         if (sci.ndim() != 3 || var.ndim() != 3) {
                             throw std::runtime_error("from_image_stacks expects [T][H][W] arrays");
                         }
@@ -434,13 +434,15 @@ PYBIND11_MODULE(search, m) {
                         }
                         std::vector<Image> p = to_images(psfs);
                         const uint32_t flags = (separable_psf ? (uint32_t)KB_BUILD_SEPARABLE : 0u) |
-                                               (empty_footprint_is_zero ? (uint32_t)KB_BUILD_EMPTY_IS_ZERO : 0u);
+                                               (empty_footprint_is_zero ? (uint32_t)KB_BUILD_EMPTY_IS_ZERO : 0u) |
+                                               (register_host_memory ? (uint32_t)KB_BUILD_REGISTER_HOST : 0u);
                         return std::unique_ptr<StackSearch>(new StackSearch(sci.data(), var.data(), (unsigned)sci.shape(0),
                                                                             (unsigned)sci.shape(1), (unsigned)sci.shape(2), p,
                                                                             times, num_bytes, flags));
                     },
                     py::arg("sci_stack"), py::arg("var_stack"), py::arg("psf_kernels"), py::arg("zeroed_times"),
-                    py::arg("num_bytes") = -1, py::arg("separable_psf") = false, py::arg("empty_footprint_is_zero") = false)
+                    py::arg("num_bytes") = -1, py::arg("separable_psf") = false, py::arg("empty_footprint_is_zero") = false,
+                    py::arg("register_host_memory") = true)
             .def("set_search_devices", &StackSearch::set_search_devices)
             .def("get_search_devices", &StackSearch::get_search_devices)
             .def_property_readonly("num_images", &StackSearch::num_images)

@@ -1013,12 +1013,44 @@ static int build_psi_phi(const float* sci_dev, const float* var_dev, const float
         launch_epochs(0, num_times, stream);
         KB_HIP_TRY(hipGetLastError());
     } else {
-        // chunks of whole epochs, at most ~16 MiB per stack and chunk; chunk c is copied into the pinned
-        // buffer c % 2 by this thread, sent by the copy engine, and correlated behind its arrival
+        // chunks of whole epochs, at most ~16 MiB per stack and chunk.  Where the caller's stacks are page-locked
+        // -- allocated pinned (hipHostMalloc, a torch pinned tensor) or registered, which KB_BUILD_REGISTER_HOST does
+        // here for the duration of the build -- every chunk is ONE DMA out of the caller's memory; otherwise chunk c is
+        // copied into the pinned buffer c % 2 by this thread, sent by the copy engine, and correlated behind its arrival.
         std::lock_guard<std::mutex> lock(g_stage_mutex);
         const int chunk_epochs = (int)std::max<size_t>(1, std::min<size_t>((size_t)num_times, (16u << 20) / (img * sizeof(float))));
         const size_t chunk_bytes = (size_t)chunk_epochs * img * sizeof(float);
-        if (g_stage.bytes < 2 * chunk_bytes) {
+        auto page_locked = [](const void* p) {
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+                (void)hipGetLastError();  // plain pageable memory is reported as an error
+                return false;
+            }
+            return attr.type == hipMemoryTypeHost;
+        };
+        bool direct = page_locked(sci_host) && page_locked(var_host);
+        bool registered_here[2] = {false, false};
+        if (!direct && (build_flags & KB_BUILD_REGISTER_HOST) != 0) {
+            const size_t whole = n_pix * sizeof(float);
+            registered_here[0] = hipHostRegister(const_cast<float*>(sci_host), whole, hipHostRegisterDefault) == hipSuccess;
+            registered_here[1] = registered_here[0] &&
+                                 hipHostRegister(const_cast<float*>(var_host), whole, hipHostRegisterDefault) == hipSuccess;
+            direct = registered_here[0] && registered_here[1];
+            if (!direct) {  // (could not be locked: the staged path still works)
+                (void)hipGetLastError();
+                if (registered_here[0]) (void)hipHostUnregister(const_cast<float*>(sci_host));
+                registered_here[0] = registered_here[1] = false;
+            }
+        }
+        struct Unregister {
+            const float *a, *b;
+            bool* on;
+            ~Unregister() {
+                if (on[0]) (void)hipHostUnregister(const_cast<float*>(a));
+                if (on[1]) (void)hipHostUnregister(const_cast<float*>(b));
+            }
+        } unregister{sci_host, var_host, registered_here};
+        if (!direct && g_stage.bytes < 2 * chunk_bytes) {
             for (void*& p : g_stage.p) {
                 if (p != nullptr) (void)hipHostFree(p);
                 p = nullptr;
@@ -1041,14 +1073,20 @@ static int build_psi_phi(const float* sci_dev, const float* var_dev, const float
             const int nt = std::min(chunk_epochs, num_times - t0);
             const size_t nb = (size_t)nt * img * sizeof(float);
             const int b = c & 1;
-            if (c >= 2 && hipEventSynchronize(consumed[b]) != hipSuccess) rc = 1;  // the copy two chunks ago has left the buffer
-            char* host_buf = reinterpret_cast<char*>(g_stage.p[b]);
-            std::memcpy(host_buf, sci_host + (size_t)t0 * img, nb);
-            std::memcpy(host_buf + chunk_bytes, var_host + (size_t)t0 * img, nb);
-            if (hipMemcpyAsync(reinterpret_cast<float*>(d_sci.p) + (size_t)t0 * img, host_buf, nb, hipMemcpyHostToDevice,
+            const char *src_sci = reinterpret_cast<const char*>(sci_host + (size_t)t0 * img),
+                       *src_var = reinterpret_cast<const char*>(var_host + (size_t)t0 * img);
+            if (!direct) {
+                if (c >= 2 && hipEventSynchronize(consumed[b]) != hipSuccess) rc = 1;  // the copy two chunks ago has left the buffer
+                char* host_buf = reinterpret_cast<char*>(g_stage.p[b]);
+                std::memcpy(host_buf, src_sci, nb);
+                std::memcpy(host_buf + chunk_bytes, src_var, nb);
+                src_sci = host_buf;
+                src_var = host_buf + chunk_bytes;
+            }
+            if (hipMemcpyAsync(reinterpret_cast<float*>(d_sci.p) + (size_t)t0 * img, src_sci, nb, hipMemcpyHostToDevice,
                                copy_stream) != hipSuccess ||
-                hipMemcpyAsync(reinterpret_cast<float*>(d_var.p) + (size_t)t0 * img, host_buf + chunk_bytes, nb,
-                               hipMemcpyHostToDevice, copy_stream) != hipSuccess) {
+                hipMemcpyAsync(reinterpret_cast<float*>(d_var.p) + (size_t)t0 * img, src_var, nb, hipMemcpyHostToDevice,
+                               copy_stream) != hipSuccess) {
                 rc = 1;
                 break;
             }

@@ -48,6 +48,26 @@ def test_stack_constructor_builds_the_same_array(kb, stack, num_bytes):
     assert np.array_equal(np.asarray(ca), np.asarray(cb))
 
 
+def test_page_locked_ingest_paths_build_the_same_array(kb, stack):
+    """One DMA per chunk out of the caller's memory -- registered for the build, or already pinned -- gives the bytes of
+    the staged upload."""
+    import torch
+
+    sci, var = np.stack(stack.sci), np.stack(stack.var)
+    probe = [kb.Trajectory(x=int(x), y=int(y), vx=0.0, vy=0.0) for y in range(0, 150, 7) for x in range(0, 210, 5)]
+    ref = np.asarray(kb.StackSearch.from_image_stacks(sci, var, stack.psfs, stack.zeroed_times, register_host_memory=False)
+                     .get_all_psi_phi_curves(probe))
+    reg = kb.StackSearch.from_image_stacks(sci, var, stack.psfs, stack.zeroed_times, register_host_memory=True)
+    assert np.array_equal(np.asarray(reg.get_all_psi_phi_curves(probe)), ref)
+    sci_pin, var_pin = torch.from_numpy(sci).pin_memory(), torch.from_numpy(var).pin_memory()
+    pin = kb.StackSearch.from_image_stacks(sci_pin.numpy(), var_pin.numpy(), stack.psfs, stack.zeroed_times, 2)
+    enc = kb.StackSearch.from_image_stacks(sci, var, stack.psfs, stack.zeroed_times, 2)
+    assert np.array_equal(np.asarray(pin.get_all_psi_phi_curves(probe)), np.asarray(enc.get_all_psi_phi_curves(probe)))
+    # registering twice in a row works (the build unregisters what it registered)
+    again = kb.StackSearch.from_image_stacks(sci, var, stack.psfs, stack.zeroed_times, register_host_memory=True)
+    assert np.array_equal(np.asarray(again.get_all_psi_phi_curves(probe)), ref)
+
+
 def test_large_stack_constructor_chunks(kb):
     # several upload chunks (16 MiB each): 40 epochs of 512 x 512
     rng = np.random.default_rng(5)
