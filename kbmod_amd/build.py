@@ -73,6 +73,8 @@ def build_hip(force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
             return obj, True
+        if verbose:
+            print("kept (up to date):", os.path.relpath(obj, _ROOT))
         return obj, False
 
     with ThreadPoolExecutor(max_workers=6) as pool:
@@ -94,6 +96,8 @@ def build_host(force=False, verbose=False):
     deps = srcs + [os.path.join(_CSRC, h) for h in HOST_HEADERS] + [os.path.join(_INC, "kbmod_hip.h"), hip_lib_path()]
     out = host_module_path()
     if not force and not _stale(out, deps):
+        if verbose:
+            print("kept (up to date):", os.path.relpath(out, _ROOT))
         return out
     cmd = [
         "g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-fvisibility=hidden",

@@ -99,11 +99,17 @@ PYBIND11_MODULE(search, m) {
             .def_readwrite("x", &Trajectory::x)
             .def_readwrite("y", &Trajectory::y)
             .def_readwrite("obs_count", &Trajectory::obs_count)
-            .def("get_x_pos", &Trajectory::get_x_pos, py::arg("time"), py::arg("centered") = true)
-            .def("get_y_pos", &Trajectory::get_y_pos, py::arg("time"), py::arg("centered") = true)
-            .def("get_x_index", &Trajectory::get_x_index)
-            .def("get_y_index", &Trajectory::get_y_index)
-            .def("is_valid", &Trajectory::is_valid)
+            .def("get_x_pos", &Trajectory::get_x_pos, py::arg("time"), py::arg("centered") = true,
+                 "Predicted x position at `time` (days since the first epoch): x + vx * time, plus 0.5 when `centered` "
+                 "(pixel centres).")
+            .def("get_y_pos", &Trajectory::get_y_pos, py::arg("time"), py::arg("centered") = true,
+                 "Predicted y position at `time`: y + vy * time, plus 0.5 when `centered`.")
+            .def("get_x_index", &Trajectory::get_x_index,
+                 "Pixel column the trajectory is in at `time`: floor of the centred x position.")
+            .def("get_y_index", &Trajectory::get_y_index,
+                 "Pixel row the trajectory is in at `time`: floor of the centred y position.")
+            .def("is_valid", &Trajectory::is_valid,
+                 "True when vx, vy, lh and flux are finite and obs_count is not negative.")
             .def("clear", &Trajectory::clear)
             .def("__repr__", [](const Trajectory& t) { return "Trajectory(" + t.to_string() + ")"; })
             .def("__str__", &Trajectory::to_string)
@@ -196,13 +202,23 @@ PYBIND11_MODULE(search, m) {
             .def_property_readonly("cpu_array_allocated", &PsiPhiArray::cpu_array_allocated)
             .def_property_readonly("gpu_array_allocated", &PsiPhiArray::gpu_array_allocated)
             .def_property_readonly("device_resident", &PsiPhiArray::device_resident)
-            .def("set_meta_data", &PsiPhiArray::set_meta_data)
-            .def("set_time_array", &PsiPhiArray::set_time_array)
-            .def("move_to_gpu", &PsiPhiArray::move_to_gpu)
+            .def("set_meta_data", &PsiPhiArray::set_meta_data,
+                 "Set the encoding width (1, 2 or 4 bytes per value; -1 means 4), the number of epochs and the image "
+                 "size, and derive the array sizes from them.  Clears any existing data.")
+            .def("set_time_array", &PsiPhiArray::set_time_array,
+                 "Copy the epoch times (one per image, zero-shifted days) into the array object; their number must "
+                 "equal num_times.")
+            .def("move_to_gpu", &PsiPhiArray::move_to_gpu,
+                 "Make the data resident on the device (allocates and uploads what is not there yet); raises "
+                 "RuntimeError without a GPU or when already there.")
             .def("clear", &PsiPhiArray::clear)
-            .def("clear_from_gpu", &PsiPhiArray::clear_from_gpu)
-            .def("read_psi_phi", &PsiPhiArray::read_psi_phi)
-            .def("read_time", &PsiPhiArray::read_time)
+            .def("clear_from_gpu", &PsiPhiArray::clear_from_gpu,
+                 "Release the device copy (and keep the host copy).")
+            .def("read_psi_phi", &PsiPhiArray::read_psi_phi,
+                 "(psi, phi) at epoch `time`, pixel (`row`, `col`), decoded to float; NaN for both when the position "
+                 "is outside the image or the value is NO_DATA.")
+            .def("read_time", &PsiPhiArray::read_time,
+                 "The zero-shifted time of epoch `time_index`; raises for an index out of range.")
             // Raw encoded array as a flat numpy vector (parity tests compare it bit for bit).
             .def("encoded_array", [](PsiPhiArray& a) -> py::array {
                 const void* p = a.host_ptr();
@@ -219,16 +235,25 @@ PYBIND11_MODULE(search, m) {
                 py::array_t<float> out(n);
                 std::memcpy(out.mutable_data(), p, (size_t)n * 4);
                 return out;
-            });
+            },
+                 "The array as stored ([T][H][W][psi, phi] of uint8 / uint16 / float32), copied to the host if it "
+                 "lives in HBM.");
     m.def("compute_scale_params_from_image_vect", [](const std::vector<conv_array>& imgs, int num_bytes) {
         return compute_scale_params_from_image_vect(to_images(imgs), num_bytes);
-    });
-    m.def("decode_uint_scalar", &decode_uint_scalar);
-    m.def("encode_uint_scalar", &encode_uint_scalar);
+    },
+                 "[min, max, scale] for encoding a list of images with `num_bytes` bytes per value: min / max over all "
+                 "finite pixels, scale = max(max - min, 1e-6) / (2^(8 num_bytes) - 1).");
+    m.def("decode_uint_scalar", &decode_uint_scalar,
+                 "Float value of an encoded sample: NaN for code 0, else (code - 1) * scale + min_val.");
+    m.def("encode_uint_scalar", &encode_uint_scalar,
+                 "Code of a float value: 0 for non-finite input, else the value clamped to [min_val, max_val] shifted "
+                 "to start at 1 (fractional; the array stores its truncation).");
     m.def("fill_psi_phi_array", [](PsiPhiArray& result_data, int num_bytes, const std::vector<conv_array>& psi_imgs,
                                    const std::vector<conv_array>& phi_imgs, const std::vector<double> zeroed_times) {
         fill_psi_phi_array(result_data, num_bytes, to_images(psi_imgs), to_images(phi_imgs), zeroed_times);
-    });
+    },
+                 "Fill `result_data` from per-epoch psi and phi images and their zero-shifted times, encoding with "
+                 "`num_bytes` bytes per value (scale parameters taken over all images).  The data stays on the host.");
     m.def(
             "fill_psi_phi_array_from_image_arrays",
             [](PsiPhiArray& result_data, int num_bytes, const std::vector<conv_array>& sci,
@@ -238,7 +263,9 @@ PYBIND11_MODULE(search, m) {
                 fill_psi_phi_array_from_image_arrays(result_data, num_bytes, s, v, p, times, force_cpu);
             },
             py::arg("result_data"), py::arg("num_bytes"), py::arg("sci_imgs"), py::arg("var_imgs"),
-            py::arg("psf_kernels"), py::arg("zeroed_times"), py::arg("force_cpu") = false);
+            py::arg("psf_kernels"), py::arg("zeroed_times"), py::arg("force_cpu") = false,
+                 "Build psi and phi from science / variance images and PSF kernels (generate_psi / generate_phi per "
+                 "epoch) and fill `result_data` from them.");
 
     // ---- debug_timer.cpp:57-69 ----
     py::class_<DebugTimer>(m, "DebugTimer")
@@ -258,22 +285,40 @@ PYBIND11_MODULE(search, m) {
             .def(py::init<std::vector<Trajectory>&>())
             .def_property_readonly("on_gpu", &TrajectoryList::on_gpu)
             .def("__len__", &TrajectoryList::get_size)
-            .def("resize", &TrajectoryList::resize)
-            .def("get_size", &TrajectoryList::get_size)
-            .def("get_memory", &TrajectoryList::get_memory)
-            .def_static("estimate_memory", &TrajectoryList::estimate_memory)
-            .def("get_trajectory", &TrajectoryList::get_trajectory, py::return_value_policy::reference_internal)
-            .def("reset_all", &TrajectoryList::reset_all)
-            .def("set_trajectory", &TrajectoryList::set_trajectory)
-            .def("set_trajectories", &TrajectoryList::set_trajectories)
-            .def("get_list", &TrajectoryList::get_list)
-            .def("get_batch", &TrajectoryList::get_batch)
-            .def("sort_by_likelihood", &TrajectoryList::sort_by_likelihood)
-            .def("filter_by_likelihood", &TrajectoryList::filter_by_likelihood)
-            .def("filter_by_obs_count", &TrajectoryList::filter_by_obs_count)
-            .def("assert_valid", &TrajectoryList::assert_valid)
-            .def("move_to_cpu", &TrajectoryList::move_to_cpu)
-            .def("move_to_gpu", &TrajectoryList::move_to_gpu)
+            .def("resize", &TrajectoryList::resize,
+                 "Change the number of entries; new entries are zeroed trajectories.  Host data only.")
+            .def("get_size", &TrajectoryList::get_size,
+                 "Number of trajectories in the list.")
+            .def("get_memory", &TrajectoryList::get_memory,
+                 "Bytes the list occupies (28 per trajectory).")
+            .def_static("estimate_memory", &TrajectoryList::estimate_memory,
+                 "Bytes a list of `num_elements` trajectories would occupy.")
+            .def("get_trajectory", &TrajectoryList::get_trajectory, py::return_value_policy::reference_internal,
+                 "Reference to entry `index` (changes made through it are seen by the list); raises for an index out "
+                 "of range or data on the device.")
+            .def("reset_all", &TrajectoryList::reset_all,
+                 "Zero every entry.")
+            .def("set_trajectory", &TrajectoryList::set_trajectory,
+                 "Overwrite entry `index` with a copy of `new_value`.")
+            .def("set_trajectories", &TrajectoryList::set_trajectories,
+                 "Replace the whole list by copies of the given trajectories.")
+            .def("get_list", &TrajectoryList::get_list,
+                 "The trajectories as a Python list (copies).")
+            .def("get_batch", &TrajectoryList::get_batch,
+                 "Copies of `count` entries starting at `start` (fewer at the end of the list).")
+            .def("sort_by_likelihood", &TrajectoryList::sort_by_likelihood,
+                 "Sort in place by likelihood, highest first.")
+            .def("filter_by_likelihood", &TrajectoryList::filter_by_likelihood,
+                 "Drop entries whose likelihood is below `min_likelihood`; the survivors end up sorted by likelihood.")
+            .def("filter_by_obs_count", &TrajectoryList::filter_by_obs_count,
+                 "Drop entries with fewer than `min_obs_count` observations.")
+            .def("assert_valid", &TrajectoryList::assert_valid,
+                 "Raise RuntimeError at the first entry that is not valid (see Trajectory.is_valid).")
+            .def("move_to_cpu", &TrajectoryList::move_to_cpu,
+                 "Bring the data back from the device and release the device buffer.")
+            .def("move_to_gpu", &TrajectoryList::move_to_gpu,
+                 "Make the data resident on the device (allocates and uploads what is not there yet); raises "
+                 "RuntimeError without a GPU or when already there.")
             // Bulk transfer as an (N, 7) float64 table [x, y, vx, vy, lh, flux, obs_count].
             .def("to_numpy", [](TrajectoryList& l) {
                 const std::vector<Trajectory>& v = l.get_list();
@@ -290,13 +335,20 @@ PYBIND11_MODULE(search, m) {
                 }
                 return out;
             });
-    m.def("extract_all_trajectory_x", &extract_all_trajectory_x);
-    m.def("extract_all_trajectory_y", &extract_all_trajectory_y);
-    m.def("extract_all_trajectory_vx", &extract_all_trajectory_vx);
-    m.def("extract_all_trajectory_vy", &extract_all_trajectory_vy);
-    m.def("extract_all_trajectory_lh", &extract_all_trajectory_lh);
-    m.def("extract_all_trajectory_flux", &extract_all_trajectory_flux);
-    m.def("extract_all_trajectory_obs_count", &extract_all_trajectory_obs_count);
+    m.def("extract_all_trajectory_x", &extract_all_trajectory_x,
+                 "x of every trajectory of a list, in order.");
+    m.def("extract_all_trajectory_y", &extract_all_trajectory_y,
+                 "y of every trajectory of a list, in order.");
+    m.def("extract_all_trajectory_vx", &extract_all_trajectory_vx,
+                 "vx of every trajectory of a list, in order.");
+    m.def("extract_all_trajectory_vy", &extract_all_trajectory_vy,
+                 "vy of every trajectory of a list, in order.");
+    m.def("extract_all_trajectory_lh", &extract_all_trajectory_lh,
+                 "Likelihood of every trajectory of a list, in order.");
+    m.def("extract_all_trajectory_flux", &extract_all_trajectory_flux,
+                 "Flux of every trajectory of a list, in order.");
+    m.def("extract_all_trajectory_obs_count", &extract_all_trajectory_obs_count,
+                 "Observation count of every trajectory of a list, in order.");
 
     m.def("merge_topk_host", [](py::array_t<uint8_t, py::array::c_style> raw, int n_lists, uint64_t n_pixels, int K) {
         if ((uint64_t)raw.size() != (uint64_t)n_lists * n_pixels * K * sizeof(Trajectory)) {
@@ -405,8 +457,14 @@ PYBIND11_MODULE(search, m) {
             py::arg("coeff") = 0.7413f, py::arg("clip_negative") = false);
 
     // ---- cpu_search_algorithms.cpp:128-131 ----
-    m.def("evaluate_trajectory_cpu", &evaluate_trajectory_cpu);
-    m.def("search_cpu_only", &search_cpu_only);
+    m.def("evaluate_trajectory_cpu", &evaluate_trajectory_cpu,
+                 "Fill lh, flux and obs_count of `candidate` from the host copy of `psi_phi`: psi and phi are summed "
+                 "in epoch order over the pixels floor(x + vx t + 0.5), floor(y + vy t + 0.5) that hold data; lh = "
+                 "psi_sum / sqrt(phi_sum), flux = psi_sum / phi_sum, both -1 when phi_sum <= 0.");
+    m.def("search_cpu_only", &search_cpu_only,
+                 "The host search: for every start pixel inside the bounds of `params`, evaluate all `candidates` (no "
+                 "sigma-G clip) and keep the `results_per_pixel` most likely in `results` (slot layout ((y - y_min) * "
+                 "width + (x - x_min)) * K + rank).");
 
     // ---- stack_search.cpp:341-389 ----
     py::class_<StackSearch>(m, "StackSearch")
@@ -443,39 +501,86 @@ PYBIND11_MODULE(search, m) {
                     py::arg("sci_stack"), py::arg("var_stack"), py::arg("psf_kernels"), py::arg("zeroed_times"),
                     py::arg("num_bytes") = -1, py::arg("separable_psf") = false, py::arg("empty_footprint_is_zero") = false,
                     py::arg("register_host_memory") = true)
-            .def("set_search_devices", &StackSearch::set_search_devices)
-            .def("get_search_devices", &StackSearch::get_search_devices)
+            .def("set_search_devices", &StackSearch::set_search_devices,
+                 "Devices the GPU search fans out over: the candidate list is cut into contiguous slices, one host "
+                 "thread per slice on its device, per-pixel lists merged on the current device.  For up to 16 results "
+                 "per pixel the merge reproduces the single-device result exactly, ties included (2 K stable lists + "
+                 "replay of the reference's insertion); for 17 .. 32 equal likelihoods go to the lower candidate index "
+                 "(logged); above 32 the search stays on one device (logged).  Entries may repeat.")
+            .def("get_search_devices", &StackSearch::get_search_devices,
+                 "The device list set by set_search_devices (empty: the current device alone).")
             .def_property_readonly("num_images", &StackSearch::num_images)
             .def_property_readonly("height", &StackSearch::get_image_height)
             .def_property_readonly("width", &StackSearch::get_image_width)
             .def_property_readonly("zeroed_times", &StackSearch::get_zeroed_times)
-            .def("search_all", &StackSearch::search_all)
-            .def("evaluate_single_trajectory", &StackSearch::evaluate_single_trajectory)
-            .def("search_linear_trajectory", &StackSearch::search_linear_trajectory)
-            .def("set_min_obs", &StackSearch::set_min_obs)
-            .def("set_min_lh", &StackSearch::set_min_lh)
-            .def("set_results_per_pixel", &StackSearch::set_results_per_pixel)
-            .def("disable_gpu_sigmag_filter", &StackSearch::disable_gpu_sigmag_filter)
-            .def("enable_gpu_sigmag_filter", &StackSearch::enable_gpu_sigmag_filter)
-            .def("set_start_bounds_x", &StackSearch::set_start_bounds_x)
-            .def("set_start_bounds_y", &StackSearch::set_start_bounds_y)
-            .def("get_num_images", &StackSearch::num_images)
-            .def("get_image_width", &StackSearch::get_image_width)
-            .def("get_image_height", &StackSearch::get_image_height)
+            .def("search_all", &StackSearch::search_all,
+                 "Search every start pixel inside the current bounds for every trajectory of `search_list` (x, y are "
+                 "ignored, vx, vy used) and keep the `results_per_pixel` best per pixel; then drop results below "
+                 "min_lh / min_obs and sort all by likelihood, highest first.  on_gpu=True runs the HIP kernels "
+                 "(per-pixel lists built in candidate order by strict-greater insertion, in-search sigma-G clip when "
+                 "enabled; raises RuntimeError without a GPU), False the host search (no sigma-G).  Results are read "
+                 "with get_results().")
+            .def("evaluate_single_trajectory", &StackSearch::evaluate_single_trajectory,
+                 "Fill lh, flux and obs_count of `trj` IN PLACE from its x, y, vx, vy.  use_kernel=False: the host "
+                 "evaluator (no sigma-G); True: the host instantiation of the device evaluator, sigma-G clip and "
+                 "thresholds included (needs a GPU, as in the reference).")
+            .def("search_linear_trajectory", &StackSearch::search_linear_trajectory,
+                 "A new Trajectory at (x, y, vx, vy) evaluated as evaluate_single_trajectory does.")
+            .def("set_min_obs", &StackSearch::set_min_obs,
+                 "Per-pixel lists only take trajectories with at least this many valid observations; 0 .. number of "
+                 "images.")
+            .def("set_min_lh", &StackSearch::set_min_lh,
+                 "Results with a likelihood below this are dropped after the search (and, with the sigma-G filter on, "
+                 "before they enter a per-pixel list).")
+            .def("set_results_per_pixel", &StackSearch::set_results_per_pixel,
+                 "How many results each start pixel keeps (K > 0; default 8).")
+            .def("disable_gpu_sigmag_filter", &StackSearch::disable_gpu_sigmag_filter,
+                 "Turn the in-search sigma-G clip off.")
+            .def("enable_gpu_sigmag_filter", &StackSearch::enable_gpu_sigmag_filter,
+                 "Turn the in-search sigma-G clip on: `percentiles` = two quantiles in (0, 1), low < high, of the "
+                 "per-epoch psi / phi ratios; `sigmag_coeff` > 0 converts their spread into a standard deviation "
+                 "(0.7413 for [0.25, 0.75]); samples further than two of those from the median are left out of the "
+                 "sums.  `min_lh` is the likelihood a trajectory must keep after the clip.")
+            .def("set_start_bounds_x", &StackSearch::set_start_bounds_x,
+                 "Start pixels cover x in [x_min, x_max) (may extend beyond the image); x_min < x_max.")
+            .def("set_start_bounds_y", &StackSearch::set_start_bounds_y,
+                 "Start pixels cover y in [y_min, y_max); y_min < y_max.")
+            .def("get_num_images", &StackSearch::num_images,
+                 "Number of epochs.")
+            .def("get_image_width", &StackSearch::get_image_width,
+                 "Image width in pixels.")
+            .def("get_image_height", &StackSearch::get_image_height,
+                 "Image height in pixels.")
             .def("get_all_psi_phi_curves",
-                 [](StackSearch& s, const std::vector<Trajectory>& t) { return from_image(s.get_all_psi_phi_curves(t)); })
-            .def("preload_psi_phi_array", &StackSearch::preload_psi_phi_array)
-            .def("unload_psi_phi_array", &StackSearch::unload_psi_phi_array)
-            .def("psi_phi_array_on_gpu", &StackSearch::psi_phi_array_on_gpu)
-            .def("get_number_total_results", &StackSearch::get_number_total_results)
-            .def("get_results", &StackSearch::get_results)
-            .def("get_all_results", &StackSearch::get_all_results)
-            .def("set_results", &StackSearch::set_results)
-            .def("clear_results", &StackSearch::clear_results)
-            .def("compute_max_results", &StackSearch::compute_max_results)
+                 [](StackSearch& s, const std::vector<Trajectory>& t) { return from_image(s.get_all_psi_phi_curves(t)); },
+                 "For every trajectory the psi values at its T predicted pixels followed by the T phi values (N x 2T "
+                 "float32; 0 where there is no data).  Runs on the device when the array is resident there.")
+            .def("preload_psi_phi_array", &StackSearch::preload_psi_phi_array,
+                 "Keep the psi/phi array resident in HBM across searches (search_all otherwise releases its logical "
+                 "hold after each search).")
+            .def("unload_psi_phi_array", &StackSearch::unload_psi_phi_array,
+                 "End the residency started by preload_psi_phi_array.")
+            .def("psi_phi_array_on_gpu", &StackSearch::psi_phi_array_on_gpu,
+                 "Whether the array is marked resident on the device.")
+            .def("get_number_total_results", &StackSearch::get_number_total_results,
+                 "Number of results the last search kept.")
+            .def("get_results", &StackSearch::get_results,
+                 "Copies of `count` results starting at `start`, most likely first; raises for a negative start or "
+                 "count.")
+            .def("get_all_results", &StackSearch::get_all_results,
+                 "All results of the last search as a list (copies).")
+            .def("set_results", &StackSearch::set_results,
+                 "Replace the stored results (used by tests and by callers that post-filter).")
+            .def("clear_results", &StackSearch::clear_results,
+                 "Forget the stored results.")
+            .def("compute_max_results", &StackSearch::compute_max_results,
+                 "Upper bound of results a search can return: start-area width x height x results_per_pixel.")
             // Extras (not in the reference): bulk results, the psi/phi store, kernel timing, debug flags.
-            .def("get_psi_phi_array", &StackSearch::get_psi_phi_array, py::return_value_policy::reference_internal)
-            .def("set_search_flags", &StackSearch::set_search_flags)
+            .def("get_psi_phi_array", &StackSearch::get_psi_phi_array, py::return_value_policy::reference_internal,
+                 "The PsiPhiArray this search owns (reference).")
+            .def("set_search_flags", &StackSearch::set_search_flags,
+                 "Flags handed to kb_device_search_filter (include/kbmod_hip.h: kernel choice, tile height, decode "
+                 "form); 0 lets the library choose.  None changes a result.")
             .def("results_to_numpy",
                  [](StackSearch& s) {
                      const std::vector<Trajectory>& v = s.get_all_results();
@@ -491,7 +596,8 @@ PYBIND11_MODULE(search, m) {
                          r(i, 6) = v[i].obs_count;
                      }
                      return out;
-                 })
+                 },
+                 "The stored results as an (N, 7) float64 array with columns x, y, vx, vy, lh, flux, obs_count.")
             .def("last_search_stats", [](StackSearch& s) {
                 const kb_search_stats& st = s.last_search_stats();
                 py::dict d;
@@ -506,18 +612,28 @@ PYBIND11_MODULE(search, m) {
                 d["sigmag_literal"] = st.sigmag_literal;
                 d["kernel_name"] = std::string(st.kernel_name);
                 return d;
-            });
+            },
+                 "Measurements of the last device search: kernel and table times (HIP events), evaluations, "
+                 "algorithmic bytes, the kernel instance that ran, sigma-G work counters.");
 
-    m.def("pixel_value_valid", &pixel_value_valid);
+    m.def("pixel_value_valid", &pixel_value_valid,
+                 "True for a finite pixel value (NO_DATA is NaN).");
 
     // ---- kernel_helpers.cpp:109-117 ----
     m.def("kb_has_gpu", &has_gpu, "Check if GPU is available");
-    m.def("sigmag_filtered_indices", &sigmaGFilteredIndices);
-    m.def("print_cuda_stats", &print_cuda_stats);
-    m.def("get_gpu_total_memory", &get_gpu_total_memory);
-    m.def("get_gpu_free_memory", &get_gpu_free_memory);
-    m.def("stat_gpu_memory_mb", &stat_gpu_memory_mb);
-    m.def("validate_gpu", &validate_gpu, py::arg("req_memory") = 0);
+    m.def("sigmag_filtered_indices", &sigmaGFilteredIndices,
+                 "Test hook of the in-search sigma-G clip: the indices of `values` that survive, in ascending value "
+                 "order (percentiles sgl0 / sgl1, coefficient, width in sigma-G).");
+    m.def("print_cuda_stats", &print_cuda_stats,
+                 "Print device name, compute units and memory to stdout.");
+    m.def("get_gpu_total_memory", &get_gpu_total_memory,
+                 "Bytes of HBM on the current device (0 without a GPU).");
+    m.def("get_gpu_free_memory", &get_gpu_free_memory,
+                 "Bytes of HBM currently free (0 without a GPU).");
+    m.def("stat_gpu_memory_mb", &stat_gpu_memory_mb,
+                 "One line of text with free and total HBM in MB.");
+    m.def("validate_gpu", &validate_gpu, py::arg("req_memory") = 0,
+                 "True when a GPU is present and has at least `req_memory` bytes free.");
 
     // ---- image_utils_cpp.cpp:180-194 (noconvert arguments) ----
     m.def(
@@ -525,33 +641,44 @@ PYBIND11_MODULE(search, m) {
             [](const py::array& image, const py::array& psf) {
                 return from_image(convolve_image_cpu(strict_image(image, "image"), strict_image(psf, "psf")));
             },
-            py::arg("image").noconvert(true), py::arg("psf").noconvert(true));
+            py::arg("image").noconvert(true), py::arg("psf").noconvert(true),
+                 "Masked, renormalised correlation of a float32 image with a PSF kernel on the host: non-finite pixels "
+                 "are skipped and pass through, the result is (sum of value x weight) x (kernel total) / (weight "
+                 "seen); NaN where no tap counted.");
     m.def(
             "convolve_image_gpu",
             [](const py::array& image, const py::array& psf) {
                 return from_image(convolve_image_gpu(strict_image(image, "image"), strict_image(psf, "psf")));
             },
-            py::arg("image").noconvert(true), py::arg("psf").noconvert(true));
+            py::arg("image").noconvert(true), py::arg("psf").noconvert(true),
+                 "The same correlation on the device (0.0 instead of NaN where no tap counted, as the reference's "
+                 "device kernel); raises RuntimeError without a GPU.");
     m.def(
             "convolve_image",
             [](const py::array& image, const py::array& psf) {
                 return from_image(convolve_image(strict_image(image, "image"), strict_image(psf, "psf")));
             },
-            py::arg("image").noconvert(true), py::arg("psf").noconvert(true));
+            py::arg("image").noconvert(true), py::arg("psf").noconvert(true),
+                 "convolve_image_gpu when a GPU is present, else convolve_image_cpu.");
     m.def(
             "square_psf_values",
             [](const py::array& psf) { return from_image(square_psf_values(strict_image(psf, "given_psf"))); },
-            py::arg("given_psf").noconvert(true));
+            py::arg("given_psf").noconvert(true),
+                 "Element-wise square of a PSF kernel (the kernel phi is built with).");
     m.def(
             "generate_psi",
             [](const py::array& sci, const py::array& var, const py::array& psf) {
                 return from_image(generate_psi(strict_image(sci, "sci"), strict_image(var, "var"), strict_image(psf, "psf")));
             },
-            py::arg("sci").noconvert(true), py::arg("var").noconvert(true), py::arg("psf").noconvert(true));
+            py::arg("sci").noconvert(true), py::arg("var").noconvert(true), py::arg("psf").noconvert(true),
+                 "psi image of one epoch: (science / variance) correlated with the PSF; NO_DATA where the variance is "
+                 "non-finite or zero or the science pixel is non-finite.");
     m.def(
             "generate_phi",
             [](const py::array& var, const py::array& psf) {
                 return from_image(generate_phi(strict_image(var, "var"), strict_image(psf, "psf")));
             },
-            py::arg("var").noconvert(true), py::arg("psf").noconvert(true));
+            py::arg("var").noconvert(true), py::arg("psf").noconvert(true),
+                 "phi image of one epoch: (1 / variance) correlated with the squared PSF; NO_DATA where the variance "
+                 "is non-finite or zero.");
 }
