@@ -138,6 +138,9 @@ int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, con
  *                           that already are page-locked (pinned allocations) are sent that way without the flag,
  *                           pageable ones otherwise go through two internal pinned buffers. */
 enum { KB_BUILD_SEPARABLE = 1, KB_BUILD_EMPTY_IS_ZERO = 2, KB_BUILD_GENERAL_TILES = 4, KB_BUILD_REGISTER_HOST = 8 };
+/* HIP-event time (ms) of the correlation kernel launch of the calling thread's last kb_build_psi_phi_from_device[_ex]
+ * (the measurement bench.py reports for the builder; 0 before the first build). */
+float kb_last_build_kernel_ms(void);
 int kb_build_psi_phi_from_device_ex(const float* sci_dev, const float* var_dev, const float* psf_host,
                                     const int32_t* psf_dims, int32_t num_times, int32_t height, int32_t width,
                                     int32_t num_bytes, uint32_t build_flags, kb_psi_phi_meta* meta_out,

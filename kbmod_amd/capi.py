@@ -52,6 +52,8 @@ def load_lib():
         raise RuntimeError("libkbmod_hip.so is not built (run __graft_entry__.build()); there is no fallback path")
     lib = C.CDLL(path)
     lib.kb_last_error.restype = C.c_char_p
+    lib.kb_last_build_kernel_ms.restype = C.c_float
+    lib.kb_last_build_kernel_ms.argtypes = []
     lib.kb_build_psi_phi_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                                  C.c_int32, C.c_int32, C.POINTER(Meta), C.POINTER(C.c_void_p), C.c_void_p]
     lib.kb_build_psi_phi_from_device_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

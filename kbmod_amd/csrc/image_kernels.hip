@@ -821,6 +821,9 @@ static bool factor_kernel(const float* k, int dim, float* u, float* w) {
     return true;
 }
 
+// HIP-event time of the correlation launch of this thread's last build from device stacks (kb_last_build_kernel_ms).
+static thread_local float g_last_build_kernel_ms = 0.0f;
+
 // Pinned staging of the host-stack build: two buffers, kept between calls.
 struct PinnedStage {
     void* p[2] = {nullptr, nullptr};
@@ -1010,8 +1013,11 @@ static int build_psi_phi(const float* sci_dev, const float* var_dev, const float
     };
 
     if (!from_host) {
+        EventTimer timer(stream, true);  // (the build synchronises the stream at its end anyway)
+        timer.begin();
         launch_epochs(0, num_times, stream);
         KB_HIP_TRY(hipGetLastError());
+        g_last_build_kernel_ms = timer.end();
     } else {
         // chunks of whole epochs, at most ~16 MiB per stack and chunk.  Where the caller's stacks are page-locked
         // -- allocated pinned (hipHostMalloc, a torch pinned tensor) or registered, which KB_BUILD_REGISTER_HOST does
@@ -1157,6 +1163,8 @@ static int build_psi_phi(const float* sci_dev, const float* var_dev, const float
 }  // namespace kb
 
 extern "C" {
+
+float kb_last_build_kernel_ms(void) { return kb::g_last_build_kernel_ms; }
 
 int kb_build_psi_phi_from_device(const float* sci_dev, const float* var_dev, const float* psf_host,
                                  const int32_t* psf_dims, int32_t num_times, int32_t height, int32_t width,
