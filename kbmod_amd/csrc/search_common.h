@@ -164,6 +164,8 @@ struct SearchArgs {
     const ChunkInfo* chunks;   // [n_chunks]
     const SlabRef* slabs;      // [n_chunks][T] slab origin inside the padded copy and slab size (kb_slab_ref_kernel)
     const int* lds_off;        // [n_chunks][T][C] byte offset of the shifted tile inside the slab
+    const int* lds_fold;       // [n_chunks][T][C] (+ slack) lds_off with the place of the epoch's slab in its group buffer folded in
+                               // (float-staged kernels: the lane's read pointer never moves inside the hand-scheduled loop)
     const int* global_box;     // {dx_min, dx_max, dy_min, dy_max, rows_max} over every (candidate, epoch)
     const int* n_invalid;      // device counter: non-zero when the image holds NO_DATA pixels (kb_pad_kernel)
     uint2* lists;              // kb_search_lds: per-pixel lists between chunks, [tile][slot][thread of the tile] of (lh bits, candidate)

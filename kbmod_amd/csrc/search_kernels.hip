@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void kb_pad_kernel(const SearchArgs a, int Hp,
 __global__ __launch_bounds__(256) void kb_slab_ref_kernel(const EpochBox* __restrict__ boxes,
                                                           const ChunkInfo* __restrict__ chunks, int64_t n, int T, int Hp,
                                                           int Wp, int px0, int py0, int pair_bytes,
-                                                          SlabRef* __restrict__ refs) {
+                                                          SlabRef* __restrict__ refs, const int* __restrict__ lds_off,
+                                                          int tile_rows, int* __restrict__ lds_fold) {
     const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (slot >= n + SLAB_REF_SLACK) return;
     const int64_t i = slot < n ? slot : n - 1;  // the entries of slack repeat the last one (loaded, never summed)
@@ -293,9 +294,20 @@ __global__ __launch_bounds__(256) void kb_slab_ref_kernel(const EpochBox* __rest
     r.origin = (box.x == BOX_NOT_STAGED)
                        ? (((int64_t)t * Hp + py0) * Wp + px0) * (int64_t)pair_bytes
                        : (((int64_t)t * Hp + box_dy(box) + py0) * Wp + box_dx(box) + px0) * (int64_t)pair_bytes;
-    r.bytes = chunks[i / T].rows_max * chunks[i / T].cols * pair_bytes;
+    const ChunkInfo ci = chunks[i / T];
+    r.bytes = ci.rows_max * ci.cols * pair_bytes;
     r.pad = 0;
     refs[slot] = r;
+    // the offsets of the hand-scheduled loop (float-staged kernels: 8-byte pairs in LDS).  Groups start at multiples of E
+    // epochs (chunk_plan of search_lds.h), slab e of a group sits e strides into the group buffer.
+    const int stride = (ci.rows_max * ci.cols * 8 + 1023) & ~1023;
+    const int E = max(1, min(T, lds_group_bytes(tile_rows) / stride));
+    const int place = (t % E) * stride;
+#pragma unroll
+    for (int c = 0; c < CHUNK; ++c) {
+        const int o = lds_off[i * CHUNK + c];
+        lds_fold[slot * CHUNK + c] = o >= 0 ? o + place : o;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -696,12 +708,14 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         const size_t off_bytes = ((size_t)a.n_chunks * a.T * CHUNK + 4 * CHUNK) * sizeof(int);  // + prefetch slack
         const size_t box_bytes = (size_t)a.n_chunks * a.T * sizeof(EpochBox);
         const size_t org_bytes = ((size_t)a.n_chunks * a.T + SLAB_REF_SLACK) * sizeof(SlabRef);
+        const size_t fold_bytes = ((size_t)a.n_chunks * a.T + SLAB_REF_SLACK) * CHUNK * sizeof(int);
         const size_t chunk_bytes = (size_t)a.n_chunks * sizeof(ChunkInfo);
         // NO_DATA pixel counter [1], unstaged (chunk, epoch) counter [1], staged shift box + tallest slab [5],
         // per-lane (chunk, epoch) counter [1]
         const size_t inv_bytes = 8 * sizeof(int);
         void* ws = nullptr;
-        if (ensure_workspace(0, table_bytes + off_bytes + box_bytes + chunk_bytes + inv_bytes + org_bytes, &ws)) return 1;
+        if (fold_bytes > 0x7fff0000ull) return fail("deviceSearchFilter: candidate list x epochs too long for the offset tables");
+        if (ensure_workspace(0, table_bytes + off_bytes + box_bytes + chunk_bytes + inv_bytes + org_bytes + fold_bytes + 64, &ws)) return 1;
         char* wsc = reinterpret_cast<char*>(ws);
         a.table = reinterpret_cast<const int2*>(wsc);
         a.lds_off = reinterpret_cast<const int*>(wsc + table_bytes);
@@ -710,6 +724,8 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         int* inv = reinterpret_cast<int*>(wsc + table_bytes + off_bytes + box_bytes + chunk_bytes);
         SlabRef* slab_refs = reinterpret_cast<SlabRef*>(wsc + table_bytes + off_bytes + box_bytes + chunk_bytes + inv_bytes);
         a.slabs = slab_refs;
+        int* lds_fold = reinterpret_cast<int*>(wsc + (table_bytes + off_bytes + box_bytes + chunk_bytes + inv_bytes + org_bytes + 63) / 64 * 64);
+        a.lds_fold = lds_fold;
         int* n_invalid = inv;
         int* n_not_lds = inv + 1;
         int* gbox = inv + 2;
@@ -833,7 +849,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                     const int64_t n_org = (int64_t)a.n_chunks * a.T;
                     hipLaunchKernelGGL(kb_slab_ref_kernel, dim3((unsigned)((n_org + SLAB_REF_SLACK + 255) / 256)), dim3(256), 0, stream,
                                        cold.boxes, a.chunks, n_org, a.T, cold.Hp, a.Wp, cold.px0, cold.py0, (int)pair_bytes,
-                                       slab_refs);
+                                       slab_refs, a.lds_off, lds_rows, lds_fold);
                     KB_HIP_TRY(hipGetLastError());
                     which = canon ? 2 : 1;
                 }

@@ -8,6 +8,7 @@
 #include <type_traits>
 
 #include "search_device.h"
+#include "search_lds_asm.h"
 
 #pragma clang fp contract(off)
 
@@ -459,14 +460,92 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     org_cur = origin_of(n_org[e]);
                 }
             };
+            // The same run as ONE asm statement (search_lds_asm.h, generated by tools/gen_lds_loop.py) for the float-staged
+            // kernels with one slab per wave and epoch at most: two epochs per trip; the table words of epoch e + 2 are
+            // fetched BEHIND the wait for epoch e's LDS reads, into the registers those reads just consumed, so the scalar
+            // loads -- which share the LDS counter and return out of order: any wait for them waits for everything -- have a
+            // whole epoch to land in instead of sitting in front of the sums; two slabs in flight; offsets with the slab's
+            // place in its group folded in (SearchArgs::lds_fold), so the lane's read pointer never moves.  Nothing the
+            // compiler schedules runs while anything is in flight: the registers involved are fixed and named as clobbers.
+            auto asm_run = [&](auto np_tag) {
+                constexpr int NP = decltype(np_tag)::value;
+                static_assert(NP <= 1 && C == 8 && sizeof(SlabRef) == 16, "search_lds_asm.h");
+                uint32_t pairs = (uint32_t)(n_both - e) >> 1;
+                const uint32_t odd = (uint32_t)(n_both - e) & 1u;
+                const int done = n_both - e;
+                uint32_t wd = (uint32_t)(uintptr_t)(nb + 16 * (int)threadIdx.x + e * n_plan.stride);
+                const uint32_t rb = (uint32_t)(uintptr_t)cb;  // this lane's pixel at the start of the group buffer
+                const uint32_t go = n_sl.goff[0];
+                const uint32_t k64 = 0x10000u;
+                const uint64_t ob = (uint64_t)(uintptr_t)(a.lds_fold + ((size_t)chunk * T + t0 + e) * C);
+                const uint64_t gb = (uint64_t)(uintptr_t)(n_org + (e + 1));
+                const uint64_t tb = (uint64_t)(uintptr_t)tile_base;
+                const uint64_t b0 = tb + (uint64_t)org_cur;
+                const uint32_t tl = (uint32_t)tb, th = (uint32_t)(tb >> 32);
+                const uint32_t st = (uint32_t)n_plan.stride;
+                if constexpr (FAST) {
+                    if constexpr (NP == 1) {
+                        asm volatile(KB_LDS_LOOP_FAST_NP1
+                                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),
+                                       [a5] "+v"(acc[5]), [a6] "+v"(acc[6]), [a7] "+v"(acc[7]), [wd] "+v"(wd), [np] "+s"(pairs)
+                                     : [rb] "v"(rb), [go] "v"(go), [ob] "s"(ob), [gb] "s"(gb), [b0] "s"(b0), [tl] "s"(tl), [th] "s"(th),
+                                       [st] "s"(st), [od] "s"(odd)
+                                     : KB_LDS_LOOP_CLOBBERS);
+                    } else {
+                        asm volatile(KB_LDS_LOOP_FAST_NP0
+                                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),
+                                       [a5] "+v"(acc[5]), [a6] "+v"(acc[6]), [a7] "+v"(acc[7]), [wd] "+v"(wd), [np] "+s"(pairs)
+                                     : [rb] "v"(rb), [ob] "s"(ob), [gb] "s"(gb), [st] "s"(st), [od] "s"(odd)
+                                     : KB_LDS_LOOP_CLOBBERS);
+                    }
+                } else {
+                    if constexpr (NP == 1) {
+                        asm volatile(KB_LDS_LOOP_COUNT_NP1
+                                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),
+                                       [a5] "+v"(acc[5]), [a6] "+v"(acc[6]), [a7] "+v"(acc[7]), [c0] "+v"(cntp[0]), [c1] "+v"(cntp[1]),
+                                       [c2] "+v"(cntp[2]), [c3] "+v"(cntp[3]), [wd] "+v"(wd), [np] "+s"(pairs)
+                                     : [rb] "v"(rb), [go] "v"(go), [k64] "v"(k64), [ob] "s"(ob), [gb] "s"(gb), [b0] "s"(b0), [tl] "s"(tl),
+                                       [th] "s"(th), [st] "s"(st), [od] "s"(odd)
+                                     : KB_LDS_LOOP_CLOBBERS);
+                    } else {
+                        asm volatile(KB_LDS_LOOP_COUNT_NP0
+                                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),
+                                       [a5] "+v"(acc[5]), [a6] "+v"(acc[6]), [a7] "+v"(acc[7]), [c0] "+v"(cntp[0]), [c1] "+v"(cntp[1]),
+                                       [c2] "+v"(cntp[2]), [c3] "+v"(cntp[3]), [wd] "+v"(wd), [np] "+s"(pairs)
+                                     : [rb] "v"(rb), [k64] "v"(k64), [ob] "s"(ob), [gb] "s"(gb), [st] "s"(st), [od] "s"(odd)
+                                     : KB_LDS_LOOP_CLOBBERS);
+                    }
+                }
+                e += done;
+                // hand over to the loop below: plain offsets and origin of epoch / slab e, from the tables it walks.
+                // Unconditional on purpose: with e == n_cur the values are never used and the reads land in the tables'
+                // slack (off_bytes' 4 * CHUNK ints, SLAB_REF_SLACK references), but the straight-line form measured
+                // 4.44 ms against 4.57 ms for the guarded one on the same chip (tools/ab.sh) -- a guard here also splits
+                // the live ranges of the loop below.
+                {
+                    const ConstIntPtr cur = offs + e * C;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) o_cur[c] = cur[c];
+                    org_cur = origin_of(n_org[e]);
+                }
+            };
             if (n_both > 0) {
                 const int wave_piece = 1024 * tc.wv;
+                constexpr bool HAND_SCHEDULED = CANON && STAGE_DEPTH == 1 && C == 8;
                 if (LDS_SLOTS >= 2 && wave_piece + stage_round(ROWS) < n_plan.slab_bytes) {
                     staged_run(std::integral_constant<int, (LDS_SLOTS >= 2 ? 2 : 1)>{});
                 } else if (wave_piece < n_plan.slab_bytes) {
-                    staged_run(std::integral_constant<int, 1>{});
+                    if constexpr (HAND_SCHEDULED) {
+                        asm_run(std::integral_constant<int, 1>{});
+                    } else {
+                        staged_run(std::integral_constant<int, 1>{});
+                    }
                 } else {
-                    staged_run(std::integral_constant<int, 0>{});
+                    if constexpr (HAND_SCHEDULED) {
+                        asm_run(std::integral_constant<int, 0>{});
+                    } else {
+                        staged_run(std::integral_constant<int, 0>{});
+                    }
                 }
             }
             KB_PROF_MARK(2)
