@@ -35,6 +35,17 @@ constexpr int TILE_GROUP_ROWS = KB_TILE_GROUP_ROWS;  // tile rows walked togethe
 __host__ __device__ constexpr int block_threads(int rows) { return rows * WAVE; }
 __host__ __device__ constexpr int stage_round(int rows) { return rows * WAVE * 16; }  // bytes one staging round moves
 __host__ __device__ constexpr int lds_group_bytes(int rows) { return 5120 * rows; }   // one of the two group buffers
+// Epochs per group: as many slabs of `stride` bytes as a group buffer holds.  The hand-scheduled instances (search_lds_asm.h)
+// take an even number when there are two or more: their run of whole groups works in pairs of epochs.
+__host__ __device__ inline int group_epochs(int T, int rows, int stride, bool even) {
+    int E = lds_group_bytes(rows) / stride;
+    if (E > T) E = T;
+    if (E < 1) E = 1;
+#ifndef KB_EXP_ODD_E
+    if (even && E >= 2) E &= ~1;
+#endif
+    return E;
+}
 
 // LDS staging (kb_search_lds): per (chunk, epoch) the workgroup stages a slab of
 // rows_max(chunk) x cols(chunk) raw pairs -- the union footprint of its 64 x ROWS tile

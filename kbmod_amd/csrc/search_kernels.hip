@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void kb_slab_ref_kernel(const EpochBox* __rest
     // the offsets of the hand-scheduled loop (float-staged kernels: 8-byte pairs in LDS).  Groups start at multiples of E
     // epochs (chunk_plan of search_lds.h), slab e of a group sits e strides into the group buffer.
     const int stride = (ci.rows_max * ci.cols * 8 + 1023) & ~1023;
-    const int E = max(1, min(T, lds_group_bytes(tile_rows) / stride));
+    const int E = group_epochs(T, tile_rows, stride, true);  // (the table is read by the hand-scheduled instances only)
     const int place = (t % E) * stride;
 #pragma unroll
     for (int c = 0; c < CHUNK; ++c) {

@@ -199,14 +199,14 @@ struct ChunkPlan {
     int E;           // epochs per group
     int clean;       // every epoch is staged with uniform shifts: the summing loop needs no per-epoch test
 };
-template <int BYTES, int ROWS>
+template <int BYTES, int ROWS, bool EVEN>
 __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) {
     ChunkPlan p;
     const ConstIntPtr ci = as_const_ints(&a.chunks[chunk]);  // {dx_min, dx_max, dy_min, dy_max, unsafe, lds_ok, rows_max, cols}
     p.cols = ci[7];
     p.slab_bytes = ci[6] * p.cols * BYTES;
     p.stride = (p.slab_bytes + 1023) & ~1023;
-    p.E = max(1, min(a.T, lds_group_bytes(ROWS) / p.stride));
+    p.E = group_epochs(a.T, ROWS, p.stride, EVEN);
     p.clean = (ci[4] == 0 && ci[5] != 0) ? 1 : 0;
     return p;
 }
@@ -223,6 +223,8 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     constexpr int SF = CANON ? 4 : NB;  // staged format
     using R = RawPair<SF>;
     constexpr int BYTES = 2 * fmt_bytes(SF);
+    // the float-staged, depth-1 instances run their epochs through search_lds_asm.h
+    constexpr bool HAND_SCHEDULED = CANON && STAGE_DEPTH == 1 && C == 8;
     const int T = a.T;
 
     PairF acc[C];  // (psi_sum, phi_sum) as pairs: one v_pk_add_f32 per sample
@@ -239,7 +241,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     uint64_t prof_t = __builtin_amdgcn_s_memtime();
 #endif
     int chunk = a.chunk_lo, t0 = 0, buf = 0;
-    ChunkPlan plan = chunk_plan<BYTES, ROWS>(a, chunk);
+    ChunkPlan plan = chunk_plan<BYTES, ROWS, HAND_SCHEDULED>(a, chunk);
     SlabRegs regs;
     typedef int Int4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) Int4* ConstSlabPtr;  // a SlabRef as four dwords
@@ -262,6 +264,82 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     KB_PROF_MARK(0)
 
     while (chunk < a.chunk_hi) {
+        if constexpr (HAND_SCHEDULED) {
+            // Whole groups of this chunk whose staged successors are whole groups of this chunk too: ONE asm statement
+            // (KB_LDS_STREAM_*), group changes -- LDS writes landed, barrier, buffers swapped -- inside it, so that slab loads
+            // and table words stay in flight across them and a group costs a handful of instructions instead of a set-up, a
+            // pipeline fill and a drain.  Needs an even number of epochs per group (chunk_plan's EVEN) and slabs of one
+            // staging round, so that every wave of the block takes this path with at most one piece per slab.
+            // (Every read-write operand of these statements is early-clobber: they are written while inputs are still
+            // being read, and without the mark an input of equal value -- pairs per group and pairs to the next barrier --
+            // is given the same register.)
+#ifdef KB_EXP_NO_STREAM
+            const int ng = 0;
+#else
+            const int ng = (T - t0) / plan.E - 1;
+#endif
+            if (plan.clean && (plan.E & 1) == 0 && plan.slab_bytes <= stage_round(ROWS) && ng >= 2) {
+                KB_PROF_MARK(1)
+                const ConstSlabPtr first = (ConstSlabPtr)(uintptr_t)(a.slabs + (size_t)chunk * T + t0 + plan.E);
+                const int GB = lds_group_bytes(ROWS);
+                uint32_t rb = (uint32_t)(uintptr_t)(smem + buf * GB + (tc.wv * plan.cols + tc.lane) * BYTES);
+                uint32_t wd = (uint32_t)(uintptr_t)(smem + (1 - buf) * GB + 16 * (int)threadIdx.x);
+                uint32_t dr = (uint32_t)((1 - 2 * buf) * GB);
+                const uint32_t pg = (uint32_t)plan.E >> 1;
+                uint32_t gc = pg, pairs = (uint32_t)ng * pg;
+                const uint32_t es = (uint32_t)(plan.E * plan.stride), st = (uint32_t)plan.stride;
+                const uint32_t go = n_sl.goff[0];
+                const uint32_t k64 = 0x10000u;
+                const uint64_t ob = (uint64_t)(uintptr_t)(a.lds_fold + ((size_t)chunk * T + t0) * C);
+                const uint64_t gb = (uint64_t)(uintptr_t)(first + 1);
+                const uint64_t tb = (uint64_t)(uintptr_t)tile_base;
+                const uint64_t b0 = tb + (uint64_t)origin_of(first[0]);
+                const uint32_t tl = (uint32_t)tb, th = (uint32_t)(tb >> 32);
+                if (1024 * tc.wv < plan.slab_bytes) {
+                    if constexpr (FAST) {
+                        asm volatile(KB_LDS_STREAM_FAST_NP1
+                                 : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
+                                   [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [wd] "+&v"(wd), [rb] "+&v"(rb),
+                                   [np] "+&s"(pairs), [gc] "+&s"(gc), [dr] "+&s"(dr)
+                                 : [go] "v"(go), [ob] "s"(ob), [gb] "s"(gb), [b0] "s"(b0), [tl] "s"(tl), [th] "s"(th), [st] "s"(st), [pg] "s"(pg), [es] "s"(es)
+                                 : KB_LDS_LOOP_CLOBBERS);
+                    } else {
+                        asm volatile(KB_LDS_STREAM_COUNT_NP1
+                                 : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
+                                   [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [c0] "+&v"(cntp[0]), [c1] "+&v"(cntp[1]),
+                                   [c2] "+&v"(cntp[2]), [c3] "+&v"(cntp[3]), [wd] "+&v"(wd), [rb] "+&v"(rb),
+                                   [np] "+&s"(pairs), [gc] "+&s"(gc), [dr] "+&s"(dr)
+                                 : [go] "v"(go), [k64] "v"(k64), [ob] "s"(ob), [gb] "s"(gb), [b0] "s"(b0), [tl] "s"(tl), [th] "s"(th), [st] "s"(st), [pg] "s"(pg), [es] "s"(es)
+                                 : KB_LDS_LOOP_CLOBBERS);
+                    }
+                } else {
+                    if constexpr (FAST) {
+                        asm volatile(KB_LDS_STREAM_FAST_NP0
+                                 : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
+                                   [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [wd] "+&v"(wd), [rb] "+&v"(rb),
+                                   [np] "+&s"(pairs), [gc] "+&s"(gc), [dr] "+&s"(dr)
+                                 : [ob] "s"(ob), [gb] "s"(gb), [st] "s"(st), [pg] "s"(pg), [es] "s"(es)
+                                 : KB_LDS_LOOP_CLOBBERS);
+                    } else {
+                        asm volatile(KB_LDS_STREAM_COUNT_NP0
+                                 : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
+                                   [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [c0] "+&v"(cntp[0]), [c1] "+&v"(cntp[1]),
+                                   [c2] "+&v"(cntp[2]), [c3] "+&v"(cntp[3]), [wd] "+&v"(wd), [rb] "+&v"(rb),
+                                   [np] "+&s"(pairs), [gc] "+&s"(gc), [dr] "+&s"(dr)
+                                 : [k64] "v"(k64), [ob] "s"(ob), [gb] "s"(gb), [st] "s"(st), [pg] "s"(pg), [es] "s"(es)
+                                 : KB_LDS_LOOP_CLOBBERS);
+                    }
+                }
+                KB_PROF_MARK(2)
+                t0 += ng * plan.E;
+                buf ^= ng & 1;
+#ifndef KB_EXP_NO_BARRIER
+                __syncthreads();
+#endif
+                KB_PROF_MARK(5)
+                continue;
+            }
+        }
         // next group in flight during this group's arithmetic
         int n_chunk = chunk, n_t0 = t0 + plan.E;
         ChunkPlan n_plan = plan;
@@ -269,7 +347,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             n_chunk = chunk + 1;
             n_t0 = 0;
             if (n_chunk < a.chunk_hi) {
-                n_plan = chunk_plan<BYTES, ROWS>(a, n_chunk);
+                n_plan = chunk_plan<BYTES, ROWS, HAND_SCHEDULED>(a, n_chunk);
                 n_sl = stage_lanes<BYTES, ROWS>(a, n_plan.cols, n_plan.slab_bytes);
             }
         }
@@ -486,32 +564,32 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 if constexpr (FAST) {
                     if constexpr (NP == 1) {
                         asm volatile(KB_LDS_LOOP_FAST_NP1
-                                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),
-                                       [a5] "+v"(acc[5]), [a6] "+v"(acc[6]), [a7] "+v"(acc[7]), [wd] "+v"(wd), [np] "+s"(pairs)
+                                     : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
+                                       [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [wd] "+&v"(wd), [np] "+&s"(pairs)
                                      : [rb] "v"(rb), [go] "v"(go), [ob] "s"(ob), [gb] "s"(gb), [b0] "s"(b0), [tl] "s"(tl), [th] "s"(th),
                                        [st] "s"(st), [od] "s"(odd)
                                      : KB_LDS_LOOP_CLOBBERS);
                     } else {
                         asm volatile(KB_LDS_LOOP_FAST_NP0
-                                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),
-                                       [a5] "+v"(acc[5]), [a6] "+v"(acc[6]), [a7] "+v"(acc[7]), [wd] "+v"(wd), [np] "+s"(pairs)
+                                     : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
+                                       [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [wd] "+&v"(wd), [np] "+&s"(pairs)
                                      : [rb] "v"(rb), [ob] "s"(ob), [gb] "s"(gb), [st] "s"(st), [od] "s"(odd)
                                      : KB_LDS_LOOP_CLOBBERS);
                     }
                 } else {
                     if constexpr (NP == 1) {
                         asm volatile(KB_LDS_LOOP_COUNT_NP1
-                                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),
-                                       [a5] "+v"(acc[5]), [a6] "+v"(acc[6]), [a7] "+v"(acc[7]), [c0] "+v"(cntp[0]), [c1] "+v"(cntp[1]),
-                                       [c2] "+v"(cntp[2]), [c3] "+v"(cntp[3]), [wd] "+v"(wd), [np] "+s"(pairs)
+                                     : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
+                                       [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [c0] "+&v"(cntp[0]), [c1] "+&v"(cntp[1]),
+                                       [c2] "+&v"(cntp[2]), [c3] "+&v"(cntp[3]), [wd] "+&v"(wd), [np] "+&s"(pairs)
                                      : [rb] "v"(rb), [go] "v"(go), [k64] "v"(k64), [ob] "s"(ob), [gb] "s"(gb), [b0] "s"(b0), [tl] "s"(tl),
                                        [th] "s"(th), [st] "s"(st), [od] "s"(odd)
                                      : KB_LDS_LOOP_CLOBBERS);
                     } else {
                         asm volatile(KB_LDS_LOOP_COUNT_NP0
-                                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),
-                                       [a5] "+v"(acc[5]), [a6] "+v"(acc[6]), [a7] "+v"(acc[7]), [c0] "+v"(cntp[0]), [c1] "+v"(cntp[1]),
-                                       [c2] "+v"(cntp[2]), [c3] "+v"(cntp[3]), [wd] "+v"(wd), [np] "+s"(pairs)
+                                     : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
+                                       [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [c0] "+&v"(cntp[0]), [c1] "+&v"(cntp[1]),
+                                       [c2] "+&v"(cntp[2]), [c3] "+&v"(cntp[3]), [wd] "+&v"(wd), [np] "+&s"(pairs)
                                      : [rb] "v"(rb), [k64] "v"(k64), [ob] "s"(ob), [gb] "s"(gb), [st] "s"(st), [od] "s"(odd)
                                      : KB_LDS_LOOP_CLOBBERS);
                     }
@@ -531,7 +609,6 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             };
             if (n_both > 0) {
                 const int wave_piece = 1024 * tc.wv;
-                constexpr bool HAND_SCHEDULED = CANON && STAGE_DEPTH == 1 && C == 8;
                 if (LDS_SLOTS >= 2 && wave_piece + stage_round(ROWS) < n_plan.slab_bytes) {
                     staged_run(std::integral_constant<int, (LDS_SLOTS >= 2 ? 2 : 1)>{});
                 } else if (wave_piece < n_plan.slab_bytes) {

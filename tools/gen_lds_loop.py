@@ -87,6 +87,39 @@ def body(fast, np_):
     return s
 
 
+def stream(fast, np_):
+    """A run of whole groups inside one chunk (every group full, staging a full group of the same chunk, an even number of
+    epochs per group): the same two-epoch trip, with the group change -- LDS writes landed, barrier, the read pointer to the
+    other buffer, the write pointer back to slot 0 of the one just read -- inside the statement, so the slab loads and the
+    table words stay in flight across it.  %[np]: pairs in total (>= 1), %[gc]: pairs until the next barrier, %[pg]: pairs per
+    group, %[dr]: distance from the buffer being read to the other one, %[es]: bytes of a group of staged slabs."""
+    s = ""
+    s += f'"s_load_dwordx8 s[{A}:{A + 7}], %[ob], 0x0\\n\\t"\n'
+    s += f'"s_load_dwordx8 s[{B}:{B + 7}], %[ob], 0x20\\n\\t"\n'
+    s += '"s_load_dwordx2 s[84:85], %[gb], 0x0\\n\\t"\n'
+    s += '"s_load_dwordx2 s[86:87], %[gb], 0x10\\n\\t"\n'
+    s += '"s_mov_b32 s90, 0x40\\n\\ts_mov_b32 s91, 0x20\\n\\t"\n'
+    if np_:
+        s += '"global_load_dwordx4 v[100:103], %[go], %[b0]\\n\\t"\n'
+    s += '"s_waitcnt lgkmcnt(0)\\n\\t"\n'
+    s += '"s_cmp_eq_u32 %[np], 1\\n\\ts_cbranch_scc1 kb_sfin_%=\\n"\n'
+    s += '"kb_sloop_%=:\\n\\t"\n'
+    s += half("A", fast, np_, True, True)
+    s += half("B", fast, np_, True, True)
+    s += '"s_add_u32 s90, s90, 0x40\\n\\ts_add_u32 s91, s91, 0x20\\n\\t"\n'
+    s += '"s_sub_u32 %[gc], %[gc], 1\\n\\ts_cmp_lg_u32 %[gc], 0\\n\\ts_cbranch_scc1 kb_snb_%=\\n\\t"\n'
+    s += '"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\\n\\t"\n'
+    s += '"v_add_u32 %[rb], %[dr], %[rb]\\n\\tv_subrev_u32 %[wd], %[es], %[wd]\\n\\tv_subrev_u32 %[wd], %[dr], %[wd]\\n\\t"\n'
+    s += '"s_sub_u32 %[dr], 0, %[dr]\\n\\ts_mov_b32 %[gc], %[pg]\\n"\n'
+    s += '"kb_snb_%=:\\n\\t"\n'
+    s += '"s_sub_u32 %[np], %[np], 1\\n\\ts_cmp_lg_u32 %[np], 1\\n\\ts_cbranch_scc1 kb_sloop_%=\\n"\n'
+    s += '"kb_sfin_%=:\\n\\t"\n'
+    s += half("A", fast, np_, True, False)
+    s += half("B", fast, np_, False, False)
+    s += '"s_waitcnt vmcnt(0) lgkmcnt(0)"\n'
+    return s
+
+
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = ['// GENERATED by tools/gen_lds_loop.py -- the hand-scheduled summing loop of kb_search_lds (search_lds.h, streamlined run).',
@@ -98,6 +131,10 @@ def main():
         for np_ in (0, 1):
             out.append(f'#define KB_LDS_LOOP_{"FAST" if fast else "COUNT"}_NP{np_} \\')
             lines = body(fast, np_).rstrip("\n").split("\n")
+            out.append(" \\\n".join("    " + ln for ln in lines))
+            out.append('')
+            out.append(f'#define KB_LDS_STREAM_{"FAST" if fast else "COUNT"}_NP{np_} \\')
+            lines = stream(fast, np_).rstrip("\n").split("\n")
             out.append(" \\\n".join("    " + ln for ln in lines))
             out.append('')
     out.append('#define KB_LDS_LOOP_CLOBBERS \\')
