@@ -69,7 +69,8 @@ typedef struct kb_search_stats {
     char kernel_name[96];         /* the search kernel instance that ran, spelled as rocprofv3 prints it
                                      (e.g. "kb::kb_search_lds<8, 8, 16, 4, true, false, 3, 1>") */
     int32_t padded_copy_reused;   /* flag 256 was honoured: no decode-and-pad pass in this search */
-    int32_t reserved_;
+    int32_t special_epochs;       /* kb_search_lds: (chunk of candidates, epoch) pairs summed per lane -- not staged, or a shift
+                                     inside the guard band of a rounding boundary -- instead of by the uniform loops */
 } kb_search_stats;
 
 const char* kb_last_error(void);

@@ -611,6 +611,7 @@ PYBIND11_MODULE(search, m) {
                 d["sigmag_trajectories"] = st.sigmag_trajectories;
                 d["sigmag_literal"] = st.sigmag_literal;
                 d["kernel_name"] = std::string(st.kernel_name);
+                d["special_epochs"] = st.special_epochs;
                 return d;
             },
                  "Measurements of the last device search: kernel and table times (HIP events), evaluations, "

@@ -22,6 +22,9 @@ constexpr int SHIFT_UNSAFE = INT32_MIN;  // dx marker: no uniform shift proven f
 #define KB_CHUNK 8
 #endif
 constexpr int CHUNK = KB_CHUNK;    // candidates accumulated together per wave
+// ... and by the packed-list float-staged instance of kb_search_lds (K <= 8, one slab in flight): twice the candidates per
+// staged slab halve the passes over the stack, and with them the bytes that cross the fabric (what bounds that kernel)
+constexpr int WIDE_CHUNK = 2 * CHUNK;
 #ifndef KB_DIRECT_ROWS
 #define KB_DIRECT_ROWS 4
 #endif
@@ -43,6 +46,7 @@ __host__ __device__ inline int group_epochs(int T, int rows, int stride, bool ev
     if (E < 1) E = 1;
 #ifndef KB_EXP_ODD_E
     if (even && E >= 2) E &= ~1;
+    if (even && E > 16) E = 16;  // (their counting form keeps 32 -- chunks of 16: 16 -- samples' NO_DATA bits per register between two tallies)
 #endif
     return E;
 }
@@ -182,6 +186,7 @@ struct SearchArgs {
     uint2* lists;              // kb_search_lds: per-pixel lists between chunks, [tile][slot][thread of the tile] of (lh bits, candidate)
     int T, W, H, Wp;
     int n_cands, n_chunks;
+    int chunk;                 // candidates per chunk the tables were built for: CHUNK, or WIDE_CHUNK for the instances that take it
     int chunk_lo, chunk_hi;    // candidate chunks [chunk_lo, chunk_hi) of this launch
     int sw, sh;
     int tiles_x, tiles_y, n_tiles;

@@ -171,7 +171,7 @@ __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int chu
         pending |= out ? 0u : (1u << c);
     }
     while (__ballot(pending != 0u) != 0ull) {  // uniform
-        const int c_sel = (int)__builtin_ctz(pending | 0x100u);  // (8: a lane with nothing left selects nothing)
+        const int c_sel = (int)__builtin_ctz(pending | (1u << C));  // (C: a lane with nothing left selects nothing)
         float p = ps[0], f = ph[0];
         int n = cnt[0];
 #pragma unroll

@@ -50,14 +50,20 @@ __device__ __forceinline__ int uniform_shift(float v, double t, int* kind) {
     const double g = __dadd_rn(a, 0.5);
     const double fl = floor(g);
     const double frac = g - fl;
-    // Guard band 2^-20 around the rounding boundary and |a| < 2^22: with start
-    // coordinates |x| < 2^22 the two extra roundings of (x + a) + 0.5 move the
-    // value by < 2^-28, so floor() cannot change ("shift table").
+    // |a| < 2^22 and start coordinates |x| < 2^22.  The reference rounds (x + a) and then ((x + a) + 0.5): each by at most
+    // 2^-31 (values below 2^23: half an ulp of 2^-30); g itself carries the rounding of a + 0.5, at most 2^-31.  So the
+    // value whose floor the reference takes lies within 1.5 * 2^-30 < 2^-29 of x + fl + frac, and floor() is x + fl for
+    // every x whenever frac keeps 2^-29 from both ends: the guard band is 2^-27, four times that ("shift
+    // table").  And when a has at most 29 fractional bits -- dyadic times, e.g. i / 64 days, times a float velocity --
+    // x + a and (x + a) + 0.5 are exact (23 + 1 integer bits, 29 fractional ones: 53), so nothing is rounded at all and
+    // the shift is uniform wherever frac lies, an exact half pixel included.
     if (!(fabs(a) < 4194304.0)) {
         *kind = 2;
         return 0;
     }
-    if (!(frac >= 9.5367431640625e-07 && frac <= 1.0 - 9.5367431640625e-07)) *kind = max(*kind, 1);
+    const double scaled = a * 536870912.0;  // 2^29: exact
+    const bool exact_sums = scaled == floor(scaled);
+    if (!exact_sums && !(frac >= 7.450580596923828e-09 && frac <= 1.0 - 7.450580596923828e-09)) *kind = max(*kind, 1);
     return (int)fl;
 }
 
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256) void kb_slab_ref_kernel(const EpochBox* __rest
                                                           const ChunkInfo* __restrict__ chunks, int64_t n, int T, int Hp,
                                                           int Wp, int px0, int py0, int pair_bytes,
                                                           SlabRef* __restrict__ refs, const int* __restrict__ lds_off,
-                                                          int tile_rows, int* __restrict__ lds_fold) {
+                                                          int tile_rows, int* __restrict__ lds_fold, int chunk_c) {
     const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (slot >= n + SLAB_REF_SLACK) return;
     const int64_t i = slot < n ? slot : n - 1;  // the entries of slack repeat the last one (loaded, never summed)
@@ -295,7 +301,8 @@ __global__ __launch_bounds__(256) void kb_slab_ref_kernel(const EpochBox* __rest
                        ? (((int64_t)t * Hp + py0) * Wp + px0) * (int64_t)pair_bytes
                        : (((int64_t)t * Hp + box_dy(box) + py0) * Wp + box_dx(box) + px0) * (int64_t)pair_bytes;
     const ChunkInfo ci = chunks[i / T];
-    r.bytes = ci.rows_max * ci.cols * pair_bytes;
+    // as tall as THIS epoch's shift box (the hand-scheduled loop skips the pieces behind it); the chunk's pitch
+    r.bytes = ((box.x == BOX_NOT_STAGED) ? ci.rows_max : box_rows(box)) * ci.cols * pair_bytes;
     r.pad = 0;
     refs[slot] = r;
     // the offsets of the hand-scheduled loop (float-staged kernels: 8-byte pairs in LDS).  Groups start at multiples of E
@@ -304,9 +311,9 @@ __global__ __launch_bounds__(256) void kb_slab_ref_kernel(const EpochBox* __rest
     const int E = group_epochs(T, tile_rows, stride, true);  // (the table is read by the hand-scheduled instances only)
     const int place = (t % E) * stride;
 #pragma unroll
-    for (int c = 0; c < CHUNK; ++c) {
-        const int o = lds_off[i * CHUNK + c];
-        lds_fold[slot * CHUNK + c] = o >= 0 ? o + place : o;
+    for (int c = 0; c < chunk_c; ++c) {
+        const int o = lds_off[i * chunk_c + c];
+        lds_fold[slot * chunk_c + c] = o >= 0 ? o + place : o;
     }
 }
 
@@ -657,6 +664,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     a.W = (int)meta->width;
     a.H = (int)meta->height;
     a.n_cands = (int)n_cands;
+    a.chunk = CHUNK;
     a.n_chunks = (int)((n_cands + CHUNK - 1) / CHUNK);
     a.sw = (int)sw;
     a.sh = (int)sh;
@@ -703,12 +711,31 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     uint64_t padded_copy_bytes = 0;
     const bool want_lds = (flags & 2u) == 0 && (flags & 1u) == 0 && a.K <= 32 &&
                           (n_cands >= 8 || (flags & 4u) != 0);
-    if (n_cands > 0) {
-        const size_t table_bytes = (size_t)a.n_chunks * a.T * CHUNK * sizeof(int2);
-        const size_t off_bytes = ((size_t)a.n_chunks * a.T * CHUNK + 4 * CHUNK) * sizeof(int);  // + prefetch slack
+    // Candidates per chunk.  WIDE_CHUNK for the one instance of kb_search_lds built for it -- float staging, lists of up to
+    // 8 as packed records in registers, one slab in flight -- when everything known before the tables says that instance
+    // will run; if the tables then say otherwise (too many epochs that cannot be staged, no room for the padded copy),
+    // they are rebuilt for CHUNK.  KBMOD_CHUNK = 8 keeps CHUNK (tests, comparisons).
+    {
+        const uint64_t image_bytes = (uint64_t)a.T * (uint64_t)a.H * (uint64_t)a.W * 8ull;
+        bool wide = want_lds && params.do_sigmag_filter == 0 && a.K <= 8 && n_cands > (uint64_t)CHUNK && n_cands < 65535 &&
+                    a.T < 65535 && (meta->num_bytes == 4 || (flags & 16u) == 0);
+        // (the two-slab instances, see `deep` below, keep CHUNK)
+        if (a.T >= 128 || (a.T > 64 && image_bytes > (1ull << 30)) || (a.T >= 64 && image_bytes > (4ull << 30))) wide = false;
+        if (const char* env = std::getenv("KBMOD_STAGE_DEPTH")) wide = wide && std::atoi(env) != 2;
+        if (const char* env = std::getenv("KBMOD_LIST_MODE")) wide = wide && (std::atoi(env) == 3 || std::atoi(env) == 2);
+        if (const char* env = std::getenv("KBMOD_CHUNK")) wide = wide && std::atoi(env) == WIDE_CHUNK;
+        if (wide) a.chunk = WIDE_CHUNK;
+    }
+    bool wide_has_special = false;
+    int special_epochs = 0;
+    for (bool settled = n_cands == 0; !settled;) {
+        a.n_chunks = (int)((n_cands + a.chunk - 1) / a.chunk);
+        which = 0;
+        const size_t table_bytes = (size_t)a.n_chunks * a.T * a.chunk * sizeof(int2);
+        const size_t off_bytes = ((size_t)a.n_chunks * a.T * a.chunk + 4 * a.chunk) * sizeof(int);  // + prefetch slack
         const size_t box_bytes = (size_t)a.n_chunks * a.T * sizeof(EpochBox);
         const size_t org_bytes = ((size_t)a.n_chunks * a.T + SLAB_REF_SLACK) * sizeof(SlabRef);
-        const size_t fold_bytes = ((size_t)a.n_chunks * a.T + SLAB_REF_SLACK) * CHUNK * sizeof(int);
+        const size_t fold_bytes = ((size_t)a.n_chunks * a.T + SLAB_REF_SLACK) * a.chunk * sizeof(int);
         const size_t chunk_bytes = (size_t)a.n_chunks * sizeof(ChunkInfo);
         // NO_DATA pixel counter [1], unstaged (chunk, epoch) counter [1], staged shift box + tallest slab [5],
         // per-lane (chunk, epoch) counter [1]
@@ -738,17 +765,28 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         table_timer.begin();
         static const int inv_init[8] = {0, 0, INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN, 0, 0};
         KB_HIP_TRY(hipMemcpyAsync(inv, inv_init, sizeof(inv_init), hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL((kb_shift_table_kernel<CHUNK>), dim3(a.n_chunks), dim3(256), 0, stream, cands_dev,
-                           times_dev, a.n_cands, a.T, reinterpret_cast<int2*>(wsc),
-                           reinterpret_cast<ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes),
-                           reinterpret_cast<EpochBox*>(wsc + table_bytes + off_bytes),
-                           reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox, lds_rows, col_quantum);
+        if (a.chunk == WIDE_CHUNK) {
+            hipLaunchKernelGGL((kb_shift_table_kernel<WIDE_CHUNK>), dim3(a.n_chunks), dim3(256), 0, stream, cands_dev,
+                               times_dev, a.n_cands, a.T, reinterpret_cast<int2*>(wsc),
+                               reinterpret_cast<ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes),
+                               reinterpret_cast<EpochBox*>(wsc + table_bytes + off_bytes),
+                               reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox, lds_rows, col_quantum);
+        } else {
+            hipLaunchKernelGGL((kb_shift_table_kernel<CHUNK>), dim3(a.n_chunks), dim3(256), 0, stream, cands_dev,
+                               times_dev, a.n_cands, a.T, reinterpret_cast<int2*>(wsc),
+                               reinterpret_cast<ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes),
+                               reinterpret_cast<EpochBox*>(wsc + table_bytes + off_bytes),
+                               reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox, lds_rows, col_quantum);
+        }
         KB_HIP_TRY(hipGetLastError());
         if (want_lds) {
             // The choice and the apron of the padded copy need six ints back.
             int back[7] = {0, 0, 0, 0, 0, 0, 0};  // unstaged epochs, dx_min, dx_max, dy_min, dy_max, rows_max, per-lane epochs
             KB_HIP_TRY(hipMemcpyAsync(back, n_not_lds, sizeof(back), hipMemcpyDeviceToHost, stream));
             KB_HIP_TRY(hipStreamSynchronize(stream));
+            // (the wide-chunk instance has no path for epochs that are not staged with uniform shifts)
+            wide_has_special = back[0] != 0 || back[6] != 0;
+            special_epochs = back[0] + back[6];
             // An unstaged epoch costs several times a staged one: above 10 % the direct kernel wins.
             const uint64_t n_epochs = (uint64_t)a.n_chunks * (uint64_t)a.T;
             if (std::getenv("KBMOD_DEBUG") != nullptr) {
@@ -849,13 +887,18 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                     const int64_t n_org = (int64_t)a.n_chunks * a.T;
                     hipLaunchKernelGGL(kb_slab_ref_kernel, dim3((unsigned)((n_org + SLAB_REF_SLACK + 255) / 256)), dim3(256), 0, stream,
                                        cold.boxes, a.chunks, n_org, a.T, cold.Hp, a.Wp, cold.px0, cold.py0, (int)pair_bytes,
-                                       slab_refs, a.lds_off, lds_rows, lds_fold);
+                                       slab_refs, a.lds_off, lds_rows, lds_fold, a.chunk);
                     KB_HIP_TRY(hipGetLastError());
                     which = canon ? 2 : 1;
                 }
             }
         }
         table_ms = table_timer.end();
+        if (a.chunk != CHUNK && (which != 2 || wide_has_special)) {
+            a.chunk = CHUNK;  // the instance the wide chunks are for will not (or cannot) run: tables for the others
+        } else {
+            settled = true;
+        }
     }
 
     const bool sigmag = params.do_sigmag_filter != 0;
@@ -930,7 +973,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     bool deep = which == 2 && (a.T >= 128 || (a.T > 64 && padded_copy_bytes > (1ull << 30)) ||
                                (a.T >= 64 && padded_copy_bytes > (4ull << 30)));
     if (const char* env = std::getenv("KBMOD_STAGE_DEPTH")) deep = which == 2 && std::atoi(env) == 2;
-    if (a.K > 32) deep = false;
+    if (a.K > 32 || a.chunk != CHUNK) deep = false;
     a.lists = nullptr;
     int list_mode = 0;
     if (!sigmag && a.K <= 32) {
@@ -1028,6 +1071,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         stats_out->sigmag_literal = 0;
         std::snprintf(stats_out->kernel_name, sizeof(stats_out->kernel_name), "%s", g_kernel_instance);
         stats_out->padded_copy_reused = padded_reused;
+        stats_out->special_epochs = which != 0 ? special_epochs : 0;
         if (cold.sg.totals != nullptr) {
             unsigned long long totals[3] = {0, 0, 0};
             KB_HIP_TRY(hipMemcpyAsync(totals, cold.sg.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));

@@ -224,7 +224,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     using R = RawPair<SF>;
     constexpr int BYTES = 2 * fmt_bytes(SF);
     // the float-staged, depth-1 instances run their epochs through search_lds_asm.h
-    constexpr bool HAND_SCHEDULED = CANON && STAGE_DEPTH == 1 && C == 8;
+    constexpr bool HAND_SCHEDULED = CANON && STAGE_DEPTH == 1 && (C == 8 || C == 16);
     const int T = a.T;
 
     PairF acc[C];  // (psi_sum, phi_sum) as pairs: one v_pk_add_f32 per sample
@@ -264,12 +264,21 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     KB_PROF_MARK(0)
 
     while (chunk < a.chunk_hi) {
+        // This trip's view of the thread's place.  Everything per-lane below derives from a thread index the compiler
+        // cannot see through, so that none of it (lane offsets, the start pixel as doubles for the exact path, ...) is
+        // hoisted out of the loop and held in registers across the hand-scheduled statements, which need them.
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        TileCoords tq = tc;
+        tq.lane = tid & (WAVE - 1);
+        tq.x_i = tc.tx * WAVE + tq.lane;
+        tq.x = tq.x_i + a.x_start_min;
         if constexpr (HAND_SCHEDULED) {
             // Whole groups of this chunk whose staged successors are whole groups of this chunk too: ONE asm statement
             // (KB_LDS_STREAM_*), group changes -- LDS writes landed, barrier, buffers swapped -- inside it, so that slab loads
             // and table words stay in flight across them and a group costs a handful of instructions instead of a set-up, a
             // pipeline fill and a drain.  Needs an even number of epochs per group (chunk_plan's EVEN) and slabs of one
-            // staging round, so that every wave of the block takes this path with at most one piece per slab.
+            // two staging rounds at most, so that every wave of the block takes this path, with none, one or two pieces per slab.
             // (Every read-write operand of these statements is early-clobber: they are written while inputs are still
             // being read, and without the mark an input of equal value -- pairs per group and pairs to the next barrier --
             // is given the same register.)
@@ -278,57 +287,42 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #else
             const int ng = (T - t0) / plan.E - 1;
 #endif
-            if (plan.clean && (plan.E & 1) == 0 && plan.slab_bytes <= stage_round(ROWS) && ng >= 2) {
+            if (plan.clean && (plan.E & 1) == 0 && plan.slab_bytes <= 2 * stage_round(ROWS) && ng >= 2) {
                 KB_PROF_MARK(1)
                 const ConstSlabPtr first = (ConstSlabPtr)(uintptr_t)(a.slabs + (size_t)chunk * T + t0 + plan.E);
                 const int GB = lds_group_bytes(ROWS);
-                uint32_t rb = (uint32_t)(uintptr_t)(smem + buf * GB + (tc.wv * plan.cols + tc.lane) * BYTES);
-                uint32_t wd = (uint32_t)(uintptr_t)(smem + (1 - buf) * GB + 16 * (int)threadIdx.x);
+                uint32_t rb = (uint32_t)(uintptr_t)(smem + buf * GB + (tc.wv * plan.cols + tq.lane) * BYTES);
+                uint32_t wd = (uint32_t)(uintptr_t)(smem + (1 - buf) * GB + 16 * tid);
                 uint32_t dr = (uint32_t)((1 - 2 * buf) * GB);
                 const uint32_t pg = (uint32_t)plan.E >> 1;
                 uint32_t gc = pg, pairs = (uint32_t)ng * pg;
                 const uint32_t es = (uint32_t)(plan.E * plan.stride), st = (uint32_t)plan.stride;
                 const uint32_t go = n_sl.goff[0];
-                const uint32_t k64 = 0x10000u;
+                // (counting statements: groups per 32 epochs -- their NO_DATA shift registers hold 32 samples -- and groups
+                // until they are emptied next)
+                const uint32_t fg = max(1u, (C == 8 ? 32u : 16u) / (uint32_t)plan.E);
+                uint32_t fc = fg;
                 const uint64_t ob = (uint64_t)(uintptr_t)(a.lds_fold + ((size_t)chunk * T + t0) * C);
                 const uint64_t gb = (uint64_t)(uintptr_t)(first + 1);
                 const uint64_t tb = (uint64_t)(uintptr_t)tile_base;
-                const uint64_t b0 = tb + (uint64_t)origin_of(first[0]);
+                // (slabs are as tall as their epoch's shift box: a piece behind a slab's end copies the first slab's instead)
+                const Int4 ref0 = first[0];
+                const uint32_t wp = (uint32_t)(1024 * tc.wv);
+                const uint32_t dl = (uint32_t)ref0.x, dh = (uint32_t)ref0.y;
+                const uint64_t b0 = tb + (uint64_t)origin_of(ref0);
                 const uint32_t tl = (uint32_t)tb, th = (uint32_t)(tb >> 32);
-                if (1024 * tc.wv < plan.slab_bytes) {
-                    if constexpr (FAST) {
-                        asm volatile(KB_LDS_STREAM_FAST_NP1
-                                 : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
-                                   [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [wd] "+&v"(wd), [rb] "+&v"(rb),
-                                   [np] "+&s"(pairs), [gc] "+&s"(gc), [dr] "+&s"(dr)
-                                 : [go] "v"(go), [ob] "s"(ob), [gb] "s"(gb), [b0] "s"(b0), [tl] "s"(tl), [th] "s"(th), [st] "s"(st), [pg] "s"(pg), [es] "s"(es)
-                                 : KB_LDS_LOOP_CLOBBERS);
-                    } else {
-                        asm volatile(KB_LDS_STREAM_COUNT_NP1
-                                 : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
-                                   [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [c0] "+&v"(cntp[0]), [c1] "+&v"(cntp[1]),
-                                   [c2] "+&v"(cntp[2]), [c3] "+&v"(cntp[3]), [wd] "+&v"(wd), [rb] "+&v"(rb),
-                                   [np] "+&s"(pairs), [gc] "+&s"(gc), [dr] "+&s"(dr)
-                                 : [go] "v"(go), [k64] "v"(k64), [ob] "s"(ob), [gb] "s"(gb), [b0] "s"(b0), [tl] "s"(tl), [th] "s"(th), [st] "s"(st), [pg] "s"(pg), [es] "s"(es)
-                                 : KB_LDS_LOOP_CLOBBERS);
-                    }
-                } else {
-                    if constexpr (FAST) {
-                        asm volatile(KB_LDS_STREAM_FAST_NP0
-                                 : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
-                                   [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [wd] "+&v"(wd), [rb] "+&v"(rb),
-                                   [np] "+&s"(pairs), [gc] "+&s"(gc), [dr] "+&s"(dr)
-                                 : [ob] "s"(ob), [gb] "s"(gb), [st] "s"(st), [pg] "s"(pg), [es] "s"(es)
-                                 : KB_LDS_LOOP_CLOBBERS);
-                    } else {
-                        asm volatile(KB_LDS_STREAM_COUNT_NP0
-                                 : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
-                                   [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [c0] "+&v"(cntp[0]), [c1] "+&v"(cntp[1]),
-                                   [c2] "+&v"(cntp[2]), [c3] "+&v"(cntp[3]), [wd] "+&v"(wd), [rb] "+&v"(rb),
-                                   [np] "+&s"(pairs), [gc] "+&s"(gc), [dr] "+&s"(dr)
-                                 : [k64] "v"(k64), [ob] "s"(ob), [gb] "s"(gb), [st] "s"(st), [pg] "s"(pg), [es] "s"(es)
-                                 : KB_LDS_LOOP_CLOBBERS);
-                    }
+                // (a wave's second piece of a slab of more than one staging round: its lane offset, its first byte)
+                const uint32_t gq = n_sl.goff[LDS_SLOTS >= 2 ? 1 : 0];
+                const uint32_t wq = wp + (uint32_t)stage_round(ROWS);
+                // (pieces of every slab this wave copies: the statement holds a body for each)
+                const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)wq < plan.slab_bytes ? 2 : ((int)wp < plan.slab_bytes ? 1 : 0));
+                (void)fc; (void)fg;
+                KB_LDS_RUN_STREAM
+                if constexpr (!FAST) {
+                    // the statement subtracted the NO_DATA samples: add its epochs to both counts of every register
+                    const uint32_t summed = (uint32_t)(ng * plan.E) * 0x10001u;
+#pragma unroll
+                    for (int c = 0; c < C / 2; ++c) cntp[c] += summed;
                 }
                 KB_PROF_MARK(2)
                 t0 += ng * plan.E;
@@ -371,7 +365,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
         };
 
         const ConstIntPtr offs = as_const_ints(a.lds_off + ((size_t)chunk * T + t0) * C);  // offsets for 8-byte pairs
-        const char* cb = smem + buf * lds_group_bytes(ROWS) + (tc.wv * plan.cols + tc.lane) * BYTES;  // this lane's start pixel inside a slab
+        const char* cb = smem + buf * lds_group_bytes(ROWS) + (tc.wv * plan.cols + tq.lane) * BYTES;  // this lane's start pixel inside a slab
         const int n_cur = min(plan.E, T - t0);
         // C samples of one staged epoch with uniform shifts: slab offsets o[] (scalars) -> LDS reads -> sums
         auto no_hook = []() {};
@@ -395,7 +389,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                         raw[c] = *reinterpret_cast<const typename R::type*>(rb + off);
                     }
                 }
-                if (c0 == 0) {
+                if (c0 + HALF >= C) {  // (behind the reads of the LAST half: the hook replaces o[])
                     __builtin_amdgcn_sched_barrier(0);
                     between();
                     __builtin_amdgcn_sched_barrier(0);
@@ -432,7 +426,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             for (int c = 0; c < C / 2; ++c) asm volatile("" : "+v"(cntp[c])::"memory");
         };
         KB_PROF_MARK(1)
-        if (plan.clean) {
+        if (__builtin_expect(plan.clean != 0, 1)) {  // (the other branch is cold: register spills belong there)
             // A block alone on its CU is bound by the chain scalar table fetch -> LDS read -> adds -> slab
             // landed -> LDS write of one epoch (measured 4.9 ms with one block per CU against 7.4 ms with
             // four).  The table words of epoch e + 1 (slab offsets, slab origin) are therefore fetched at
@@ -451,7 +445,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             const int n_both = (n_plan.slab_bytes <= LDS_SLOTS * stage_round(ROWS)) ? min(n_cur, n_next) : 0;
             auto staged_run = [&](auto np_tag) {
                 constexpr int NP = decltype(np_tag)::value;
-                char* wdst = nb + 16 * (int)threadIdx.x;
+                char* wdst = nb + 16 * tid;
                 const char* rptr = cb + e * plan.stride;  // this lane's pixel in the slab being summed
                 int64_t org_nxt = origin_of(n_org[1]);  // origin of the slab whose loads are issued next
                 auto load = [&](Piece (&v)[LDS_SLOTS], int64_t org) {
@@ -545,56 +539,34 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             // whole epoch to land in instead of sitting in front of the sums; two slabs in flight; offsets with the slab's
             // place in its group folded in (SearchArgs::lds_fold), so the lane's read pointer never moves.  Nothing the
             // compiler schedules runs while anything is in flight: the registers involved are fixed and named as clobbers.
-            auto asm_run = [&](auto np_tag) {
-                constexpr int NP = decltype(np_tag)::value;
-                static_assert(NP <= 1 && C == 8 && sizeof(SlabRef) == 16, "search_lds_asm.h");
+            auto asm_run = [&](uint32_t nq_of_wave) {  // pieces of every staged slab this wave copies
+                const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)nq_of_wave);
+                const int wave_piece_of_run = 1024 * tc.wv;
+                static_assert((C == 8 || C == 16) && sizeof(SlabRef) == 16, "search_lds_asm.h");
                 uint32_t pairs = (uint32_t)(n_both - e) >> 1;
                 const uint32_t odd = (uint32_t)(n_both - e) & 1u;
                 const int done = n_both - e;
-                uint32_t wd = (uint32_t)(uintptr_t)(nb + 16 * (int)threadIdx.x + e * n_plan.stride);
+                uint32_t wd = (uint32_t)(uintptr_t)(nb + 16 * tid + e * n_plan.stride);
                 const uint32_t rb = (uint32_t)(uintptr_t)cb;  // this lane's pixel at the start of the group buffer
                 const uint32_t go = n_sl.goff[0];
-                const uint32_t k64 = 0x10000u;
                 const uint64_t ob = (uint64_t)(uintptr_t)(a.lds_fold + ((size_t)chunk * T + t0 + e) * C);
                 const uint64_t gb = (uint64_t)(uintptr_t)(n_org + (e + 1));
                 const uint64_t tb = (uint64_t)(uintptr_t)tile_base;
                 const uint64_t b0 = tb + (uint64_t)org_cur;
                 const uint32_t tl = (uint32_t)tb, th = (uint32_t)(tb >> 32);
+                const uint32_t wp = (uint32_t)wave_piece_of_run;
+                const uint32_t dl = (uint32_t)(uint64_t)org_cur, dh = (uint32_t)((uint64_t)org_cur >> 32);
                 const uint32_t st = (uint32_t)n_plan.stride;
-                if constexpr (FAST) {
-                    if constexpr (NP == 1) {
-                        asm volatile(KB_LDS_LOOP_FAST_NP1
-                                     : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
-                                       [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [wd] "+&v"(wd), [np] "+&s"(pairs)
-                                     : [rb] "v"(rb), [go] "v"(go), [ob] "s"(ob), [gb] "s"(gb), [b0] "s"(b0), [tl] "s"(tl), [th] "s"(th),
-                                       [st] "s"(st), [od] "s"(odd)
-                                     : KB_LDS_LOOP_CLOBBERS);
-                    } else {
-                        asm volatile(KB_LDS_LOOP_FAST_NP0
-                                     : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
-                                       [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [wd] "+&v"(wd), [np] "+&s"(pairs)
-                                     : [rb] "v"(rb), [ob] "s"(ob), [gb] "s"(gb), [st] "s"(st), [od] "s"(odd)
-                                     : KB_LDS_LOOP_CLOBBERS);
-                    }
-                } else {
-                    if constexpr (NP == 1) {
-                        asm volatile(KB_LDS_LOOP_COUNT_NP1
-                                     : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
-                                       [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [c0] "+&v"(cntp[0]), [c1] "+&v"(cntp[1]),
-                                       [c2] "+&v"(cntp[2]), [c3] "+&v"(cntp[3]), [wd] "+&v"(wd), [np] "+&s"(pairs)
-                                     : [rb] "v"(rb), [go] "v"(go), [k64] "v"(k64), [ob] "s"(ob), [gb] "s"(gb), [b0] "s"(b0), [tl] "s"(tl),
-                                       [th] "s"(th), [st] "s"(st), [od] "s"(odd)
-                                     : KB_LDS_LOOP_CLOBBERS);
-                    } else {
-                        asm volatile(KB_LDS_LOOP_COUNT_NP0
-                                     : [a0] "+&v"(acc[0]), [a1] "+&v"(acc[1]), [a2] "+&v"(acc[2]), [a3] "+&v"(acc[3]), [a4] "+&v"(acc[4]),
-                                       [a5] "+&v"(acc[5]), [a6] "+&v"(acc[6]), [a7] "+&v"(acc[7]), [c0] "+&v"(cntp[0]), [c1] "+&v"(cntp[1]),
-                                       [c2] "+&v"(cntp[2]), [c3] "+&v"(cntp[3]), [wd] "+&v"(wd), [np] "+&s"(pairs)
-                                     : [rb] "v"(rb), [k64] "v"(k64), [ob] "s"(ob), [gb] "s"(gb), [st] "s"(st), [od] "s"(odd)
-                                     : KB_LDS_LOOP_CLOBBERS);
-                    }
-                }
+                const uint32_t gq = n_sl.goff[LDS_SLOTS >= 2 ? 1 : 0];
+                const uint32_t wq = wp + (uint32_t)stage_round(ROWS);
+                KB_LDS_RUN_LOOP
                 e += done;
+                if constexpr (!FAST) {
+                    // (the counting statements subtract the NO_DATA samples from the counts, see search_lds_asm.h)
+                    const uint32_t summed = (uint32_t)done * 0x10001u;
+#pragma unroll
+                    for (int c = 0; c < C / 2; ++c) cntp[c] += summed;
+                }
                 // hand over to the loop below: plain offsets and origin of epoch / slab e, from the tables it walks.
                 // Unconditional on purpose: with e == n_cur the values are never used and the reads land in the tables'
                 // slack (off_bytes' 4 * CHUNK ints, SLAB_REF_SLACK references), but the straight-line form measured
@@ -609,20 +581,15 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             };
             if (n_both > 0) {
                 const int wave_piece = 1024 * tc.wv;
-                if (LDS_SLOTS >= 2 && wave_piece + stage_round(ROWS) < n_plan.slab_bytes) {
+                if constexpr (HAND_SCHEDULED) {
+                    asm_run((LDS_SLOTS >= 2 && wave_piece + stage_round(ROWS) < n_plan.slab_bytes) ? 2u
+                                                                                                    : (wave_piece < n_plan.slab_bytes ? 1u : 0u));
+                } else if (LDS_SLOTS >= 2 && wave_piece + stage_round(ROWS) < n_plan.slab_bytes) {
                     staged_run(std::integral_constant<int, (LDS_SLOTS >= 2 ? 2 : 1)>{});
                 } else if (wave_piece < n_plan.slab_bytes) {
-                    if constexpr (HAND_SCHEDULED) {
-                        asm_run(std::integral_constant<int, 1>{});
-                    } else {
-                        staged_run(std::integral_constant<int, 1>{});
-                    }
+                    staged_run(std::integral_constant<int, 1>{});
                 } else {
-                    if constexpr (HAND_SCHEDULED) {
-                        asm_run(std::integral_constant<int, 0>{});
-                    } else {
-                        staged_run(std::integral_constant<int, 0>{});
-                    }
+                    staged_run(std::integral_constant<int, 0>{});
                 }
             }
             KB_PROF_MARK(2)
@@ -645,20 +612,29 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             }
         } else {
-            for (int e = 0; e < n_cur; ++e) {
-                const bool staging = next_load(e);
-                int o[C];
+            // A chunk with epochs that are not staged, or staged without uniform shifts (rare: a shift within 1e-6 of a
+            // half pixel, a footprint larger than a slab).  The instance for chunks of WIDE_CHUNK candidates has no such
+            // path: the host gives it candidate lists without such epochs only (search_kernels.hip) -- inlined next to
+            // 2 * WIDE_CHUNK accumulators, the per-lane predictions in double precision set the register budget of the
+            // whole kernel, and the allocator then keeps accumulators and lists in scratch memory everywhere.
+            if constexpr (C == CHUNK) {
+                for (int e = 0; e < n_cur; ++e) {
+                    const bool staging = next_load(e);
+                    int o[C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = offs[e * C + c];
-                if (o[0] >= 0) {
-                    sum_epoch(o, cb + e * plan.stride, no_hook);
-                } else {
-                    special_epoch<C, SF, CANON>(a, tc, chunk, t0 + e, o[0] == LDS_OFF_PER_LANE,
-                                                smem + buf * lds_group_bytes(ROWS) + e * plan.stride, acc, cntp);
+                    for (int c = 0; c < C; ++c) o[c] = offs[e * C + c];
+                    if (o[0] >= 0) {
+                        sum_epoch(o, cb + e * plan.stride, no_hook);
+                    } else {
+                        special_epoch<C, SF, CANON>(a, tq, chunk, t0 + e, o[0] == LDS_OFF_PER_LANE,
+                                                    smem + buf * lds_group_bytes(ROWS) + e * plan.stride, acc, cntp);
+                    }
+                    pin_sums();
+                    if (staging) next_write(e);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
                 }
-                pin_sums();
-                if (staging) next_write(e);
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            } else {
+                __builtin_trap();
             }
         }
         for (int e = n_cur; e < n_next; ++e) {  // the next group holds more epochs than this one
@@ -763,15 +739,15 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
 }
 
 // Launch of one instance (two group buffers beyond the default 64 KiB of dynamic LDS need the attribute raised).
-template <int KS, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, int STAGE_DEPTH = 1>
+template <int KS, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, int STAGE_DEPTH = 1, int C = CHUNK>
 static void launch_lds(const SearchArgs& a, hipStream_t stream) {
     constexpr size_t lds_bytes = 2 * lds_group_bytes(ROWS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb_search_lds<KS, CHUNK, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb_search_lds<KS, C, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((kb_search_lds<KS, CHUNK, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH>), dim3(a.n_tiles), dim3(ROWS * WAVE), lds_bytes,
+    hipLaunchKernelGGL((kb_search_lds<KS, C, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH>), dim3(a.n_tiles), dim3(ROWS * WAVE), lds_bytes,
                        stream, a);
     char name[96];
-    std::snprintf(name, sizeof(name), "kb::kb_search_lds<%d, %d, %d, %d, %s, %s, %d, %d>", KS, CHUNK, ROWS, NB, CANON ? "true" : "false",
+    std::snprintf(name, sizeof(name), "kb::kb_search_lds<%d, %d, %d, %d, %s, %s, %d, %d>", KS, C, ROWS, NB, CANON ? "true" : "false",
                   SIGMAG ? "true" : "false", LM, STAGE_DEPTH);
     note_kernel_instance(name);
 }

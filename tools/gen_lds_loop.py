@@ -1,146 +1,280 @@
 #!/usr/bin/env python3
-"""Writes kbmod_amd/csrc/search_lds_asm.h: the hand-scheduled summing loop of kb_search_lds as inline-asm strings.
+"""Writes kbmod_amd/csrc/search_lds_asm.h: the hand-scheduled summing loops of kb_search_lds as inline-asm statements.
 
-Register plan inside the asm statement (all named in its clobber list, so the compiler keeps nothing in them across it):
-  s[68:75]  offsets of the even epochs (set A)      s[76:83]  offsets of the odd epochs (set B)
-  s[84:85]  origin of the slab requested in even epochs (gA)   s[86:87]  ... in odd epochs (gB)
-  s[88:89]  address of the slab being requested     s90 / s91  running byte offsets into the offset / slab-reference tables
-  v[100:103] piece of the slab delivered in even epochs (va)   v[104:107] ... in odd epochs (vb)
-  v[108:123] the eight (psi, phi) samples of the epoch         v124  address / count temporary
+Two families, each for chunks of 8 and of 16 candidates (C), with and without observation counts (COUNT / FAST), for waves
+that copy a piece of every staged slab and waves that do not (NP1 / NP0):
+
+  LOOP    one group of epochs (search_lds.h, asm_run): two epochs per trip, the table words of epoch e + 2 fetched BEHIND the
+          wait for epoch e's LDS reads, into the registers those reads just consumed -- scalar loads share the LDS counter and
+          return out of order, so any wait for them waits for everything: this way they have a whole epoch to land in --,
+          two slabs in flight, nothing the compiler schedules while anything is in flight.
+  STREAM  a run of whole groups inside one chunk (every group full, staging a full group of the same chunk, an even number
+          of epochs per group): the same trip, with the group change -- LDS writes landed, barrier, the read pointer to the
+          other buffer, the write pointer back to slot 0 of the one just read -- inside the statement, so that slab loads
+          and table words stay in flight across it.
+
+Registers inside a statement (all named in its clobber list, the compiler keeps nothing in them across it):
+
+                                   C = 8        C = 16
+  offsets of the even epochs (A)   s[68:75]     s[36:51]      origin/bytes of the slab requested in even epochs (gA)  s[84:87]  s[68:71]
+  offsets of the odd epochs (B)    s[76:83]     s[52:67]      ... in odd epochs (gB)                                  s[92:95]  s[72:75]
+  address of the slab requested    s[88:89]     s[76:77]      running byte offsets into the two tables               s90, s91  s78, s79
+  v[100:103] / v[104:107]  piece of the slab delivered in even / odd epochs (va / vb)
+  v[108:123]               eight (psi, phi) samples: a chunk of 16 is summed in two batches of eight
+  v124                     address / count temporary
+  COUNT only: one register per candidate (v[92:99], C = 16: v[84:99]) as a shift register of the samples' NO_DATA bits: a
+      sample costs ONE v_alignbit_b32 (bits = bits << 1 | sign(phi); NO_DATA is (+0, -0) and no valid phi is negative).  The
+      registers are emptied -- their population counts subtracted from the packed observation counts, to which the caller
+      adds the epochs of the statement -- at its end and at least every 32 epochs inside it.
+
+A slab is as tall as ITS epoch's shift box (SlabRef::bytes), not as the chunk's tallest: a wave whose 1 KiB piece starts
+behind the slab's end (%[wp] >= bytes) reads the statement's first slab instead -- lines its neighbours hold in cache -- and
+writes that where the piece would have gone, behind every row the epoch's offsets reach; the counters of the two copies in
+flight stay the same for every wave and epoch.
+
+Every read-write operand is early-clobber: the statements write them while inputs are still being read.
 """
 import os
 
-A, B = 68, 76
-RAW = [108 + 2 * c for c in range(8)]
+
+class Plan:
+    def __init__(self, C):
+        self.C = C
+        if C == 8:
+            self.A, self.B, self.gA, self.gB, self.addr, self.o1, self.o2 = 68, 76, 84, 92, 88, 90, 91
+            self.sregs = range(68, 96)
+            self.bits = [92 + c for c in range(8)]
+        else:
+            self.A, self.B, self.gA, self.gB, self.addr, self.o1, self.o2 = 36, 52, 68, 72, 76, 78, 79
+            self.sregs = range(36, 80)   # (s32 - s35 are the stack registers of a kernel that has scratch memory)
+            self.bits = [84 + c for c in range(8)] * 2   # candidate k and k + 8 share a register (alternate bits)
+        self.row = 4 * C                    # bytes of a table row (one epoch's offsets)
+        self.loadx = f"s_load_dwordx{C}"
+        self.raw = [108 + 2 * c for c in range(8)]
+
+    def nbatch(self, fast, np_):
+        # samples per batch: eight, or four where the second piece of a slab takes the upper half of the sample registers
+        return 4 if (np_ == 2 and not fast) else 8
+
+    def second(self, fast):
+        # registers of a wave's second piece of the slabs delivered in even / odd epochs
+        return ("v[92:95]", "v[96:99]") if fast else ("v[116:119]", "v[120:123]")
+
+    def bit_regs(self):
+        return sorted(set(self.bits))
 
 
-def reads(base):
-    return "".join(f'"v_add_u32 v124, s{base + c}, %[rb]\\n\\tds_read_b64 v[{RAW[c]}:{RAW[c] + 1}], v124\\n\\t"\n' for c in range(8))
+def ln(text):
+    return f'"{text}\\n\\t"\n'
 
 
-def adds_fast():
-    return "".join(f'"v_pk_add_f32 %[a{c}], %[a{c}], v[{RAW[c]}:{RAW[c] + 1}]\\n\\t"\n' for c in range(8))
+def reads(p, base, batch, nb=8):
+    return "".join(ln(f"v_add_u32 v124, s{base + nb * batch + c}, %[rb]\\n\\tds_read_b64 v[{p.raw[c]}:{p.raw[c] + 1}], v124") for c in range(nb))
 
 
-def adds_count():
-    # per pair j: candidate 2j counts in the low half of cnt j (carry-in), 2j + 1 in the high half (0x10000 through a select);
-    # two instructions between a compare and the reader of its vcc where packed adds are left to fill the gap, s_nop 1 where not
-    out = []
-    pk = [f'"v_pk_add_f32 %[a{c}], %[a{c}], v[{RAW[c]}:{RAW[c] + 1}]\\n\\t"\n' for c in range(8)]
-    fill = [pk[0] + pk[1], pk[2] + pk[3], pk[4] + pk[5], pk[6] + pk[7]] + ['"s_nop 1\\n\\t"\n'] * 4
-    f = 0
-    for j in range(4):
-        hi_y, lo_y = RAW[2 * j + 1] + 1, RAW[2 * j] + 1
-        out.append(f'"v_cmp_ne_u32 vcc, 0x80000000, v{hi_y}\\n\\t"\n')
-        out.append(fill[f]); f += 1
-        out.append('"v_cndmask_b32 v124, 0, %[k64], vcc\\n\\t"\n')
-        out.append(f'"v_cmp_ne_u32 vcc, 0x80000000, v{lo_y}\\n\\t"\n')
-        out.append(fill[f]); f += 1
-        out.append(f'"v_addc_co_u32 %[c{j}], vcc, v124, %[c{j}], vcc\\n\\t"\n')
-    return "".join(out)
+def adds(p, fast, batch, nb=8):
+    out = ""
+    for c in range(nb):
+        k = nb * batch + c
+        out += ln(f"v_pk_add_f32 %[a{k}], %[a{k}], v[{p.raw[c]}:{p.raw[c] + 1}]"
+                  + ("" if fast else f"\\n\\tv_alignbit_b32 v{p.bits[k]}, v{p.bits[k]}, v{p.raw[c] + 1}, 31"))
+    return out
 
 
-def half(which, fast, np_, request, refill):
-    base = A if which == "A" else B
-    g = 84 if which == "A" else 86
+def zero_bits(p):
+    return "".join(ln(f"v_mov_b32 v{b}, 0") for b in p.bit_regs())
+
+
+def flush_bits(p, zero):
+    # candidate 2j in the low half of count j, 2j + 1 in the high half
+    out = ""
+    if p.C == 8:
+        for j in range(4):
+            out += ln(f"v_bcnt_u32_b32 v124, v{p.bits[2 * j + 1]}, 0\\n\\tv_lshlrev_b32 v124, 16, v124\\n\\t"
+                      f"v_bcnt_u32_b32 v124, v{p.bits[2 * j]}, v124\\n\\tv_sub_u32 %[c{j}], %[c{j}], v124")
+    else:
+        # register r holds candidate r in its odd bits and candidate r + 8 in its even bits (the later one of an epoch);
+        # v108 / v109 are free here (no sample is in flight at a tally)
+        for j in range(4):
+            lo, hi = p.bits[2 * j], p.bits[2 * j + 1]
+            for mask, cnt in (("0xaaaaaaaa", j), ("0x55555555", j + 4)):
+                out += ln(f"v_and_b32 v124, {mask}, v{lo}\\n\\tv_and_b32 v108, {mask}, v{hi}\\n\\t"
+                          f"v_bcnt_u32_b32 v124, v124, 0\\n\\tv_bcnt_u32_b32 v108, v108, 0\\n\\t"
+                          f"v_lshl_add_u32 v124, v108, 16, v124\\n\\tv_sub_u32 %[c{cnt}], %[c{cnt}], v124")
+    return out + (zero_bits(p) if zero else "")
+
+
+def half(p, which, fast, np_, request, refill):
+    base = p.A if which == "A" else p.B
+    g = p.gA if which == "A" else p.gB
     mine, other = ("v[100:103]", "v[104:107]") if which == "A" else ("v[104:107]", "v[100:103]")
-    imm8, imm2 = ("", "") if which == "A" else (" offset:0x20", " offset:0x10")
+    sa, sb = p.second(fast)
+    mine2, other2 = (sa, sb) if which == "A" else (sb, sa)
+    imm1, imm2 = ("", "") if which == "A" else (f" offset:{hex(p.row)}", " offset:0x10")
     s = ""
     if request and np_:
-        s += f'"s_add_u32 s88, %[tl], s{g}\\n\\ts_addc_u32 s89, %[th], s{g + 1}\\n\\t"\n'
-        s += f'"global_load_dwordx4 {other}, %[go], s[88:89]\\n\\t"\n'
-    s += reads(base)
-    s += '"s_waitcnt lgkmcnt(0)\\n\\t"\n'
-    if refill:
-        s += f'"s_load_dwordx8 s[{base}:{base + 7}], %[ob], s90{imm8}\\n\\t"\n'
-        s += f'"s_load_dwordx2 s[{g}:{g + 1}], %[gb], s91{imm2}\\n\\t"\n'
-    s += adds_fast() if fast else adds_count()
+        for piece in range(np_):
+            wp, go, dst = (("%[wp]", "%[go]", other), ("%[wq]", "%[gq]", other2))[piece]
+            s += ln(f"s_cmp_lt_u32 {wp}, s{g + 2}\\n\\ts_cselect_b32 s{p.addr}, s{g}, %[dl]\\n\\ts_cselect_b32 s{p.addr + 1}, s{g + 1}, %[dh]")
+            s += ln(f"s_add_u32 s{p.addr}, %[tl], s{p.addr}\\n\\ts_addc_u32 s{p.addr + 1}, %[th], s{p.addr + 1}")
+            s += ln(f"global_load_dwordx4 {dst}, {go}, s[{p.addr}:{p.addr + 1}]")
+    nb = p.nbatch(fast, np_)
+    batches = p.C // nb
+    for b in range(batches):
+        s += reads(p, base, b, nb)
+        s += ln("s_waitcnt lgkmcnt(0)")
+        if b == batches - 1 and refill:
+            s += ln(f"{p.loadx} s[{base}:{base + p.C - 1}], %[ob], s{p.o1}{imm1}")
+            if np_:
+                s += ln(f"s_load_dwordx4 s[{g}:{g + 3}], %[gb], s{p.o2}{imm2}")
+        s += adds(p, fast, b, nb)
     if np_:
-        s += f'"s_waitcnt vmcnt({1 if request else 0})\\n\\t"\n'
-        s += f'"ds_write_b128 %[wd], {mine}\\n\\t"\n'
-    s += '"v_add_u32 %[wd], %[st], %[wd]\\n\\t"\n'
+        s += ln(f"s_waitcnt vmcnt({np_ if request else 0})")
+        s += ln(f"ds_write_b128 %[wd], {mine}")
+        if np_ == 2:
+            s += ln(f"ds_write_b128 %[wd], {mine2} offset:%[so]")
+    s += ln("v_add_u32 %[wd], %[st], %[wd]")
     return s
 
 
-def body(fast, np_):
-    s = ""
-    # prologue: both sets of table words, the first slab's piece
-    s += f'"s_load_dwordx8 s[{A}:{A + 7}], %[ob], 0x0\\n\\t"\n'
-    s += f'"s_load_dwordx8 s[{B}:{B + 7}], %[ob], 0x20\\n\\t"\n'
-    s += '"s_load_dwordx2 s[84:85], %[gb], 0x0\\n\\t"\n'
-    s += '"s_load_dwordx2 s[86:87], %[gb], 0x10\\n\\t"\n'
-    s += '"s_mov_b32 s90, 0x40\\n\\ts_mov_b32 s91, 0x20\\n\\t"\n'
+def prologue(p, fast, np_):
+    s = "" if fast else zero_bits(p)
+    s += ln(f"{p.loadx} s[{p.A}:{p.A + p.C - 1}], %[ob], 0x0")
+    s += ln(f"{p.loadx} s[{p.B}:{p.B + p.C - 1}], %[ob], {hex(p.row)}")
     if np_:
-        s += '"global_load_dwordx4 v[100:103], %[go], %[b0]\\n\\t"\n'
-    s += '"s_waitcnt lgkmcnt(0)\\n\\t"\n'
-    s += '"s_cmp_eq_u32 %[np], 0\\n\\ts_cbranch_scc1 kb_tail_%=\\n"\n'
-    s += '"kb_loop_%=:\\n\\t"\n'
-    s += half("A", fast, np_, True, True)
-    s += half("B", fast, np_, True, True)
-    s += '"s_add_u32 s90, s90, 0x40\\n\\ts_add_u32 s91, s91, 0x20\\n\\t"\n'
-    s += '"s_sub_u32 %[np], %[np], 1\\n\\ts_cmp_lg_u32 %[np], 0\\n\\ts_cbranch_scc1 kb_loop_%=\\n"\n'
-    s += '"kb_tail_%=:\\n\\t"\n'
-    s += '"s_cmp_eq_u32 %[od], 0\\n\\ts_cbranch_scc1 kb_end_%=\\n\\t"\n'
-    s += half("A", fast, np_, False, False)
-    s += '"kb_end_%=:\\n\\t"\n'
+        s += ln(f"s_load_dwordx4 s[{p.gA}:{p.gA + 3}], %[gb], 0x0")
+        s += ln(f"s_load_dwordx4 s[{p.gB}:{p.gB + 3}], %[gb], 0x10")
+    s += ln(f"s_mov_b32 s{p.o1}, {hex(2 * p.row)}\\n\\ts_mov_b32 s{p.o2}, 0x20")
+    if np_:
+        s += ln("global_load_dwordx4 v[100:103], %[go], %[b0]")
+    if np_ == 2:
+        s += ln(f"global_load_dwordx4 {p.second(fast)[0]}, %[gq], %[b0]")
+    s += ln("s_waitcnt lgkmcnt(0)")
+    return s
+
+
+def advance(p):
+    return ln(f"s_add_u32 s{p.o1}, s{p.o1}, {hex(2 * p.row)}\\n\\ts_add_u32 s{p.o2}, s{p.o2}, 0x20")
+
+
+def loop(p, fast, np_):
+    s = prologue(p, fast, np_)
+    s += f'"s_cmp_eq_u32 %[np], 0\\n\\ts_cbranch_scc1 kb_tail_%=_{np_}\\n"\n'
+    s += f'"kb_loop_%=_{np_}:\\n\\t"\n'
+    s += half(p, "A", fast, np_, True, True)
+    s += half(p, "B", fast, np_, True, True)
+    s += advance(p)
+    s += f'"s_sub_u32 %[np], %[np], 1\\n\\ts_cmp_lg_u32 %[np], 0\\n\\ts_cbranch_scc1 kb_loop_%=_{np_}\\n"\n'
+    s += f'"kb_tail_%=_{np_}:\\n\\t"\n'
+    s += ln(f"s_cmp_eq_u32 %[od], 0\\n\\ts_cbranch_scc1 kb_end_%=_{np_}")
+    s += half(p, "A", fast, np_, False, False)
+    s += f'"kb_end_%=_{np_}:\\n\\t"\n'
+    return s
+
+
+def stream(p, fast, np_):
+    """%[np]: pairs of epochs in total (>= 1), %[gc]: pairs until the next barrier, %[pg]: pairs per group, %[dr]: distance
+    from the buffer being read to the other one, %[es]: bytes of a group of staged slabs; COUNT: %[fc] groups until the
+    shift registers are emptied, %[fg] groups per 32 epochs."""
+    s = prologue(p, fast, np_)
+    s += f'"s_cmp_eq_u32 %[np], 1\\n\\ts_cbranch_scc1 kb_sfin_%=_{np_}\\n"\n'
+    s += f'"kb_sloop_%=_{np_}:\\n\\t"\n'
+    s += half(p, "A", fast, np_, True, True)
+    s += half(p, "B", fast, np_, True, True)
+    s += advance(p)
+    s += ln(f"s_sub_u32 %[gc], %[gc], 1\\n\\ts_cmp_lg_u32 %[gc], 0\\n\\ts_cbranch_scc1 kb_snb_%=_{np_}")
+    s += ln("s_waitcnt lgkmcnt(0)\\n\\ts_barrier")
+    s += ln("v_add_u32 %[rb], %[dr], %[rb]\\n\\tv_subrev_u32 %[wd], %[es], %[wd]\\n\\tv_subrev_u32 %[wd], %[dr], %[wd]")
+    s += ln("s_sub_u32 %[dr], 0, %[dr]\\n\\ts_mov_b32 %[gc], %[pg]")
+    if not fast:
+        s += ln(f"s_sub_u32 %[fc], %[fc], 1\\n\\ts_cmp_lg_u32 %[fc], 0\\n\\ts_cbranch_scc1 kb_snb_%=_{np_}")
+        s += flush_bits(p, True)
+        s += ln("s_mov_b32 %[fc], %[fg]")
+    s += '"\\n"\n'
+    s += f'"kb_snb_%=_{np_}:\\n\\t"\n'
+    s += f'"s_sub_u32 %[np], %[np], 1\\n\\ts_cmp_lg_u32 %[np], 1\\n\\ts_cbranch_scc1 kb_sloop_%=_{np_}\\n"\n'
+    s += f'"kb_sfin_%=_{np_}:\\n\\t"\n'
+    s += half(p, "A", fast, np_, True, False)
+    s += half(p, "B", fast, np_, False, False)
+    return s
+
+
+def combined(p, body, fast):
+    """One statement for every wave: %[nq] (0, 1 or 2: the pieces of each slab this wave copies) picks the body."""
+    s = ln("s_cmp_eq_u32 %[nq], 2\\n\\ts_cbranch_scc1 kb_two_%=\\n\\ts_cmp_eq_u32 %[nq], 1\\n\\ts_cbranch_scc1 kb_one_%=")
+    s += body(p, fast, 0)
+    s += '"s_branch kb_done_%=\\n"\n"kb_one_%=:\\n\\t"\n'
+    s += body(p, fast, 1)
+    s += '"s_branch kb_done_%=\\n"\n"kb_two_%=:\\n\\t"\n'
+    s += body(p, fast, 2)
+    s += '"\\n"\n"kb_done_%=:\\n\\t"\n'
+    if not fast:
+        s += flush_bits(p, False)
     s += '"s_waitcnt vmcnt(0) lgkmcnt(0)"\n'
     return s
 
 
-def stream(fast, np_):
-    """A run of whole groups inside one chunk (every group full, staging a full group of the same chunk, an even number of
-    epochs per group): the same two-epoch trip, with the group change -- LDS writes landed, barrier, the read pointer to the
-    other buffer, the write pointer back to slot 0 of the one just read -- inside the statement, so the slab loads and the
-    table words stay in flight across it.  %[np]: pairs in total (>= 1), %[gc]: pairs until the next barrier, %[pg]: pairs per
-    group, %[dr]: distance from the buffer being read to the other one, %[es]: bytes of a group of staged slabs."""
-    s = ""
-    s += f'"s_load_dwordx8 s[{A}:{A + 7}], %[ob], 0x0\\n\\t"\n'
-    s += f'"s_load_dwordx8 s[{B}:{B + 7}], %[ob], 0x20\\n\\t"\n'
-    s += '"s_load_dwordx2 s[84:85], %[gb], 0x0\\n\\t"\n'
-    s += '"s_load_dwordx2 s[86:87], %[gb], 0x10\\n\\t"\n'
-    s += '"s_mov_b32 s90, 0x40\\n\\ts_mov_b32 s91, 0x20\\n\\t"\n'
-    if np_:
-        s += '"global_load_dwordx4 v[100:103], %[go], %[b0]\\n\\t"\n'
-    s += '"s_waitcnt lgkmcnt(0)\\n\\t"\n'
-    s += '"s_cmp_eq_u32 %[np], 1\\n\\ts_cbranch_scc1 kb_sfin_%=\\n"\n'
-    s += '"kb_sloop_%=:\\n\\t"\n'
-    s += half("A", fast, np_, True, True)
-    s += half("B", fast, np_, True, True)
-    s += '"s_add_u32 s90, s90, 0x40\\n\\ts_add_u32 s91, s91, 0x20\\n\\t"\n'
-    s += '"s_sub_u32 %[gc], %[gc], 1\\n\\ts_cmp_lg_u32 %[gc], 0\\n\\ts_cbranch_scc1 kb_snb_%=\\n\\t"\n'
-    s += '"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\\n\\t"\n'
-    s += '"v_add_u32 %[rb], %[dr], %[rb]\\n\\tv_subrev_u32 %[wd], %[es], %[wd]\\n\\tv_subrev_u32 %[wd], %[dr], %[wd]\\n\\t"\n'
-    s += '"s_sub_u32 %[dr], 0, %[dr]\\n\\ts_mov_b32 %[gc], %[pg]\\n"\n'
-    s += '"kb_snb_%=:\\n\\t"\n'
-    s += '"s_sub_u32 %[np], %[np], 1\\n\\ts_cmp_lg_u32 %[np], 1\\n\\ts_cbranch_scc1 kb_sloop_%=\\n"\n'
-    s += '"kb_sfin_%=:\\n\\t"\n'
-    s += half("A", fast, np_, True, False)
-    s += half("B", fast, np_, False, False)
-    s += '"s_waitcnt vmcnt(0) lgkmcnt(0)"\n'
-    return s
+def operands(p, family, fast):
+    outs = [f'[a{c}] "+&v"(acc[{c}])' for c in range(p.C)]
+    if not fast:
+        outs += [f'[c{j}] "+&v"(cntp[{j}])' for j in range(p.C // 2)]
+    outs.append('[wd] "+&v"(wd)')
+    ins = []
+    if family == "STREAM":
+        outs += ['[rb] "+&v"(rb)', '[np] "+&s"(pairs)', '[gc] "+&s"(gc)', '[dr] "+&s"(dr)']
+        if not fast:
+            outs.append('[fc] "+&s"(fc)')
+    else:
+        outs.append('[np] "+&s"(pairs)')
+        ins.append('[rb] "v"(rb)')
+    ins += ['[go] "v"(go)', '[gq] "v"(gq)', '[nq] "s"(nq)', '[ob] "s"(ob)', '[gb] "s"(gb)', '[b0] "s"(b0)', '[tl] "s"(tl)',
+            '[th] "s"(th)', '[wp] "s"(wp)', '[dl] "s"(dl)', '[dh] "s"(dh)', '[wq] "s"(wq)', '[so] "i"(stage_round(ROWS))',
+            '[st] "s"(st)']
+    if family == "STREAM":
+        ins += ['[pg] "s"(pg)', '[es] "s"(es)']
+        if not fast:
+            ins.append('[fg] "s"(fg)')
+    else:
+        ins.append('[od] "s"(odd)')
+    return ", ".join(outs), ", ".join(ins)
+
+
+def clobbers(p, fast):
+    v = [f'"v{i}"' for i in range(92, 100)] if fast else [f'"v{b}"' for b in p.bit_regs()]
+    v += [f'"v{i}"' for i in range(100, 125)]
+    return ", ".join(v + [f'"s{i}"' for i in p.sregs] + ['"vcc"', '"scc"', '"memory"'])
 
 
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = ['// GENERATED by tools/gen_lds_loop.py -- the hand-scheduled summing loop of kb_search_lds (search_lds.h, streamlined run).',
-           '// One asm statement runs a whole group: two epochs per trip, table words of epoch e + 2 fetched BEHIND the wait for',
-           '// epoch e\'s LDS reads (a whole epoch for the scalar loads to land in), two slabs in flight, no compiler-scheduled',
-           '// code while anything is in flight.  Register plan: see the generator.',
+    out = ['// GENERATED by tools/gen_lds_loop.py -- the hand-scheduled summing loops of kb_search_lds (search_lds.h: asm_run and the',
+           '// run of whole groups at the top of the group loop).  Register plan, schedule and the reasons: the generator\'s header.',
+           '// KB_LDS_RUN_<LOOP|STREAM> expand, inside lds_search_tile, to the statement for its C and FAST; a statement holds the',
+           '// bodies for waves that copy no, one or two pieces of every slab and picks by nq; it names the variables of its call',
+           '// site (acc, cntp, wd, rb, pairs, gc, dr, fc, go, gq, nq, ob, gb, b0, tl, th, wp, wq, dl, dh, st, pg, es, fg, odd).',
            '#ifndef KB_SEARCH_LDS_ASM_H_', '#define KB_SEARCH_LDS_ASM_H_', '']
-    for fast in (True, False):
-        for np_ in (0, 1):
-            out.append(f'#define KB_LDS_LOOP_{"FAST" if fast else "COUNT"}_NP{np_} \\')
-            lines = body(fast, np_).rstrip("\n").split("\n")
-            out.append(" \\\n".join("    " + ln for ln in lines))
-            out.append('')
-            out.append(f'#define KB_LDS_STREAM_{"FAST" if fast else "COUNT"}_NP{np_} \\')
-            lines = stream(fast, np_).rstrip("\n").split("\n")
-            out.append(" \\\n".join("    " + ln for ln in lines))
-            out.append('')
-    out.append('#define KB_LDS_LOOP_CLOBBERS \\')
-    regs = [f'"v{i}"' for i in range(100, 125)] + [f'"s{i}"' for i in range(68, 92)] + ['"vcc"', '"scc"', '"memory"']
-    out.append("    " + ", ".join(regs))
-    out.append('')
+    for C in (8, 16):
+        p = Plan(C)
+        for family, body in (("LOOP", loop), ("STREAM", stream)):
+            for fast in (True, False):
+                kind = "FAST" if fast else "COUNT"
+                outs, ins = operands(p, family, fast)
+                lines = combined(p, body, fast).rstrip("\n").split("\n")
+                out.append(f'#define KB_LDS_{family}_{kind}_C{C} \\')
+                out.append("    asm volatile( \\")
+                out.append(" \\\n".join("        " + x for x in lines) + " \\")
+                out.append(f"        : {outs} \\")
+                out.append(f"        : {ins} \\")
+                out.append(f"        : {clobbers(p, fast)});")
+                out.append('')
+    for family in ("LOOP", "STREAM"):
+        out.append(f'#define KB_LDS_RUN_{family} \\')
+        out.append('    if constexpr (C == 8) { \\')
+        out.append(f'        if constexpr (FAST) {{ KB_LDS_{family}_FAST_C8 }} else {{ KB_LDS_{family}_COUNT_C8 }} \\')
+        out.append('    } else { \\')
+        out.append(f'        if constexpr (FAST) {{ KB_LDS_{family}_FAST_C16 }} else {{ KB_LDS_{family}_COUNT_C16 }} \\')
+        out.append('    }')
+        out.append('')
     out.append('#endif')
     with open(os.path.join(root, "kbmod_amd", "csrc", "search_lds_asm.h"), "w") as fh:
         fh.write("\n".join(out) + "\n")
