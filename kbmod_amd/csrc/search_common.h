@@ -44,10 +44,8 @@ __host__ __device__ inline int group_epochs(int T, int rows, int stride, bool ev
     int E = lds_group_bytes(rows) / stride;
     if (E > T) E = T;
     if (E < 1) E = 1;
-#ifndef KB_EXP_ODD_E
     if (even && E >= 2) E &= ~1;
     if (even && E > 16) E = 16;  // (their counting form keeps 32 -- chunks of 16: 16 -- samples' NO_DATA bits per register between two tallies)
-#endif
     return E;
 }
 

@@ -722,7 +722,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         // (the two-slab instances, see `deep` below, keep CHUNK)
         if (a.T >= 128 || (a.T > 64 && image_bytes > (1ull << 30)) || (a.T >= 64 && image_bytes > (4ull << 30))) wide = false;
         if (const char* env = std::getenv("KBMOD_STAGE_DEPTH")) wide = wide && std::atoi(env) != 2;
-        if (const char* env = std::getenv("KBMOD_LIST_MODE")) wide = wide && (std::atoi(env) == 3 || std::atoi(env) == 2);
+        if (const char* env = std::getenv("KBMOD_LIST_MODE")) wide = wide && std::atoi(env) == 3;
         if (const char* env = std::getenv("KBMOD_CHUNK")) wide = wide && std::atoi(env) == WIDE_CHUNK;
         if (wide) a.chunk = WIDE_CHUNK;
     }

@@ -721,7 +721,11 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
     const bool fast = a.all_staged && as_const_ints(a.n_invalid)[0] == 0 && (tc.tile_x0 + gb[0] >= 0) &&
                       (tc.tile_x0 + WAVE + gb[1] <= a.W) && (tc.tile_y0 + gb[2] >= 0) &&
                       (tc.tile_y0 + ROWS + gb[3] <= a.H);
+#ifdef KB_EXP_ALL_FAST
+    if (true) {
+#else
     if (fast) {
+#endif
         lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH, true>(a, tc, smem, lists);
     } else {
         lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH, false>(a, tc, smem, lists);

@@ -25,13 +25,7 @@ void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, int lis
             launch_lds<8, LDS_ROWS_WIDE_K, 4, true, true, LIST_REGISTERS>(a, stream);
         }
     } else if (a.K <= 8 && a.chunk == WIDE_CHUNK) {  // (the host pairs the wide chunks with this list mode, search_kernels.hip)
-        if (list_mode == LIST_STORE_RECORDS) {
-            if (tall) {
-                launch_lds<8, LDS_ROWS_TALL, 4, true, false, LIST_STORE_RECORDS, 1, WIDE_CHUNK>(a, stream);
-            } else {
-                launch_lds<8, LDS_ROWS_WIDE_K, 4, true, false, LIST_STORE_RECORDS, 1, WIDE_CHUNK>(a, stream);
-            }
-        } else if (tall) {
+        if (tall) {
             launch_lds<8, LDS_ROWS_TALL, 4, true, false, LIST_REGISTER_RECORDS, 1, WIDE_CHUNK>(a, stream);
         } else {
             launch_lds<8, LDS_ROWS_WIDE_K, 4, true, false, LIST_REGISTER_RECORDS, 1, WIDE_CHUNK>(a, stream);

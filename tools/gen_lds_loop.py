@@ -36,6 +36,8 @@ Every read-write operand is early-clobber: the statements write them while input
 """
 import os
 
+TRIM = os.environ.get("KB_GEN_NO_TRIM") is None  # (timing experiment: first pieces copied whatever the slab's height)
+
 
 class Plan:
     def __init__(self, C):
@@ -115,8 +117,11 @@ def half(p, which, fast, np_, request, refill):
     if request and np_:
         for piece in range(np_):
             wp, go, dst = (("%[wp]", "%[go]", other), ("%[wq]", "%[gq]", other2))[piece]
-            s += ln(f"s_cmp_lt_u32 {wp}, s{g + 2}\\n\\ts_cselect_b32 s{p.addr}, s{g}, %[dl]\\n\\ts_cselect_b32 s{p.addr + 1}, s{g + 1}, %[dh]")
-            s += ln(f"s_add_u32 s{p.addr}, %[tl], s{p.addr}\\n\\ts_addc_u32 s{p.addr + 1}, %[th], s{p.addr + 1}")
+            if TRIM or piece == 1:
+                s += ln(f"s_cmp_lt_u32 {wp}, s{g + 2}\\n\\ts_cselect_b32 s{p.addr}, s{g}, %[dl]\\n\\ts_cselect_b32 s{p.addr + 1}, s{g + 1}, %[dh]")
+                s += ln(f"s_add_u32 s{p.addr}, %[tl], s{p.addr}\\n\\ts_addc_u32 s{p.addr + 1}, %[th], s{p.addr + 1}")
+            else:
+                s += ln(f"s_add_u32 s{p.addr}, %[tl], s{g}\\n\\ts_addc_u32 s{p.addr + 1}, %[th], s{g + 1}")
             s += ln(f"global_load_dwordx4 {dst}, {go}, s[{p.addr}:{p.addr + 1}]")
     nb = p.nbatch(fast, np_)
     batches = p.C // nb
