@@ -518,7 +518,6 @@ __host__ __device__ constexpr size_t scratch_words_per_wave(int T) { return (siz
 void launch_search_direct(const SearchArgs& a, int fmt, bool sigmag, bool records, hipStream_t stream);
 void launch_search_large_k(const SearchArgs& a, bool sigmag, int blocks, hipStream_t stream);
 void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, int list_mode, hipStream_t stream);
-void launch_search_lds_canon_deep(const SearchArgs& a, int rows, bool sigmag, hipStream_t stream);  // search_lds_deep.hip
 void launch_search_lds_encoded(const SearchArgs& a, int rows, int fmt, bool sigmag, hipStream_t stream);
 
 // The launchers record which template instance they started, spelled as rocprofv3 prints it (kb_search_stats::kernel_name).

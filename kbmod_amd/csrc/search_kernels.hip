@@ -548,11 +548,9 @@ static SearchArgs with_tile_rows(SearchArgs a, int rows) {
 }
 
 // which: 0 = kb_search_direct, 1 = kb_search_lds on an encoded padded copy, 2 = kb_search_lds on canonical floats
-static void launch_search(const SearchArgs& a, int fmt, bool sigmag, int which, int lds_rows, int list_mode, bool deep,
+static void launch_search(const SearchArgs& a, int fmt, bool sigmag, int which, int lds_rows, int list_mode,
                           hipStream_t stream) {
-    if (which == 2 && deep) {
-        launch_search_lds_canon_deep(with_tile_rows(a, lds_rows), lds_rows, sigmag, stream);
-    } else if (which == 2) {
+    if (which == 2) {
         launch_search_lds_canon(with_tile_rows(a, lds_rows), lds_rows, sigmag, list_mode, stream);
     } else if (which == 1) {
         launch_search_lds_encoded(with_tile_rows(a, lds_rows), lds_rows, fmt, sigmag, stream);
@@ -716,12 +714,8 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     // will run; if the tables then say otherwise (too many epochs that cannot be staged, no room for the padded copy),
     // they are rebuilt for CHUNK.  KBMOD_CHUNK = 8 keeps CHUNK (tests, comparisons).
     {
-        const uint64_t image_bytes = (uint64_t)a.T * (uint64_t)a.H * (uint64_t)a.W * 8ull;
         bool wide = want_lds && params.do_sigmag_filter == 0 && a.K <= 8 && n_cands > (uint64_t)CHUNK && n_cands < 65535 &&
                     a.T < 65535 && (meta->num_bytes == 4 || (flags & 16u) == 0);
-        // (the two-slab instances, see `deep` below, keep CHUNK)
-        if (a.T >= 128 || (a.T > 64 && image_bytes > (1ull << 30)) || (a.T >= 64 && image_bytes > (4ull << 30))) wide = false;
-        if (const char* env = std::getenv("KBMOD_STAGE_DEPTH")) wide = wide && std::atoi(env) != 2;
         if (const char* env = std::getenv("KBMOD_LIST_MODE")) wide = wide && std::atoi(env) == 3;
         if (const char* env = std::getenv("KBMOD_CHUNK")) wide = wide && std::atoi(env) == WIDE_CHUNK;
         if (wide) a.chunk = WIDE_CHUNK;
@@ -965,15 +959,6 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     // candidates, the alternative costs an exact re-evaluation of every winner, K x T samples per pixel), else as
     // (likelihood, candidate) pairs in that store (1, lists of more than 8) or in registers (0).
     // KBMOD_LIST_MODE = 0 / 1 / 2 / 3 overrides where the pair (K, mode) exists (tests).
-    // Two staged slabs in flight per wave (search_lds_deep.hip; those instances keep their lists in the HBM store:
-    // records up to 8, pairs beyond).  What decides is measured: the second slab pays from
-    // about a hundred epochs per stack on whatever the image size (512 x 512 x 128: -12 %, 2048 x 2048 x 256: -20 %),
-    // below that only for copies of several GiB (4096 x 4096 x 64: -4 %), and costs 6-8 % where it does not pay
-    // (512 x 512 x 96, 4096 x 4096 x 32).  KBMOD_STAGE_DEPTH = 1 / 2 overrides (tests).
-    bool deep = which == 2 && (a.T >= 128 || (a.T > 64 && padded_copy_bytes > (1ull << 30)) ||
-                               (a.T >= 64 && padded_copy_bytes > (4ull << 30)));
-    if (const char* env = std::getenv("KBMOD_STAGE_DEPTH")) deep = which == 2 && std::atoi(env) == 2;
-    if (a.K > 32 || a.chunk != CHUNK) deep = false;
     a.lists = nullptr;
     int list_mode = 0;
     if (!sigmag && a.K <= 32) {
@@ -988,7 +973,6 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 list_mode = want;
             }
         }
-        if (deep) list_mode = ks == 8 ? 2 : 1;
         if (which != 2 && list_mode == 3) list_mode = 0;
         if (which == 1 && list_mode != 0) list_mode = 0;  // encoded staging: registers (K <= 8)
         if (which == 2 && (list_mode == 1 || list_mode == 2)) {
@@ -999,7 +983,6 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 a.lists = reinterpret_cast<uint2*>(lists);
             } else if (ks == 8) {
                 list_mode = packable ? 3 : 0;  // no room for the store: lists of 8 fit the registers
-                deep = false;                  // (the one-deep instances)
             } else {
                 which = 0;  // ... longer ones do in kb_search_direct
             }
@@ -1034,7 +1017,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
             a.chunk_hi = std::min(a.n_chunks, a.chunk_lo + batch_chunks);
             KB_HIP_TRY(hipMemsetAsync(cold.sg.slots, 0, (size_t)n_rows * cold.sg.batch_cands * sizeof(uint32_t), stream));
             KB_HIP_TRY(hipMemsetAsync(cold.sg.n_entries, 0, sizeof(int), stream));
-            if (a.chunk_lo < a.chunk_hi) launch_search(a, fmt, true, which, lds_rows, 0, deep, stream);  // the emitting instances keep no list
+            if (a.chunk_lo < a.chunk_hi) launch_search(a, fmt, true, which, lds_rows, 0, stream);  // the emitting instances keep no list
             KB_HIP_TRY(hipGetLastError());
             const ResultSink* next = &bufs[(n_batches - 1 - b) % 2];
             if (launch_sigmag_resolve(a, cold, prev, *next, resolve_waves, stream)) return 1;
@@ -1042,7 +1025,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         }
         variant = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
     } else {
-        launch_search(a, fmt, false, which, lds_rows, list_mode, deep, stream);
+        launch_search(a, fmt, false, which, lds_rows, list_mode, stream);
         variant = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);
     }
     KB_HIP_TRY(hipGetLastError());

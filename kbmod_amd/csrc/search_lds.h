@@ -217,14 +217,14 @@ __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) 
 // the epoch's sums and written to LDS after them.
 // FAST: no sample of this tile can be NO_DATA (the tile stays inside the image under
 // every shift, the array has no NO_DATA pixel, every epoch is staged): obs_count is T.
-template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, int STAGE_DEPTH, bool FAST>
+template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, bool FAST>
 __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileCoords& tc, char* smem,
                                                 TileLists<KS, LM>& lists) {
     constexpr int SF = CANON ? 4 : NB;  // staged format
     using R = RawPair<SF>;
     constexpr int BYTES = 2 * fmt_bytes(SF);
     // the float-staged, depth-1 instances run their epochs through search_lds_asm.h
-    constexpr bool HAND_SCHEDULED = CANON && STAGE_DEPTH == 1 && (C == 8 || C == 16);
+    constexpr bool HAND_SCHEDULED = CANON && (C == 8 || C == 16);
     const int T = a.T;
 
     PairF acc[C];  // (psi_sum, phi_sum) as pairs: one v_pk_add_f32 per sample
@@ -474,7 +474,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                         ConstSlabPtr pg = n_org;
 #else
                         ConstIntPtr po = offs + (e + 1) * C;
-                        ConstSlabPtr pg = n_org + (e + STAGE_DEPTH);
+                        ConstSlabPtr pg = n_org + (e + 1);
 #endif
 #pragma unroll
                         for (int c = 0; c < C; ++c) o_cur[c] = po[c];
@@ -495,27 +495,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     rptr += plan.stride;
                     ++e;
                 };
-                if constexpr (STAGE_DEPTH == 2) {
-                    // Two slabs in flight: the loads of slab e + 1 are issued before the sums of epoch e, the
-                    // registers of slab e (issued an epoch earlier) are written behind them; the two register
-                    // sets swap roles.  Every load in the pair loop is unconditional, so the wait in front of a
-                    // write counts the younger loads (vmcnt(NP)) instead of draining them.
-                    Piece va[LDS_SLOTS], vb[LDS_SLOTS];
-                    load(va, org_cur);
-                    while (e + 2 < n_both) {
-                        load(vb, org_nxt);
-                        step(va);
-                        load(va, org_nxt);
-                        step(vb);
-                    }
-                    if (e + 1 < n_both) {
-                        load(vb, org_nxt);
-                        step(va);
-                        step(vb);
-                    } else {
-                        step(va);
-                    }
-                } else {
+                {
                     Piece va[LDS_SLOTS];
                     org_nxt = org_cur;
                     while (e < n_both) {
@@ -524,13 +504,9 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     }
                 }
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-                // origin of slab e (for the loop below, and for the next group when this one ends here): one deep, the
-                // last step's prefetch already holds it
-                if constexpr (STAGE_DEPTH == 1) {
-                    org_cur = org_nxt;
-                } else {
-                    org_cur = origin_of(n_org[e]);
-                }
+                // origin of slab e (for the loop below, and for the next group when this one ends here): the last step's
+                // prefetch already holds it
+                org_cur = org_nxt;
             };
             // The same run as ONE asm statement (search_lds_asm.h, generated by tools/gen_lds_loop.py) for the float-staged
             // kernels with one slab per wave and epoch at most: two epochs per trip; the table words of epoch e + 2 are
@@ -698,10 +674,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 }
 
 
-// STAGE_DEPTH: staged slabs a wave holds in registers -- 1, or 2 (about 20 more registers) for deep stacks: the loads
-// of a slab then have two epochs of sums to land in (cfg5 2.80 -> 2.10 s, cfg4 share 51.3 -> 41.1 ms; nothing at 64
-// epochs, whatever the size of the array: DESIGN.md section 3.3).
-template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, int STAGE_DEPTH>
+template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, int LM>
 // second launch bound = waves per SIMD: 16 waves per CU (one 64 x 16 or two 64 x 8 workgroups)
 __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // two group buffers
@@ -726,9 +699,9 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
 #else
     if (fast) {
 #endif
-        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH, true>(a, tc, smem, lists);
+        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, true>(a, tc, smem, lists);
     } else {
-        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH, false>(a, tc, smem, lists);
+        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, false>(a, tc, smem, lists);
     }
     if constexpr (!SIGMAG) {
         if constexpr (TileLists<KS, LM>::STORED) {
@@ -743,16 +716,16 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
 }
 
 // Launch of one instance (two group buffers beyond the default 64 KiB of dynamic LDS need the attribute raised).
-template <int KS, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, int STAGE_DEPTH = 1, int C = CHUNK>
+template <int KS, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, int C = CHUNK>
 static void launch_lds(const SearchArgs& a, hipStream_t stream) {
     constexpr size_t lds_bytes = 2 * lds_group_bytes(ROWS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb_search_lds<KS, C, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb_search_lds<KS, C, ROWS, NB, CANON, SIGMAG, LM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((kb_search_lds<KS, C, ROWS, NB, CANON, SIGMAG, LM, STAGE_DEPTH>), dim3(a.n_tiles), dim3(ROWS * WAVE), lds_bytes,
+    hipLaunchKernelGGL((kb_search_lds<KS, C, ROWS, NB, CANON, SIGMAG, LM>), dim3(a.n_tiles), dim3(ROWS * WAVE), lds_bytes,
                        stream, a);
     char name[96];
-    std::snprintf(name, sizeof(name), "kb::kb_search_lds<%d, %d, %d, %d, %s, %s, %d, %d>", KS, C, ROWS, NB, CANON ? "true" : "false",
-                  SIGMAG ? "true" : "false", LM, STAGE_DEPTH);
+    std::snprintf(name, sizeof(name), "kb::kb_search_lds<%d, %d, %d, %d, %s, %s, %d>", KS, C, ROWS, NB, CANON ? "true" : "false",
+                  SIGMAG ? "true" : "false", LM);
     note_kernel_instance(name);
 }
 

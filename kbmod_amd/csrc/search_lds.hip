@@ -26,9 +26,9 @@ void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, int lis
         }
     } else if (a.K <= 8 && a.chunk == WIDE_CHUNK) {  // (the host pairs the wide chunks with this list mode, search_kernels.hip)
         if (tall) {
-            launch_lds<8, LDS_ROWS_TALL, 4, true, false, LIST_REGISTER_RECORDS, 1, WIDE_CHUNK>(a, stream);
+            launch_lds<8, LDS_ROWS_TALL, 4, true, false, LIST_REGISTER_RECORDS, WIDE_CHUNK>(a, stream);
         } else {
-            launch_lds<8, LDS_ROWS_WIDE_K, 4, true, false, LIST_REGISTER_RECORDS, 1, WIDE_CHUNK>(a, stream);
+            launch_lds<8, LDS_ROWS_WIDE_K, 4, true, false, LIST_REGISTER_RECORDS, WIDE_CHUNK>(a, stream);
         }
     } else if (a.K <= 8) {
         if (list_mode == LIST_STORE_RECORDS) {

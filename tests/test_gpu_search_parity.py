@@ -205,12 +205,14 @@ def test_list_modes_agree_with_the_oracle(kb, orc, stack, cands, K, mode, kern, 
                                  {"K": 6, "xb": (-20, 130), "yb": (-15, 95), "min_lh": -1e30}])
 @pytest.mark.parametrize("num_bytes", [-1, 1])
 @pytest.mark.parametrize("tiles", ["lds", "lds_tall"])
-def test_two_slabs_in_flight(kb, orc, stack, lds_cands, cfg, num_bytes, tiles, monkeypatch):
-    # The instances the host launches for arrays beyond the Infinity Cache (two staged slabs in flight per wave,
-    # lists in the HBM store), pinned here on a small stack with KBMOD_STAGE_DEPTH.
-    monkeypatch.setenv("KBMOD_STAGE_DEPTH", "2")
+def test_narrow_chunks_pinned(kb, orc, stack, lds_cands, cfg, num_bytes, tiles, monkeypatch):
+    # Lists of up to 8 results on a candidate list without per-lane epochs run the instance for chunks of 16 candidates;
+    # the instances for chunks of 8 (which also serve every list the wide one cannot take) are pinned here on the same
+    # inputs with KBMOD_CHUNK.
+    monkeypatch.setenv("KBMOD_CHUNK", "8")
     got, exp, s = util.run_both(kb, orc, stack, *lds_cands, cfg, num_bytes=num_bytes, flags=KERNELS[tiles])
     assert _variant(s) == 2
+    assert "kb::kb_search_lds<" in s.last_search_stats()["kernel_name"] and ", 16, " not in s.last_search_stats()["kernel_name"][:24]
     _check(got, exp)
     assert len(got) > 50
 

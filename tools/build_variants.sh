@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/probe_bin
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Iinclude -Ikbmod_amd/csrc"
-SRCS="search_lds search_lds_deep search_lds_encoded search_direct search_kernels sigmag_kernels"
+SRCS="search_lds search_lds_encoded search_direct search_kernels sigmag_kernels"
 for v in "$@"; do
   name=${v%%:*}; defs=${v#*:}
   (
