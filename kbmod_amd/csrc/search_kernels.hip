@@ -709,14 +709,15 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     uint64_t padded_copy_bytes = 0;
     const bool want_lds = (flags & 2u) == 0 && (flags & 1u) == 0 && a.K <= 32 &&
                           (n_cands >= 8 || (flags & 4u) != 0);
-    // Candidates per chunk.  WIDE_CHUNK for the one instance of kb_search_lds built for it -- float staging, lists of up to
-    // 8 as packed records in registers, one slab in flight -- when everything known before the tables says that instance
-    // will run; if the tables then say otherwise (too many epochs that cannot be staged, no room for the padded copy),
+    // Candidates per chunk.  WIDE_CHUNK for the two instances of kb_search_lds built for it -- float staging; lists of up to
+    // 8 as packed records in registers, or none (the in-search sigma-G filter) -- when everything known before the tables
+    // says one of them will run; if the tables then say otherwise (too many epochs that cannot be staged, no room for the padded copy),
     // they are rebuilt for CHUNK.  KBMOD_CHUNK = 8 keeps CHUNK (tests, comparisons).
     {
-        bool wide = want_lds && params.do_sigmag_filter == 0 && a.K <= 8 && n_cands > (uint64_t)CHUNK && n_cands < 65535 &&
-                    a.T < 65535 && (meta->num_bytes == 4 || (flags & 16u) == 0);
-        if (const char* env = std::getenv("KBMOD_LIST_MODE")) wide = wide && std::atoi(env) == 3;
+        const bool emitting = params.do_sigmag_filter != 0;  // (the in-search sigma-G filter: the search launch keeps no list)
+        bool wide = want_lds && n_cands > (uint64_t)CHUNK && (meta->num_bytes == 4 || (flags & 16u) == 0) &&
+                    (emitting || (a.K <= 8 && n_cands < 65535 && a.T < 65535));
+        if (const char* env = std::getenv("KBMOD_LIST_MODE")) wide = wide && (emitting || std::atoi(env) == 3);
         if (const char* env = std::getenv("KBMOD_CHUNK")) wide = wide && std::atoi(env) == WIDE_CHUNK;
         if (wide) a.chunk = WIDE_CHUNK;
     }
@@ -922,9 +923,9 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         uint64_t cap_limit = 4ull << 20;
         if (const char* env = std::getenv("KBMOD_SIGMAG_CAP")) cap_limit = std::max<uint64_t>(1, std::strtoull(env, nullptr, 10));
         batch_chunks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(a.n_chunks, 1),
-                                                                     cap_limit / ((uint64_t)n_rows * CHUNK)));
+                                                                     cap_limit / ((uint64_t)n_rows * a.chunk)));
         n_batches = std::max(1, (a.n_chunks + batch_chunks - 1) / batch_chunks);
-        const uint64_t capacity = (uint64_t)n_rows * (uint64_t)batch_chunks * CHUNK;
+        const uint64_t capacity = (uint64_t)n_rows * (uint64_t)batch_chunks * a.chunk;
         const size_t slot_bytes = (capacity * sizeof(uint32_t) + 255) / 256 * 256;
         const size_t entry_bytes = capacity * sizeof(SgEntry);
         const size_t out_bytes = capacity * WAVE * sizeof(float);
@@ -939,7 +940,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         cold.sg.lh = reinterpret_cast<float*>(wc + slot_bytes + 256 + entry_bytes);
         cold.sg.flux = reinterpret_cast<float*>(wc + slot_bytes + 256 + entry_bytes + out_bytes);
         cold.sg.obs = reinterpret_cast<int*>(wc + slot_bytes + 256 + entry_bytes + 2 * out_bytes);
-        cold.sg.batch_cands = batch_chunks * CHUNK;
+        cold.sg.batch_cands = batch_chunks * a.chunk;
         if (n_batches > 1) {
             void* pp = nullptr;
             if (ensure_workspace(4, (size_t)expected * sizeof(kb_trajectory), &pp)) return 1;

@@ -263,6 +263,10 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     __syncthreads();
     KB_PROF_MARK(0)
 
+    // Operands of the hand-scheduled statements that must sit in scalar registers: read through the first lane, because an
+    // "s" constraint on a value the compiler holds (or believes) per-lane is not enforced -- it prints the vector register.
+    auto sgpr32 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto sgpr64 = [&](uint64_t v) { return ((uint64_t)sgpr32((uint32_t)(v >> 32)) << 32) | (uint64_t)sgpr32((uint32_t)v); };
     while (chunk < a.chunk_hi) {
         // This trip's view of the thread's place.  Everything per-lane below derives from a thread index the compiler
         // cannot see through, so that none of it (lane offsets, the start pixel as doubles for the exact path, ...) is
@@ -293,27 +297,27 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 const int GB = lds_group_bytes(ROWS);
                 uint32_t rb = (uint32_t)(uintptr_t)(smem + buf * GB + (tc.wv * plan.cols + tq.lane) * BYTES);
                 uint32_t wd = (uint32_t)(uintptr_t)(smem + (1 - buf) * GB + 16 * tid);
-                uint32_t dr = (uint32_t)((1 - 2 * buf) * GB);
-                const uint32_t pg = (uint32_t)plan.E >> 1;
-                uint32_t gc = pg, pairs = (uint32_t)ng * pg;
-                const uint32_t es = (uint32_t)(plan.E * plan.stride), st = (uint32_t)plan.stride;
+                uint32_t dr = sgpr32((uint32_t)((1 - 2 * buf) * GB));
+                const uint32_t pg = sgpr32((uint32_t)plan.E >> 1);
+                uint32_t gc = pg, pairs = sgpr32((uint32_t)ng * pg);
+                const uint32_t es = sgpr32((uint32_t)(plan.E * plan.stride)), st = sgpr32((uint32_t)plan.stride);
                 const uint32_t go = n_sl.goff[0];
                 // (counting statements: groups per 32 epochs -- their NO_DATA shift registers hold 32 samples -- and groups
                 // until they are emptied next)
-                const uint32_t fg = max(1u, (C == 8 ? 32u : 16u) / (uint32_t)plan.E);
+                const uint32_t fg = sgpr32(max(1u, (C == 8 ? 32u : 16u) / (uint32_t)plan.E));
                 uint32_t fc = fg;
-                const uint64_t ob = (uint64_t)(uintptr_t)(a.lds_fold + ((size_t)chunk * T + t0) * C);
-                const uint64_t gb = (uint64_t)(uintptr_t)(first + 1);
-                const uint64_t tb = (uint64_t)(uintptr_t)tile_base;
+                const uint64_t ob = sgpr64((uint64_t)(uintptr_t)(a.lds_fold + ((size_t)chunk * T + t0) * C));
+                const uint64_t gb = sgpr64((uint64_t)(uintptr_t)(first + 1));
+                const uint64_t tb = sgpr64((uint64_t)(uintptr_t)tile_base);
                 // (slabs are as tall as their epoch's shift box: a piece behind a slab's end copies the first slab's instead)
                 const Int4 ref0 = first[0];
-                const uint32_t wp = (uint32_t)(1024 * tc.wv);
-                const uint32_t dl = (uint32_t)ref0.x, dh = (uint32_t)ref0.y;
-                const uint64_t b0 = tb + (uint64_t)origin_of(ref0);
+                const uint32_t wp = sgpr32((uint32_t)(1024 * tc.wv));
+                const uint32_t dl = sgpr32((uint32_t)ref0.x), dh = sgpr32((uint32_t)ref0.y);
+                const uint64_t b0 = sgpr64(tb + (uint64_t)origin_of(ref0));
                 const uint32_t tl = (uint32_t)tb, th = (uint32_t)(tb >> 32);
                 // (a wave's second piece of a slab of more than one staging round: its lane offset, its first byte)
                 const uint32_t gq = n_sl.goff[LDS_SLOTS >= 2 ? 1 : 0];
-                const uint32_t wq = wp + (uint32_t)stage_round(ROWS);
+                const uint32_t wq = sgpr32(wp + (uint32_t)stage_round(ROWS));
                 // (pieces of every slab this wave copies: the statement holds a body for each)
                 const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)wq < plan.slab_bytes ? 2 : ((int)wp < plan.slab_bytes ? 1 : 0));
                 (void)fc; (void)fg;
@@ -519,22 +523,22 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)nq_of_wave);
                 const int wave_piece_of_run = 1024 * tc.wv;
                 static_assert((C == 8 || C == 16) && sizeof(SlabRef) == 16, "search_lds_asm.h");
-                uint32_t pairs = (uint32_t)(n_both - e) >> 1;
-                const uint32_t odd = (uint32_t)(n_both - e) & 1u;
+                uint32_t pairs = sgpr32((uint32_t)(n_both - e) >> 1);
+                const uint32_t odd = sgpr32((uint32_t)(n_both - e) & 1u);
                 const int done = n_both - e;
                 uint32_t wd = (uint32_t)(uintptr_t)(nb + 16 * tid + e * n_plan.stride);
                 const uint32_t rb = (uint32_t)(uintptr_t)cb;  // this lane's pixel at the start of the group buffer
                 const uint32_t go = n_sl.goff[0];
-                const uint64_t ob = (uint64_t)(uintptr_t)(a.lds_fold + ((size_t)chunk * T + t0 + e) * C);
-                const uint64_t gb = (uint64_t)(uintptr_t)(n_org + (e + 1));
-                const uint64_t tb = (uint64_t)(uintptr_t)tile_base;
-                const uint64_t b0 = tb + (uint64_t)org_cur;
+                const uint64_t ob = sgpr64((uint64_t)(uintptr_t)(a.lds_fold + ((size_t)chunk * T + t0 + e) * C));
+                const uint64_t gb = sgpr64((uint64_t)(uintptr_t)(n_org + (e + 1)));
+                const uint64_t tb = sgpr64((uint64_t)(uintptr_t)tile_base);
+                const uint64_t b0 = sgpr64(tb + (uint64_t)org_cur);
                 const uint32_t tl = (uint32_t)tb, th = (uint32_t)(tb >> 32);
-                const uint32_t wp = (uint32_t)wave_piece_of_run;
-                const uint32_t dl = (uint32_t)(uint64_t)org_cur, dh = (uint32_t)((uint64_t)org_cur >> 32);
-                const uint32_t st = (uint32_t)n_plan.stride;
+                const uint32_t wp = sgpr32((uint32_t)wave_piece_of_run);
+                const uint32_t dl = sgpr32((uint32_t)(uint64_t)org_cur), dh = sgpr32((uint32_t)((uint64_t)org_cur >> 32));
+                const uint32_t st = sgpr32((uint32_t)n_plan.stride);
                 const uint32_t gq = n_sl.goff[LDS_SLOTS >= 2 ? 1 : 0];
-                const uint32_t wq = wp + (uint32_t)stage_round(ROWS);
+                const uint32_t wq = sgpr32(wp + (uint32_t)stage_round(ROWS));
                 KB_LDS_RUN_LOOP
                 e += done;
                 if constexpr (!FAST) {

@@ -18,7 +18,13 @@ static void launch_canon(const SearchArgs& a, bool tall, hipStream_t stream) {
 // (the host chooses, search_kernels.hip)
 void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, int list_mode, hipStream_t stream) {
     const bool tall = rows == LDS_ROWS_TALL;
-    if (sigmag) {  // the emitting instances keep no list: KS is irrelevant
+    if (sigmag && a.chunk == WIDE_CHUNK) {
+        if (tall) {
+            launch_lds<8, LDS_ROWS_TALL, 4, true, true, LIST_REGISTERS, WIDE_CHUNK>(a, stream);
+        } else {
+            launch_lds<8, LDS_ROWS_WIDE_K, 4, true, true, LIST_REGISTERS, WIDE_CHUNK>(a, stream);
+        }
+    } else if (sigmag) {  // the emitting instances keep no list: KS is irrelevant
         if (tall) {
             launch_lds<8, LDS_ROWS_TALL, 4, true, true, LIST_REGISTERS>(a, stream);
         } else {

@@ -82,8 +82,12 @@ def test_sigma_g_candidate_batches(kb, orc, kern, cap, monkeypatch):
     _check(got, exp)
     assert len(got) > 100
     n_rows = 3 * 40
-    want_batches = -(-18 // max(1, min(18, cap // (n_rows * 8))))
-    assert s.last_search_stats()["num_search_launches"] == 3 * want_batches
+    # candidates per chunk of the instance that ran: 16 for the float-staged kernel on a list without per-lane epochs, else 8
+    stats = s.last_search_stats()
+    chunk = 16 if stats["kernel_name"].startswith("kb::kb_search_lds<8, 16,") else 8
+    n_chunks = -(-len(vx) // chunk)
+    want_batches = -(-n_chunks // max(1, min(n_chunks, cap // (n_rows * chunk))))
+    assert stats["num_search_launches"] == 3 * want_batches
 
 
 @pytest.mark.parametrize("kern", [DIRECT, LDS])
