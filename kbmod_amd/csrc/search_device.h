@@ -23,6 +23,24 @@ __device__ __forceinline__ ConstIntPtr as_const_ints(const P* p) {
 }
 
 
+// Screen of a finished candidate against the likelihood its list's last slot holds: true when the candidate
+// CANNOT enter, decided on an approximate likelihood (psi * rsq(phi): three instructions instead of the thirty of
+// the correctly rounded sqrt and divide).  The threshold is lowered by a relative 2^-18 and one smallest normal,
+// which no rounding of either computation bridges (v_rsq_f32 and the product are good to 2^-21 relative; the exact
+// value to 2^-22), so a candidate that fails the screen also fails `lh > threshold` with the exact likelihood;
+// everything else -- passes, NaN, a phi sum too small for v_rsq_f32 -- is left to the exact test.
+__device__ __forceinline__ float screen_floor(float threshold) {
+    return threshold - fabsf(threshold) * 3.814697265625e-06f - 1.17549435e-38f;  // -FLT_MAX -> -inf, NaN stays NaN
+}
+__device__ __forceinline__ bool screened_out(float psi_sum, float phi_sum, float floor_lh) {
+    // straight-line on purpose (bitwise, not short-circuit: as branches the screen of a chunk was ~360 instructions, the
+    // largest single piece of the finish): v_rsq_f32 of a non-positive or denormal sum yields a value that is not used
+    const bool pos = phi_sum > 0.0f;
+    const float approx = pos ? psi_sum * __builtin_amdgcn_rsqf(phi_sum) : -1.0f;
+    const bool denormal = pos & (phi_sum < 1.17549435e-38f);  // (no argument for v_rsq_f32: left to the exact test)
+    return (approx < floor_lh) & !denormal;                   // NaN compares false: left to the exact test
+}
+
 // Threshold / insertion of one chunk's C finished candidates.  With the sigma-G filter on nothing is
 // inserted here: the ballot of the lanes that pass the unclipped thresholds (kernels.cu:201-203 and
 // :318-320; this includes the obs_count == 0 corner, which the clip leaves alone) becomes one work item
@@ -39,15 +57,22 @@ __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoor
         const bool live = tc.x_i < a.sw;  // lanes past the right edge of the search area own no pixel
         // two passes over the candidates (count, then write): the ballots are cheap to form again and C
         // 64-bit masks kept alive would cost the surrounding loop its scalar registers
+        // `lh < min_lh` is decided on the approximate likelihood wherever that is safe (screened_out: a candidate it rejects
+        // also fails the exact test); the correctly rounded sqrt and divide run only for candidates some lane cannot
+        // decide that way -- a fraction of a percent of cfg3's
+        const float floor_lh = screen_floor(a.min_lh);
         uint32_t pass_bits = 0;
         int n_items = 0;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             float p = ps[c], f = ph[c];
             asm volatile("" : "+v"(p), "+v"(f), "+v"(pass_bits));
-            const float lh = lh_from_sums(p, f);
             const bool real = (chunk * C + c) < a.n_cands;  // uniform
-            const bool pass = real && live && !(cnt[c] < a.min_obs) && !(lh < a.min_lh);
+            bool pass = real & live & !(cnt[c] < a.min_obs) & !screened_out(p, f, floor_lh);
+            if (__ballot(pass) != 0) {  // uniform
+                const float lh = lh_from_sums(p, f);
+                pass = pass & !(lh < a.min_lh);
+            }
             pass_bits |= pass ? (1u << c) : 0u;
             n_items += (__ballot(pass) != 0) ? 1 : 0;
         }
@@ -137,21 +162,6 @@ __device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chu
     ls.stored = 1;
 }
 
-// Screen of a finished candidate against the likelihood its list's last slot holds: true when the candidate
-// CANNOT enter, decided on an approximate likelihood (psi * rsq(phi): three instructions instead of the thirty of
-// the correctly rounded sqrt and divide).  The threshold is lowered by a relative 2^-18 and one smallest normal,
-// which no rounding of either computation bridges (v_rsq_f32 and the product are good to 2^-21 relative; the exact
-// value to 2^-22), so a candidate that fails the screen also fails `lh > threshold` with the exact likelihood;
-// everything else -- passes, NaN, a phi sum too small for v_rsq_f32 -- is left to the exact test.
-__device__ __forceinline__ float screen_floor(float threshold) {
-    return threshold - fabsf(threshold) * 3.814697265625e-06f - 1.17549435e-38f;  // -FLT_MAX -> -inf, NaN stays NaN
-}
-__device__ __forceinline__ bool screened_out(float psi_sum, float phi_sum, float floor_lh) {
-    const float approx = (phi_sum > 0.0f) ? psi_sum * __builtin_amdgcn_rsqf(phi_sum) : -1.0f;
-    const bool usable = !(phi_sum > 0.0f) || phi_sum >= 1.17549435e-38f;  // (a denormal sum is no argument for v_rsq_f32)
-    return usable && approx < floor_lh;
-}
-
 // finish_chunk / epilogue for packed records in registers (kb_search_lds, lists of up to 8, long candidate lists).
 // Two steps.  (1) Screen all C candidates (above): per lane a bit mask of those that may enter its list.  (2) While
 // any lane has a bit left, EVERY lane takes its own lowest candidate -- selected out of the C register sets --,
@@ -165,10 +175,13 @@ __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int chu
     const float floor_lh = screen_floor(top.lh[KS - 1]);
     uint32_t pending = 0;
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const bool real = (chunk * C + c) < a.n_cands;  // uniform
-        const bool out = !real || cnt[c] < a.min_obs || screened_out(ps[c], ph[c], floor_lh);
-        pending |= out ? 0u : (1u << c);
+    for (int c = C - 1; c >= 0; --c) {  // (downwards: the mask is built by shifting)
+        const bool out = (cnt[c] < a.min_obs) | screened_out(ps[c], ph[c], floor_lh);
+        pending = (pending << 1) | (out ? 0u : 1u);
+    }
+    {
+        const int left = a.n_cands - chunk * C;  // uniform: candidates of this chunk that exist
+        if (left < C) pending &= (1u << left) - 1u;
     }
     while (__ballot(pending != 0u) != 0ull) {  // uniform
         const int c_sel = (int)__builtin_ctz(pending | (1u << C));  // (C: a lane with nothing left selects nothing)

@@ -8,7 +8,11 @@
 #include <type_traits>
 
 #include "search_device.h"
+#ifdef KB_ASM_HEADER  // (timing experiments: a variant of the generated statements, tools/gen_lds_loop.py)
+#include KB_ASM_HEADER
+#else
 #include "search_lds_asm.h"
+#endif
 
 #pragma clang fp contract(off)
 

@@ -37,6 +37,12 @@ Every read-write operand is early-clobber: the statements write them while input
 import os
 
 TRIM = os.environ.get("KB_GEN_NO_TRIM") is None  # (timing experiment: first pieces copied whatever the slab's height)
+# timing experiments (wrong results): statements without the slab loads / the LDS writes / the barrier / the table refills;
+# KB_GEN_OUT = where the header goes (a variant build includes it through -DKB_ASM_HEADER)
+NO_GLOAD = os.environ.get("KB_GEN_NO_GLOAD") is not None
+NO_LWRITE = os.environ.get("KB_GEN_NO_LWRITE") is not None
+NO_BARRIER = os.environ.get("KB_GEN_NO_BARRIER") is not None
+NO_REFILL = os.environ.get("KB_GEN_NO_REFILL") is not None
 
 
 class Plan:
@@ -122,22 +128,24 @@ def half(p, which, fast, np_, request, refill):
                 s += ln(f"s_add_u32 s{p.addr}, %[tl], s{p.addr}\\n\\ts_addc_u32 s{p.addr + 1}, %[th], s{p.addr + 1}")
             else:
                 s += ln(f"s_add_u32 s{p.addr}, %[tl], s{g}\\n\\ts_addc_u32 s{p.addr + 1}, %[th], s{g + 1}")
-            s += ln(f"global_load_dwordx4 {dst}, {go}, s[{p.addr}:{p.addr + 1}]")
+            if not NO_GLOAD:
+                s += ln(f"global_load_dwordx4 {dst}, {go}, s[{p.addr}:{p.addr + 1}]")
     nb = p.nbatch(fast, np_)
     batches = p.C // nb
     for b in range(batches):
         s += reads(p, base, b, nb)
         s += ln("s_waitcnt lgkmcnt(0)")
-        if b == batches - 1 and refill:
+        if b == batches - 1 and refill and not NO_REFILL:
             s += ln(f"{p.loadx} s[{base}:{base + p.C - 1}], %[ob], s{p.o1}{imm1}")
             if np_:
                 s += ln(f"s_load_dwordx4 s[{g}:{g + 3}], %[gb], s{p.o2}{imm2}")
         s += adds(p, fast, b, nb)
     if np_:
         s += ln(f"s_waitcnt vmcnt({np_ if request else 0})")
-        s += ln(f"ds_write_b128 %[wd], {mine}")
-        if np_ == 2:
-            s += ln(f"ds_write_b128 %[wd], {mine2} offset:%[so]")
+        if not NO_LWRITE:
+            s += ln(f"ds_write_b128 %[wd], {mine}")
+            if np_ == 2:
+                s += ln(f"ds_write_b128 %[wd], {mine2} offset:%[so]")
     s += ln("v_add_u32 %[wd], %[st], %[wd]")
     return s
 
@@ -188,7 +196,7 @@ def stream(p, fast, np_):
     s += half(p, "B", fast, np_, True, True)
     s += advance(p)
     s += ln(f"s_sub_u32 %[gc], %[gc], 1\\n\\ts_cmp_lg_u32 %[gc], 0\\n\\ts_cbranch_scc1 kb_snb_%=_{np_}")
-    s += ln("s_waitcnt lgkmcnt(0)\\n\\ts_barrier")
+    s += ln("s_waitcnt lgkmcnt(0)" + ("" if NO_BARRIER else "\\n\\ts_barrier"))
     s += ln("v_add_u32 %[rb], %[dr], %[rb]\\n\\tv_subrev_u32 %[wd], %[es], %[wd]\\n\\tv_subrev_u32 %[wd], %[dr], %[wd]")
     s += ln("s_sub_u32 %[dr], 0, %[dr]\\n\\ts_mov_b32 %[gc], %[pg]")
     if not fast:
@@ -281,7 +289,7 @@ def main():
         out.append('    }')
         out.append('')
     out.append('#endif')
-    with open(os.path.join(root, "kbmod_amd", "csrc", "search_lds_asm.h"), "w") as fh:
+    with open(os.environ.get("KB_GEN_OUT", os.path.join(root, "kbmod_amd", "csrc", "search_lds_asm.h")), "w") as fh:
         fh.write("\n".join(out) + "\n")
 
 
