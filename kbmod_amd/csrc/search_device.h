@@ -201,6 +201,160 @@ __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int chu
         pending &= pending - 1u;
     }
 }
+// Stable lists of 16 in the list store of kb_search_lds, pooled (LIST_STORE_POOLED): what the tie-exact exchange between
+// devices runs with chunks of WIDE_CHUNK candidates (2 K = 16 records per pixel, flag 512).  A thread's list is
+//   * 16 likelihoods in list order (four 16-byte rows of the lane-interleaved store),
+//   * a 64-bit word of 16 four-bit cell numbers in list order (slot s in bits [4 s, 4 s + 4)), and
+//   * a pool of 16 cells of (flux, candidate | count << 16) that never move: a new entry takes the cell of the entry that
+//     falls off the end (cells are numbered by the slots that first used them).
+// In registers the list is 18 words instead of the 48 of packed records -- next to 32 sums, 8 counts and the state of the
+// summing loop, 48 put 150 registers into scratch memory whose round trips made the finish 130 us per chunk --, and an
+// insertion moves one word per slot instead of three.  Stable insertion only (TopK::insert with `stable`): the new entry
+// goes behind every entry that is not smaller and everything below shifts by one, i.e. the list is the top 16 by (likelihood
+// descending, candidate ascending); the reference's swap-down, which rotates runs of equal likelihoods, stays with the
+// register and record lists.  The finish is the one of the packed register lists: screen, then rounds in which every lane
+// inserts its own lowest passing candidate; only lanes with a candidate past the screen touch the store.
+struct PooledLayout {
+    // byte offsets inside a tile's block of the store (threads = ROWS * WAVE); 16 * 16 bytes per thread are allocated
+    uint32_t threads;
+    __device__ __forceinline__ uint32_t lh_row(int r, uint32_t tid) const { return (uint32_t)r * threads * 16u + tid * 16u; }   // r < 4
+    __device__ __forceinline__ uint32_t cells(uint32_t tid) const { return 4u * threads * 16u + tid * 16u; }
+    __device__ __forceinline__ uint32_t pool(uint32_t cell, uint32_t tid) const { return 5u * threads * 16u + cell * threads * 8u + tid * 8u; }
+};
+struct PooledList {
+    float lh[16];
+    uint64_t cells;
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) lh[s] = -FLT_MAX;  // (an entry's likelihood is above this: -FLT_MAX marks an empty slot)
+        cells = 0xfedcba9876543210ull;
+    }
+    __device__ __forceinline__ void load(const char* tile_list, const PooledLayout& lay, uint32_t tid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tile_list + lay.lh_row(r, tid));
+            lh[4 * r] = __uint_as_float(v.x);
+            lh[4 * r + 1] = __uint_as_float(v.y);
+            lh[4 * r + 2] = __uint_as_float(v.z);
+            lh[4 * r + 3] = __uint_as_float(v.w);
+        }
+        const uint2 c = *reinterpret_cast<const uint2*>(tile_list + lay.cells(tid));
+        cells = ((uint64_t)c.y << 32) | (uint64_t)c.x;
+    }
+    __device__ __forceinline__ void store(char* tile_list, const PooledLayout& lay, uint32_t tid) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            *reinterpret_cast<uint4*>(tile_list + lay.lh_row(r, tid)) =
+                    make_uint4(__float_as_uint(lh[4 * r]), __float_as_uint(lh[4 * r + 1]), __float_as_uint(lh[4 * r + 2]),
+                               __float_as_uint(lh[4 * r + 3]));
+        }
+        *reinterpret_cast<uint2*>(tile_list + lay.cells(tid)) = make_uint2((uint32_t)cells, (uint32_t)(cells >> 32));
+    }
+    // Stable insertion of a candidate known to beat the last slot; returns the pool cell its record goes to.
+    __device__ __forceinline__ uint32_t insert(float cand_lh) {
+        const uint32_t cell = (uint32_t)(cells >> 60);  // the cell of the entry that falls off
+        // g[s] = the candidate is above slot s: false ... false, true ... true down the (descending) list
+        uint32_t pos = 0;  // slots that stay in front of the candidate
+        float prev = lh[0];
+        bool g_prev = cand_lh > prev;
+        lh[0] = g_prev ? cand_lh : prev;
+        pos += g_prev ? 0u : 1u;
+#pragma unroll
+        for (int s = 1; s < 16; ++s) {
+            const float cur = lh[s];
+            const bool g = cand_lh > cur;
+            lh[s] = g ? (g_prev ? prev : cand_lh) : cur;
+            pos += g ? 0u : 1u;
+            prev = cur;
+            g_prev = g;
+        }
+        const uint32_t sh = 4u * pos;                      // pos <= 15: the caller tested the last slot
+        const uint64_t below = cells & ((1ull << sh) - 1ull);
+        const uint64_t above = (cells >> sh) << sh << 4;  // the top nibble leaves the word
+        cells = below | ((uint64_t)cell << sh) | above;
+        return cell;
+    }
+};
+template <int C, bool FAST>
+__device__ __forceinline__ void finish_chunk_pooled(const SearchArgs& a, int chunk, const float (&ps)[C], const float (&ph)[C],
+                                                    const uint32_t (&cntp)[C / 2], ListState& ls, char* tile_list,
+                                                    const PooledLayout lay, uint32_t tid) {
+    const float floor_lh = screen_floor(ls.threshold);
+    uint32_t pending = 0;
+#pragma unroll
+    for (int c = C - 1; c >= 0; --c) {
+        const int n = FAST ? a.T : (int)((cntp[c >> 1] >> (16 * (c & 1))) & 0xffffu);
+        const bool out = (n < a.min_obs) | screened_out(ps[c], ph[c], floor_lh);
+        pending = (pending << 1) | (out ? 0u : 1u);
+    }
+    {
+        const int left = a.n_cands - chunk * C;  // uniform
+        if (left < C) pending &= (1u << left) - 1u;
+    }
+    if (__ballot(pending != 0u) == 0ull) return;  // uniform: nothing of this chunk can enter any list of the wave
+    PooledList top;
+    top.init();
+    const bool mine = pending != 0u;  // per lane: the memory operations below run under the mask of these lanes
+    if (mine && ls.stored) top.load(tile_list, lay, tid);
+    while (__ballot(pending != 0u) != 0ull) {  // uniform
+        const int c_sel = (int)__builtin_ctz(pending | (1u << C));
+        float p = ps[0], f = ph[0];
+#pragma unroll
+        for (int c = 1; c < C; ++c) {
+            const bool pick = c_sel == c;
+            p = pick ? ps[c] : p;
+            f = pick ? ph[c] : f;
+        }
+        uint32_t n = (uint32_t)a.T;
+        if constexpr (!FAST) {
+            uint32_t w = cntp[0];
+#pragma unroll
+            for (int j = 1; j < C / 2; ++j) w = ((c_sel >> 1) == j) ? cntp[j] : w;
+            n = (w >> (16 * (c_sel & 1))) & 0xffffu;
+        }
+        const float lh = lh_from_sums(p, f);
+        if (pending != 0u && lh > top.lh[15]) {
+            const uint32_t cell = top.insert(lh);
+            *reinterpret_cast<uint2*>(tile_list + lay.pool(cell, tid)) =
+                    make_uint2(__float_as_uint(flux_from_sums(p, f)), (uint32_t)(chunk * C + c_sel) | (n << 16));
+        }
+        pending &= pending - 1u;
+    }
+    if (mine) {
+        top.store(tile_list, lay, tid);
+        ls.threshold = top.lh[15];
+        ls.stored = 1;
+    }
+}
+__device__ __forceinline__ void write_results_pooled(const SearchArgs& a, const TileCoords& tc, const ListState& ls,
+                                                     const char* tile_list, const PooledLayout lay, uint32_t tid) {
+    if (tc.x_i >= a.sw || !tc.row_active) return;
+    const size_t slot0 = ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
+    uint64_t cells = 0;
+    if (ls.stored) {
+        const uint2 c = *reinterpret_cast<const uint2*>(tile_list + lay.cells(tid));
+        cells = ((uint64_t)c.y << 32) | (uint64_t)c.x;
+    }
+    for (int s = 0; s < a.K; ++s) {  // (K <= 16)
+        kb_trajectory res = placeholder_result(tc.x, tc.y);  // kernels.cu:293-301
+        int id_s = -1;
+        if (ls.stored) {
+            const float lh = *reinterpret_cast<const float*>(tile_list + lay.lh_row(s >> 2, tid) + 4 * (s & 3));
+            if (lh != -FLT_MAX) {
+                const uint32_t cell = (uint32_t)(cells >> (4 * s)) & 15u;
+                const uint2 r = *reinterpret_cast<const uint2*>(tile_list + lay.pool(cell, tid));
+                id_s = (int)(r.y & 0xffffu);
+                res.vx = a.cold->cands[id_s].vx;
+                res.vy = a.cold->cands[id_s].vy;
+                res.lh = lh;
+                res.flux = __uint_as_float(r.x);
+                res.obs_count = (int)(r.y >> 16);
+            }
+        }
+        store_result(a.cold->results, slot0 + s, res, id_s);
+    }
+}
+
 template <int KS>
 __device__ __forceinline__ void write_packed(const SearchArgs& a, const TileCoords& tc, const TopKPacked<KS>& top) {
     if (tc.x_i >= a.sw || !tc.row_active) return;

@@ -716,12 +716,15 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     {
         const bool emitting = params.do_sigmag_filter != 0;  // (the in-search sigma-G filter: the search launch keeps no list)
         bool wide = want_lds && n_cands > (uint64_t)CHUNK && (meta->num_bytes == 4 || (flags & 16u) == 0) &&
-                    (emitting || (a.K <= 8 && n_cands < 65535 && a.T < 65535));
-        if (const char* env = std::getenv("KBMOD_LIST_MODE")) wide = wide && (emitting || std::atoi(env) == 3);
+                    (emitting || ((a.K <= 8 || (a.K <= 16 && a.stable_lists != 0)) && n_cands < 65535 && a.T < 65535));
+        // (list modes of the wide instances: 3 = packed records in registers, K <= 8; 4 = pooled stable lists in the store, K <= 16)
+        if (const char* env = std::getenv("KBMOD_LIST_MODE")) wide = wide && (emitting || std::atoi(env) == (a.K <= 8 ? 3 : 4));
         if (const char* env = std::getenv("KBMOD_CHUNK")) wide = wide && std::atoi(env) == WIDE_CHUNK;
         if (wide) a.chunk = WIDE_CHUNK;
     }
     bool wide_has_special = false;
+    bool wide_store_failed = false;  // lists of 9 to 16 with wide chunks live in the list store: without it, chunks of CHUNK
+    void* wide_lists = nullptr;
     int special_epochs = 0;
     for (bool settled = n_cands == 0; !settled;) {
         a.n_chunks = (int)((n_cands + a.chunk - 1) / a.chunk);
@@ -889,7 +892,11 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
             }
         }
         table_ms = table_timer.end();
-        if (a.chunk != CHUNK && (which != 2 || wide_has_special)) {
+        if (a.chunk == WIDE_CHUNK && which == 2 && !wide_has_special && params.do_sigmag_filter == 0 && a.K > 8) {
+            const SearchArgs at = with_tile_rows(a, lds_rows);
+            wide_store_failed = !try_workspace(6, (size_t)at.n_tiles * 16 * block_threads(lds_rows) * 16, &wide_lists);
+        }
+        if (a.chunk != CHUNK && (which != 2 || wide_has_special || wide_store_failed)) {
             a.chunk = CHUNK;  // the instance the wide chunks are for will not (or cannot) run: tables for the others
         } else {
             settled = true;
@@ -973,6 +980,10 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
             if ((ks == 8 && (want == 0 || want == 2 || (want == 3 && packable))) || (ks == 16 && (want == 1 || want == 2))) {
                 list_mode = want;
             }
+        }
+        if (which == 2 && ks == 16 && a.chunk == WIDE_CHUNK) {  // the wide-chunk instance for lists of 9 to 16
+            list_mode = 4;
+            a.lists = reinterpret_cast<uint2*>(wide_lists);
         }
         if (which != 2 && list_mode == 3) list_mode = 0;
         if (which == 1 && list_mode != 0) list_mode = 0;  // encoded staging: registers (K <= 8)

@@ -181,13 +181,17 @@ __device__ __forceinline__ void special_epoch(const SearchArgs& a, const TileCoo
 // 128 epochs: 124 -> 53 ms) and registers / ids when it is long (cfg2's 1024 on 64: 5.16 vs 5.61 ms).
 //  LIST_REGISTER_RECORDS  whole results in registers at three words per slot (TopKPacked; K <= 8, fewer than 65535
 //                  candidates): no store, no re-evaluation; the default for long candidate lists with K <= 8.
-enum ListMode { LIST_REGISTERS = 0, LIST_STORE_IDS = 1, LIST_STORE_RECORDS = 2, LIST_REGISTER_RECORDS = 3 };
+//  LIST_STORE_POOLED  stable lists of 16 in that store as likelihoods + cell numbers + a pool of records that never move
+//                  (PooledList, search_device.h), fetched only by the lanes with a candidate past the screen: what the
+//                  tie-exact exchange between devices runs (2 K = 16 records per pixel) with chunks of WIDE_CHUNK candidates.
+enum ListMode { LIST_REGISTERS = 0, LIST_STORE_IDS = 1, LIST_STORE_RECORDS = 2, LIST_REGISTER_RECORDS = 3, LIST_STORE_POOLED = 4 };
 template <int KS, int LM>
 struct TileLists {
-    static constexpr bool STORED = LM == LIST_STORE_IDS || LM == LIST_STORE_RECORDS;
+    static constexpr bool STORED = LM == LIST_STORE_IDS || LM == LIST_STORE_RECORDS || LM == LIST_STORE_POOLED;
     static constexpr bool PACKED = LM == LIST_REGISTER_RECORDS;
     static constexpr bool RECORDS = LM == LIST_STORE_RECORDS;
-    static constexpr uint32_t SLOT_BYTES = RECORDS ? 16u : 8u;
+    static constexpr bool STORE_POOLED = LM == LIST_STORE_POOLED;
+    static constexpr uint32_t SLOT_BYTES = (RECORDS || STORE_POOLED) ? 16u : 8u;
     TopK<KS> top;     // LIST_REGISTERS
     TopKPacked<KS> packed;  // LIST_REGISTER_RECORDS
     ListState state;  // STORED
@@ -627,7 +631,19 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
         }
         KB_PROF_MARK(3)
         if (n_chunk != chunk) {  // chunk complete: likelihoods + top-K, while the next chunk's first group lands
-            if (tc.row_active) {
+            if constexpr (TileLists<KS, LM>::STORE_POOLED) {
+                if (tc.row_active) {
+                    float ps[C], ph[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        ps[c] = acc[c].x;
+                        ph[c] = acc[c].y;
+                    }
+                    static_assert(KS == 16, "pooled lists hold 16 slots");
+                    finish_chunk_pooled<C, FAST>(a, chunk, ps, ph, cntp, lists.state, lists.store, PooledLayout{(uint32_t)(ROWS * WAVE)},
+                                                 threadIdx.x);
+                }
+            } else if (tc.row_active) {
                 float ps[C], ph[C];
                 int cnt[C];
 #pragma unroll
@@ -712,7 +728,9 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
         lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, false>(a, tc, smem, lists);
     }
     if constexpr (!SIGMAG) {
-        if constexpr (TileLists<KS, LM>::STORED) {
+        if constexpr (TileLists<KS, LM>::STORE_POOLED) {
+            write_results_pooled(a, tc, lists.state, lists.store, PooledLayout{(uint32_t)(ROWS * WAVE)}, threadIdx.x);
+        } else if constexpr (TileLists<KS, LM>::STORED) {
             write_results_stored<TileLists<KS, LM>::RECORDS>(a, tc, lists.state, lists.store, TileLists<KS, LM>::SLOT_BYTES * threadIdx.x,
                                                          ROWS * WAVE * TileLists<KS, LM>::SLOT_BYTES);
         } else if constexpr (TileLists<KS, LM>::PACKED) {

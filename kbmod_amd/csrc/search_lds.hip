@@ -36,6 +36,12 @@ void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, int lis
         } else {
             launch_lds<8, LDS_ROWS_WIDE_K, 4, true, false, LIST_REGISTER_RECORDS, WIDE_CHUNK>(a, stream);
         }
+    } else if (a.K <= 16 && a.chunk == WIDE_CHUNK) {  // (... and stable lists of 9 to 16 with the pooled store)
+        if (tall) {
+            launch_lds<16, LDS_ROWS_TALL, 4, true, false, LIST_STORE_POOLED, WIDE_CHUNK>(a, stream);
+        } else {
+            launch_lds<16, LDS_ROWS_WIDE_K, 4, true, false, LIST_STORE_POOLED, WIDE_CHUNK>(a, stream);
+        }
     } else if (a.K <= 8) {
         if (list_mode == LIST_STORE_RECORDS) {
             launch_canon<8, LIST_STORE_RECORDS>(a, tall, stream);

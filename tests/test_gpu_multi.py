@@ -23,6 +23,23 @@ def ds():
 
 
 @pytest.fixture(scope="module")
+def ds_dyadic():
+    """Time stamps i / 16: every velocity x time product is exact in double precision, the shift table proves every epoch
+    uniform (half pixels included) and the search takes its wide-chunk instances -- `ds` (i / 20) has rounding-boundary
+    epochs, which only the chunk-of-8 instances handle."""
+    st = util.make_stack(16, 60, 100, seed=101, noise=4.0, psf=1.0, objects=OBJ, mask_fraction=0.01)
+    d = util.DeviceStack(st)
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def grid_dense():
+    # 128 candidates whose chunks of 16 (one speed, sixteen angles) spread over few pixels: staged as wide chunks
+    return fd.kbmod_v1_candidates(8, 5.0, 20.0, 16, 0.0, 0.5)
+
+
+@pytest.fixture(scope="module")
 def grid():
     return fd.kbmod_v1_candidates(12, 5.0, 40.0, 11, 0.0, 1.5)  # 132 candidates
 
@@ -142,6 +159,53 @@ def test_stable_lists_are_the_top_by_likelihood_then_candidate(ds, grid):
         both = filled[:, :-1] & filled[:, 1:]
         assert ((lh_a > lh_b) | ((lh_a == lh_b) & (c_a < c_b)))[both].all()
         assert ((lh_a == lh_b) & both).any()  # ties are present in this stack
+
+
+@pytest.mark.parametrize("K,min_obs", [(9, 0), (12, 14), (16, 16)])
+def test_pooled_stable_lists_equal_the_stored_ones(ds_dyadic, grid_dense, K, min_obs, monkeypatch):
+    """Stable lists of 9 to 16 (what the tie-exact exchange asks every device for): the wide-chunk instance with the pooled
+    list store (kb_search_lds<16, 16, ..., 4>) against the chunk-of-8 instances with (likelihood, candidate) lists and
+    against the direct kernel -- every record, bit for bit, ties included."""
+    ds = ds_dyadic
+    vx, vy = grid_dense
+    cands = ds.candidates(vx, vy)
+    p = ds.params(K=K, min_obs=min_obs)
+    got, st = ds.search_compact(p, cands, 0, 512 | 4)
+    assert "kb_search_lds<16, 16," in st.kernel_name.decode() and st.kernel_name.decode().rstrip(">").endswith(" 4")
+    monkeypatch.setenv("KBMOD_CHUNK", "8")
+    narrow, st8 = ds.search_compact(p, cands, 0, 512 | 4)
+    assert "kb_search_lds<16, 8," in st8.kernel_name.decode()
+    direct, _ = ds.search_compact(p, cands, 0, 512 | 2)
+    assert ds.torch.equal(got.view(ds.torch.int32), narrow.view(ds.torch.int32))
+    assert ds.torch.equal(got.view(ds.torch.int32), direct.view(ds.torch.int32))
+    g = util.as_records(got, util.COMPACT_DTYPE).reshape(-1, K)
+    assert (g["cand"] >= 0).all(axis=1).any()
+    if min_obs > 0:  # (trajectories that leave the image or cross masked pixels fall short: lists with empty slots)
+        assert (g["cand"] < 0).any()
+    lh_a, lh_b = g["lh"][:, :-1], g["lh"][:, 1:]
+    assert ((lh_a == lh_b) & (g["cand"][:, 1:] >= 0)).any()  # ties are present
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_tie_exact_exchange_on_the_wide_chunk_instances(ds_dyadic, grid_dense, world):
+    """The tie-exact exchange as bench.py --gpus N runs it for K = 8 -- every slice through the pooled 16-slot instance -- ==
+    the unsharded search (packed register lists, reference insertion), every field at every pixel."""
+    from kbmod_amd import distributed as kdist
+
+    ds = ds_dyadic
+    vx, vy = grid_dense
+    all_cands = ds.candidates(vx, vy)
+    p, p2 = ds.params(K=8), ds.params(K=16)
+    parts = []
+    for r in range(world):
+        lo, hi = kdist.shard_bounds(len(vx), r, world)
+        rec, st = ds.search_compact(p2, all_cands[lo:hi], lo, 512)
+        assert "kb_search_lds<16, 16," in st.kernel_name.decode()
+        parts.append(rec)
+    merged = kdist.merge_compact_exact(ds.torch.stack(parts), (0, ds.W), (0, ds.H), 8, 16, all_cands)
+    full, st = ds.search(p, all_cands, 0)
+    assert "kb_search_lds<8, 16," in st.kernel_name.decode()
+    assert ds.torch.equal(merged.view(ds.torch.int32), full.view(ds.torch.int32))
 
 
 def test_two_ranks_on_one_gpu_through_gloo(tmp_path):
