@@ -121,11 +121,24 @@ __device__ __forceinline__ bool clip_wave(const ResolveArgs& a, int lane, const 
     const int min_keep = min(below, median_ind);
     const int max_keep = max(median_ind + 1, upto) - 1;
     // ((0 + v[min_keep]) + v[min_keep + 1]) + ... + v[max_keep], chained across the lanes
+    // One v_add_f32_dpp per sum and step (written out: from chain_add the compiler makes two DPP moves and a packed add,
+    // 16 cycles of the vector unit per step instead of 8, and a scalar loop of three more instructions around them -- the
+    // chain was a third of this kernel's instructions).  A DPP read of a register needs two wait states behind the vector
+    // instruction that wrote it: the other sum's add is one, an s_nop the other.
     float acc_psi = 0.0f, acc_phi = 0.0f;
-    for (int i = min_keep; i <= max_keep; ++i) {
-        acc_psi = chain_add(acc_psi, spsi);
-        acc_phi = chain_add(acc_phi, sphi);
+#define KB_CHAIN_STEP                                                                                   \
+    "v_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                   \
+    "v_add_f32_dpp %1, %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 0\n\t"
+    int i = min_keep;
+    asm volatile("s_nop 1" : "+v"(acc_psi), "+v"(acc_phi));
+    for (; i + 3 <= max_keep; i += 4) {
+        asm volatile(KB_CHAIN_STEP KB_CHAIN_STEP KB_CHAIN_STEP KB_CHAIN_STEP : "+v"(acc_psi), "+v"(acc_phi) : "v"(spsi), "v"(sphi));
     }
+    for (; i <= max_keep; ++i) {
+        asm volatile(KB_CHAIN_STEP : "+v"(acc_psi), "+v"(acc_phi) : "v"(spsi), "v"(sphi));
+    }
+    asm volatile("s_nop 1" : "+v"(acc_psi), "+v"(acc_phi));
+#undef KB_CHAIN_STEP
     const float new_psi = lane_value(acc_psi, max_keep), new_phi = lane_value(acc_phi, max_keep);
     *lh_out = new_psi;
     *flux_out = new_phi;
