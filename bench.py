@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--reuse-padded-copy", action="store_true",
                     help="from the second step on tell the library that the array is unchanged (flag 256), as a StackSearch "
                          "with a resident array does: the decode-and-pad pass is then skipped (not the default: a step is a whole search)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="--gpus N > 1: finish every step's gather and merge before the next search starts (default: the "
+                         "gather of step i travels while step i + 1 searches; all K steps complete inside the timed region)")
     ap.add_argument("--plain-ties", action="store_true",
                     help="multi-GPU: exchange K records per pixel and break ties by candidate index (the default exchanges "
                          "2 K records built by stable insertion and reproduces the single-GPU result exactly, ties included)")
@@ -231,8 +234,10 @@ def main():
     if world > 1:
         rank_params = Params.from_buffer_copy(params)
         rank_params.results_per_pixel = list_len
-        records = torch.empty((S * list_len, 4), dtype=torch.int32, device=dev)  # kb_compact_result per slot
-        gathered = torch.empty((world, S * list_len, 4), dtype=torch.int32, device=dev) if rank == 0 else None
+        # two sets of exchange buffers: the records of step i are on the wire while step i + 1 fills the other set
+        records2 = [torch.empty((S * list_len, 4), dtype=torch.int32, device=dev) for _ in range(2)]  # kb_compact_result per slot
+        gathered2 = [torch.empty((world, S * list_len, 4), dtype=torch.int32, device=dev) if rank == 0 else None
+                     for _ in range(2)]
         results = torch.empty((S * K, 7), dtype=torch.float32, device=dev) if rank == 0 else None
     else:
         results = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
@@ -240,6 +245,13 @@ def main():
     kernel_ms = []
 
     searched = [False]
+    in_flight = [None]   # the exchange of the previous step (N > 1, overlapped)
+    which_set = [0]
+
+    def drain():
+        if in_flight[0] is not None:
+            in_flight[0].finish()
+            in_flight[0] = None
 
     def step(record):
         st = Stats()
@@ -249,11 +261,18 @@ def main():
         flags = args.flags | (256 if (searched[0] and args.reuse_padded_copy) else 0)
         searched[0] = True
         if world > 1:
+            b = which_set[0]
+            which_set[0] ^= 1
+            records, gathered = records2[b], gathered2[b]
             check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), rank_params, cands.data_ptr(),
                                                     n_local, rank * n_local, records.data_ptr(), S * list_len,
                                                     flags | (512 if exact_ties else 0), stream, C.byref(st)))
-            kdist.gather_and_merge_compact(records, (ins, W - ins), (ins, H - ins), K, all_cands, gathered=gathered,
-                                           out=results, list_len=list_len)
+            nxt = kdist.start_gather_compact(records, (ins, W - ins), (ins, H - ins), K, all_cands, gathered=gathered,
+                                             out=results, list_len=list_len)
+            drain()               # the previous step's gather has had this step's search to travel in; merge it now
+            in_flight[0] = nxt
+            if args.no_overlap:
+                drain()
         else:
             check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), n_local,
                                                    results.data_ptr(), S * K, flags, stream, C.byref(st)))
@@ -263,6 +282,7 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    drain()
 
     def barrier():
         if world > 1:
@@ -274,6 +294,7 @@ def main():
     last = None
     for _ in range(args.steps):
         last = step(True)
+    drain()   # the last step's gather and merge belong to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

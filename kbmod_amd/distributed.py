@@ -180,6 +180,54 @@ def gather_and_merge_compact(local_records, x_bounds, y_bounds, K, all_cands, gr
     return merge_compact_exact(gathered, x_bounds, y_bounds, K, list_len, all_cands, out)
 
 
+class ExchangeInFlight:
+    """One gather of per-rank record lists under way (``start_gather_compact``); ``finish()`` waits for it and merges on the
+    root.  Lets a caller that searches batch after batch overlap the exchange of batch i with the search of batch i + 1:
+    on GPUs the gather runs on RCCL's own stream (it starts when the search that filled ``local_records`` has finished,
+    and the calling stream is not held up), the merge is enqueued behind it when ``finish()`` is called.  The caller must
+    leave ``local_records`` (and ``gathered``) alone until then."""
+
+    def __init__(self, work, gathered, staged, merge_args, is_root):
+        self._work, self._gathered, self._staged, self._merge_args, self._is_root = work, gathered, staged, merge_args, is_root
+
+    def finish(self):
+        if self._work is not None:
+            self._work.wait()  # device backends: the current stream waits for the collective; host backends: blocks
+            self._work = None
+        if not self._is_root:
+            return None
+        if self._staged is not None:
+            self._gathered.copy_(self._staged)
+        x_bounds, y_bounds, K, list_len, all_cands, out = self._merge_args
+        if list_len is None or int(list_len) == int(K):
+            return merge_compact(self._gathered, x_bounds, y_bounds, K, all_cands, out)
+        return merge_compact_exact(self._gathered, x_bounds, y_bounds, K, list_len, all_cands, out)
+
+
+def start_gather_compact(local_records, x_bounds, y_bounds, K, all_cands, group=None, gathered=None, out=None, dst=0,
+                         list_len=None):
+    """The exchange of ``gather_and_merge_compact`` in two halves: starts the ONE gather (asynchronously) and returns an
+    ``ExchangeInFlight`` whose ``finish()`` completes it and merges on global rank ``dst`` (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    local_records = local_records.contiguous()
+    via_host = local_records.is_cuda and dist.get_backend(group) != "nccl"
+    send = local_records.cpu() if via_host else local_records
+    merge_args = (x_bounds, y_bounds, K, list_len, all_cands, out)
+    if not _is_root(dst, group):
+        work = dist.gather(send, None, dst=dst, group=group, async_op=True)
+        return ExchangeInFlight(work, None, None, merge_args, False)
+    if gathered is None:
+        gathered = torch.empty((world,) + tuple(local_records.shape), dtype=local_records.dtype,
+                               device=local_records.device)
+    staged = torch.empty(gathered.shape, dtype=gathered.dtype) if via_host else None
+    target = staged if via_host else gathered
+    work = dist.gather(send, [target[r] for r in range(world)], dst=dst, group=group, async_op=True)
+    return ExchangeInFlight(work, gathered, staged, merge_args, True)
+
+
 def merge_topk(gathered, n_pixels, K, out=None):
     """Merge ``gathered`` = [world, n_pixels*K, 7] per-rank lists of full 28-byte trajectories into
     [n_pixels*K, 7] (the exchange format for results_per_pixel > 32, which the compact search does not

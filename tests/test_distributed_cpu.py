@@ -63,7 +63,17 @@ def _exact_worker(rank, world, port, out_dir):
         local_t = torch.from_numpy(rec.reshape(-1).view(np.int32).reshape(S * 2 * K, 4).copy())
         all_cands = np.zeros((len(vx), 7), dtype=np.float32)
         all_cands[:, 0], all_cands[:, 1] = vx, vy
-        merged = kdist.gather_and_merge_compact(local_t, (0, 40), (0, 24), K, torch.from_numpy(all_cands), list_len=2 * K)
+        if world == 3:
+            # the exchange in two halves (what bench.py --gpus N overlaps with the next search): two under way at once
+            first = kdist.start_gather_compact(local_t, (0, 40), (0, 24), K, torch.from_numpy(all_cands), list_len=2 * K)
+            second = kdist.start_gather_compact(local_t.clone(), (0, 40), (0, 24), K, torch.from_numpy(all_cands),
+                                                list_len=2 * K)
+            merged, again = first.finish(), second.finish()
+            assert (again is None) == (rank != 0)
+            if rank == 0:
+                assert torch.equal(merged, again)
+        else:
+            merged = kdist.gather_and_merge_compact(local_t, (0, 40), (0, 24), K, torch.from_numpy(all_cands), list_len=2 * K)
         assert (merged is None) == (rank != 0)
         if rank == 0:
             full = pp.search_kernel_semantics(orc.make_candidates(vx, vy), pp.default_params(results_per_pixel=K))
