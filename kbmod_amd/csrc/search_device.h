@@ -162,6 +162,34 @@ __device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chu
     ls.stored = 1;
 }
 
+// The sums and count of candidate `sel` (per lane) out of the C register sets of a chunk, halving by the bits of `sel`: four
+// bit tests and C - 1 selects per field instead of C - 1 compares and as many selects (sel >= C selects set sel % C).
+template <int C>
+__device__ __forceinline__ void select_by_bits(const float (&ps)[C], const float (&ph)[C], const int (&cnt)[C], uint32_t sel,
+                                               float* p_out, float* f_out, int* n_out) {
+    float p[C], f[C];
+    int n[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        p[c] = ps[c];
+        f[c] = ph[c];
+        n[c] = cnt[c];
+    }
+#pragma unroll
+    for (int w = C / 2, bit = 1; w >= 1; w >>= 1, bit <<= 1) {
+        const bool odd = (sel & (uint32_t)bit) != 0u;
+#pragma unroll
+        for (int i = 0; i < w; ++i) {
+            p[i] = odd ? p[2 * i + 1] : p[2 * i];
+            f[i] = odd ? f[2 * i + 1] : f[2 * i];
+            n[i] = odd ? n[2 * i + 1] : n[2 * i];
+        }
+    }
+    *p_out = p[0];
+    *f_out = f[0];
+    *n_out = n[0];
+}
+
 // finish_chunk / epilogue for packed records in registers (kb_search_lds, lists of up to 8, long candidate lists).
 // Two steps.  (1) Screen all C candidates (above): per lane a bit mask of those that may enter its list.  (2) While
 // any lane has a bit left, EVERY lane takes its own lowest candidate -- selected out of the C register sets --,
@@ -185,15 +213,9 @@ __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int chu
     }
     while (__ballot(pending != 0u) != 0ull) {  // uniform
         const int c_sel = (int)__builtin_ctz(pending | (1u << C));  // (C: a lane with nothing left selects nothing)
-        float p = ps[0], f = ph[0];
-        int n = cnt[0];
-#pragma unroll
-        for (int c = 1; c < C; ++c) {
-            const bool pick = c_sel == c;
-            p = pick ? ps[c] : p;
-            f = pick ? ph[c] : f;
-            n = pick ? cnt[c] : n;
-        }
+        float p, f;
+        int n;
+        select_by_bits<C>(ps, ph, cnt, (uint32_t)c_sel, &p, &f, &n);
         const float lh = lh_from_sums(p, f);
         if (pending != 0u && lh > top.lh[KS - 1]) {
             top.insert(lh, flux_from_sums(p, f), (uint32_t)(chunk * C + c_sel) | ((uint32_t)n << 16), a.stable_lists != 0);

@@ -161,14 +161,14 @@ def test_stable_lists_are_the_top_by_likelihood_then_candidate(ds, grid):
         assert ((lh_a == lh_b) & both).any()  # ties are present in this stack
 
 
-@pytest.mark.parametrize("K,min_obs", [(9, 0), (12, 14), (16, 16)])
-def test_pooled_stable_lists_equal_the_stored_ones(ds_dyadic, grid_dense, K, min_obs, monkeypatch):
+@pytest.mark.parametrize("K,min_obs,n_cands", [(9, 0, 128), (12, 14, 121), (16, 16, 128), (16, 0, 39)])
+def test_pooled_stable_lists_equal_the_stored_ones(ds_dyadic, grid_dense, K, min_obs, n_cands, monkeypatch):
     """Stable lists of 9 to 16 (what the tie-exact exchange asks every device for): the wide-chunk instance with the pooled
     list store (kb_search_lds<16, 16, ..., 4>) against the chunk-of-8 instances with (likelihood, candidate) lists and
     against the direct kernel -- every record, bit for bit, ties included."""
     ds = ds_dyadic
     vx, vy = grid_dense
-    cands = ds.candidates(vx, vy)
+    cands = ds.candidates(vx[:n_cands], vy[:n_cands])  # (121, 39: a last chunk that is not full)
     p = ds.params(K=K, min_obs=min_obs)
     got, st = ds.search_compact(p, cands, 0, 512 | 4)
     assert "kb_search_lds<16, 16," in st.kernel_name.decode() and st.kernel_name.decode().rstrip(">").endswith(" 4")
