@@ -418,31 +418,44 @@ __global__ __launch_bounds__(256) void kb_sigmag_select_kernel(const ResolveArgs
     }
 
     const uint32_t* slot_row = a.sg.slots + (size_t)row * a.sg.batch_cands;
-    constexpr int AHEAD = 4;  // entries whose mask and likelihoods are fetched together
-    for (int c0 = 0; c0 < a.sg.batch_cands; c0 += WAVE) {
-        const uint32_t slot = (c0 + lane < a.sg.batch_cands) ? slot_row[c0 + lane] : 0u;
-        uint64_t m = __ballot(slot != 0u);
-        while (m != 0) {  // candidate order
-            int e[AHEAD];
-            uint64_t mask[AHEAD];
-            float lh[AHEAD];
+    // entries whose mask and likelihoods are fetched together: a row that crosses a bright mover holds hundreds of entries, walked
+    // one group after the other -- the launch ends with those rows, so the depth of a group is what its duration follows
+    constexpr int AHEAD = KS <= 8 ? 16 : 8;
+    constexpr int BLOCKS = 16;  // blocks of 64 slot words fetched together (one dependent load per block was most of this
+                                // kernel's time: a row's 1024 slots are 16 round trips when fetched one after the other)
+    for (int c_base = 0; c_base < a.sg.batch_cands; c_base += BLOCKS * WAVE) {
+        uint32_t slots[BLOCKS];
 #pragma unroll
-            for (int k = 0; k < AHEAD; ++k) {
-                e[k] = -1;
-                mask[k] = 0;
-                lh[k] = 0.0f;
-                if (m != 0) {  // uniform
-                    const int b = __ffsll((unsigned long long)m) - 1;
-                    m &= m - 1;
-                    e[k] = __builtin_amdgcn_readlane((int)slot, b) - 1;
-                    mask[k] = a.sg.entries[e[k]].mask;
-                    lh[k] = a.sg.lh[(size_t)e[k] * WAVE + lane];
+        for (int j = 0; j < BLOCKS; ++j) {
+            const int idx = c_base + j * WAVE + lane;
+            slots[j] = (idx < a.sg.batch_cands) ? slot_row[idx] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < BLOCKS; ++j) {
+            const uint32_t slot = slots[j];
+            uint64_t m = __ballot(slot != 0u);
+            while (m != 0) {  // candidate order
+                int e[AHEAD];
+                uint64_t mask[AHEAD];
+                float lh[AHEAD];
+#pragma unroll
+                for (int k = 0; k < AHEAD; ++k) {
+                    e[k] = -1;
+                    mask[k] = 0;
+                    lh[k] = 0.0f;
+                    if (m != 0) {  // uniform
+                        const int b = __ffsll((unsigned long long)m) - 1;
+                        m &= m - 1;
+                        e[k] = __builtin_amdgcn_readlane((int)slot, b) - 1;
+                        mask[k] = a.sg.entries[e[k]].mask;
+                        lh[k] = a.sg.lh[(size_t)e[k] * WAVE + lane];
+                    }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < AHEAD; ++k) {
-                // kernels.cu:318-320 on the clipped value (obs_count was tested before the clip and is unchanged)
-                if (e[k] >= 0 && ((mask[k] >> lane) & 1) && !(lh[k] < a.params.min_lh)) top.insert(lh[k], e[k], a.stable_lists != 0);
+                for (int k = 0; k < AHEAD; ++k) {
+                    // kernels.cu:318-320 on the clipped value (obs_count was tested before the clip and is unchanged)
+                    if (e[k] >= 0 && ((mask[k] >> lane) & 1) && !(lh[k] < a.params.min_lh)) top.insert(lh[k], e[k], a.stable_lists != 0);
+                }
             }
         }
     }
