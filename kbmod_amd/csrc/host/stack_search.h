@@ -333,7 +333,11 @@ public:
 
             // The result slots are written by the kernels themselves; nothing is uploaded (the reference
             // uploads S*K*28 bytes of zeros here).
-            detail::DeviceBlock raw(max_results * sizeof(Trajectory)), kept(max_results * sizeof(Trajectory));
+            // (both blocks stay with this object between searches, grown when a search needs more: two allocations and
+            // two releases of S * K * 28 bytes were a third of the time search_all spent outside the search kernel)
+            ResultBlocks& blocks = result_blocks;
+            blocks.reserve(max_results * sizeof(Trajectory));
+            detail::DeviceBlock &raw = blocks.raw, &kept = blocks.kept;
             bool fan_out = search_devices.size() > 1 && !search_list.empty();
             if (fan_out && params.results_per_pixel > 32) {
                 // (the 16-byte exchange records and the merge kernels cover lists of up to 32 per pixel)
@@ -436,6 +440,7 @@ public:
     void clear_results() {
         if (results.on_gpu()) results.move_to_cpu();
         results.resize(0);
+        result_blocks.release();  // (the device-side result buffers kept between searches go with them)
     }
     // kb_device_search_filter flags (include/kbmod_hip.h): kernel choice, self-check paths.
     void set_search_flags(uint32_t f) { search_flags = f; }
@@ -590,6 +595,23 @@ protected:
     uint32_t search_flags = 0;
     bool resident_searched = false;  // the resident array has been searched on the device since it was (re)loaded
     std::vector<int> search_devices;
+    // result buffers of search_all on the home device (raw per-pixel lists, filtered + sorted survivors)
+    struct ResultBlocks {
+        detail::DeviceBlock raw, kept;
+        uint64_t bytes = 0;
+        void reserve(uint64_t need) {
+            if (need <= bytes && raw.ptr != nullptr && kept.ptr != nullptr) return;
+            release();
+            check_status(kb_allocate_gpu_block(std::max<uint64_t>(need, 1), &raw.ptr));
+            check_status(kb_allocate_gpu_block(std::max<uint64_t>(need, 1), &kept.ptr));
+            bytes = need;
+        }
+        void release() {
+            if (raw.ptr != nullptr) (void)kb_free_gpu_block(raw.release());
+            if (kept.ptr != nullptr) (void)kb_free_gpu_block(kept.release());
+            bytes = 0;
+        }
+    } result_blocks;
     std::vector<Replica> replicas;
 };
 

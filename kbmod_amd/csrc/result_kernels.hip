@@ -7,6 +7,7 @@
 // (stable, so equal likelihoods keep their slot order -- one of the orders the
 // reference's unstable sort may produce); the kernels around them are ours.
 #include <algorithm>
+#include <mutex>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -298,6 +299,55 @@ static int sort_pairs(bool descending, K* keys_in, K* keys_out, uint32_t* val_in
 
 }  // namespace kb
 
+namespace kb {
+// Scratch arena of kb_filter_sort_results, one per device, grow-only; the lock is held for the duration of a call.
+struct ResultArena {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+constexpr int ARENA_DEVICES = 64;
+static std::mutex g_arena_mutex[ARENA_DEVICES];
+static ResultArena g_arena[ARENA_DEVICES];
+static int arena_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ARENA_DEVICES) dev = 0;
+    return dev;
+}
+struct ArenaLock {
+    int slot;
+    std::unique_lock<std::mutex> lock;
+    ArenaLock() : slot(arena_slot()), lock(g_arena_mutex[slot]) {}
+    int reserve(size_t bytes, char** out) {
+        ResultArena& a = g_arena[slot];
+        if (a.ptr != nullptr && a.bytes < bytes) {
+            (void)hipFree(a.ptr);
+            a.ptr = nullptr;
+            a.bytes = 0;
+        }
+        if (a.ptr == nullptr) {
+            KB_HIP_TRY(hipMalloc(&a.ptr, bytes));
+            a.bytes = bytes;
+        }
+        *out = static_cast<char*>(a.ptr);
+        return 0;
+    }
+};
+// (called by kb_release_workspaces)
+void release_result_arenas() {
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    for (int dev = 0; dev < ARENA_DEVICES; ++dev) {
+        std::lock_guard<std::mutex> lock(g_arena_mutex[dev]);
+        if (g_arena[dev].ptr != nullptr) {
+            (void)hipSetDevice(dev);
+            (void)hipFree(g_arena[dev].ptr);
+            g_arena[dev] = ResultArena();
+        }
+    }
+    if (have_prev) (void)hipSetDevice(prev);
+}
+}  // namespace kb
+
 extern "C" int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs,
                                       kb_trajectory* out_dev, uint64_t* n_out_host, void* stream_v) {
     using namespace kb;
@@ -309,48 +359,46 @@ extern "C" int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t
     if (results_dev == nullptr || out_dev == nullptr) return fail("filter_sort_results: null pointer");
     if (n > 0xffffffffull) return fail("filter_sort_results: more than 2^32 results");
 
-    // ---- 1. stable compaction into a temporary ----
-    Scratch compact, count, tmp, keys_in, keys_out, idx_in, idx_out;
-    KB_HIP_TRY(hipMalloc(&compact.p, n * sizeof(kb_trajectory)));
-    KB_HIP_TRY(hipMalloc(&count.p, sizeof(size_t)));
+    // One arena per device, kept between calls and grown when a call needs more (kb_release_workspaces returns it): the
+    // eight allocations and releases this function used to make per call were most of what search_all spent outside the
+    // search kernel when few results survive.  Sized for the worst case (every record survives).
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t rec_bytes = up(n * sizeof(kb_trajectory)), key_bytes = up(n * sizeof(float));
     const KeepPredicate pred{min_lh, min_obs};
-    size_t tmp_bytes = 0;
-    KB_HIP_TRY(rocprim::select(nullptr, tmp_bytes, results_dev, reinterpret_cast<kb_trajectory*>(compact.p),
-                               reinterpret_cast<size_t*>(count.p), (size_t)n, pred, stream));
-    KB_HIP_TRY(hipMalloc(&tmp.p, std::max<size_t>(tmp_bytes, 16)));
-    KB_HIP_TRY(rocprim::select(tmp.p, tmp_bytes, results_dev, reinterpret_cast<kb_trajectory*>(compact.p),
-                               reinterpret_cast<size_t*>(count.p), (size_t)n, pred, stream));
+    size_t tmp_bytes = 0, tmp2_bytes = 0;
+    KB_HIP_TRY(rocprim::select(nullptr, tmp_bytes, results_dev, static_cast<kb_trajectory*>(nullptr), static_cast<size_t*>(nullptr),
+                               (size_t)n, pred, stream));
+    KB_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, tmp2_bytes, static_cast<float*>(nullptr), static_cast<float*>(nullptr),
+                                              static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), (size_t)n, 0, 32,
+                                              stream));
+    const size_t tmp_all = up(std::max<size_t>(std::max(tmp_bytes, tmp2_bytes), 16));
+    ArenaLock arena;
+    char* base = nullptr;
+    if (arena.reserve(rec_bytes + 256 + tmp_all + 4 * key_bytes, &base)) return 1;
+    kb_trajectory* compact = reinterpret_cast<kb_trajectory*>(base);
+    size_t* count = reinterpret_cast<size_t*>(base + rec_bytes);
+    void* tmp = base + rec_bytes + 256;
+    float* keys_in = reinterpret_cast<float*>(base + rec_bytes + 256 + tmp_all);
+    float* keys_out = reinterpret_cast<float*>(base + rec_bytes + 256 + tmp_all + key_bytes);
+    uint32_t* idx_in = reinterpret_cast<uint32_t*>(base + rec_bytes + 256 + tmp_all + 2 * key_bytes);
+    uint32_t* idx_out = reinterpret_cast<uint32_t*>(base + rec_bytes + 256 + tmp_all + 3 * key_bytes);
+
+    // ---- 1. stable compaction into a temporary ----
+    KB_HIP_TRY(rocprim::select(tmp, tmp_bytes, results_dev, compact, count, (size_t)n, pred, stream));
     size_t kept = 0;
-    KB_HIP_TRY(hipMemcpyAsync(&kept, count.p, sizeof(size_t), hipMemcpyDeviceToHost, stream));
+    KB_HIP_TRY(hipMemcpyAsync(&kept, count, sizeof(size_t), hipMemcpyDeviceToHost, stream));
     KB_HIP_TRY(hipStreamSynchronize(stream));
     *n_out_host = kept;
     if (kept == 0) return 0;
 
     // ---- 2. stable descending radix sort of (lh, index) ----
-    KB_HIP_TRY(hipMalloc(&keys_in.p, kept * sizeof(float)));
-    KB_HIP_TRY(hipMalloc(&keys_out.p, kept * sizeof(float)));
-    KB_HIP_TRY(hipMalloc(&idx_in.p, kept * sizeof(uint32_t)));
-    KB_HIP_TRY(hipMalloc(&idx_out.p, kept * sizeof(uint32_t)));
     const unsigned blocks = (unsigned)((kept + 255) / 256);
-    hipLaunchKernelGGL(kb_extract_keys_kernel, dim3(blocks), dim3(256), 0, stream,
-                       reinterpret_cast<const kb_trajectory*>(compact.p), (uint64_t)kept,
-                       reinterpret_cast<float*>(keys_in.p), reinterpret_cast<uint32_t*>(idx_in.p));
+    hipLaunchKernelGGL(kb_extract_keys_kernel, dim3(blocks), dim3(256), 0, stream, compact, (uint64_t)kept, keys_in, idx_in);
     KB_HIP_TRY(hipGetLastError());
-    Scratch tmp2;
-    size_t tmp2_bytes = 0;
-    KB_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, tmp2_bytes, reinterpret_cast<float*>(keys_in.p),
-                                              reinterpret_cast<float*>(keys_out.p),
-                                              reinterpret_cast<uint32_t*>(idx_in.p),
-                                              reinterpret_cast<uint32_t*>(idx_out.p), kept, 0, 32, stream));
-    KB_HIP_TRY(hipMalloc(&tmp2.p, std::max<size_t>(tmp2_bytes, 16)));
-    KB_HIP_TRY(rocprim::radix_sort_pairs_desc(tmp2.p, tmp2_bytes, reinterpret_cast<float*>(keys_in.p),
-                                              reinterpret_cast<float*>(keys_out.p),
-                                              reinterpret_cast<uint32_t*>(idx_in.p),
-                                              reinterpret_cast<uint32_t*>(idx_out.p), kept, 0, 32, stream));
+    size_t sort_bytes = tmp2_bytes;  // (sized for n >= kept records)
+    KB_HIP_TRY(rocprim::radix_sort_pairs_desc(tmp, sort_bytes, keys_in, keys_out, idx_in, idx_out, kept, 0, 32, stream));
     // ---- 3. gather the 28-byte records in sorted order ----
-    hipLaunchKernelGGL(kb_gather_kernel, dim3(blocks), dim3(256), 0, stream,
-                       reinterpret_cast<const kb_trajectory*>(compact.p),
-                       reinterpret_cast<const uint32_t*>(idx_out.p), (uint64_t)kept, out_dev);
+    hipLaunchKernelGGL(kb_gather_kernel, dim3(blocks), dim3(256), 0, stream, compact, idx_out, (uint64_t)kept, out_dev);
     KB_HIP_TRY(hipGetLastError());
     KB_HIP_TRY(hipStreamSynchronize(stream));
     return 0;

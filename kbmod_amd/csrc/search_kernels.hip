@@ -1121,6 +1121,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     }
     return 0;
 }
+void release_result_arenas();  // result_kernels.hip: the scratch arena of kb_filter_sort_results
 }  // namespace kb
 
 extern "C" {
@@ -1145,6 +1146,7 @@ int kb_device_search_compact(const kb_psi_phi_meta* meta, const void* psi_phi_de
 
 int kb_release_workspaces(void) {
     using namespace kb;
+    release_result_arenas();
     int prev = 0;
     const bool have_prev = hipGetDevice(&prev) == hipSuccess;
     for (int dev = 0; dev < MAX_DEVICES; ++dev) {
