@@ -296,6 +296,40 @@ int kb_evaluate_trajectory_host(const kb_psi_phi_meta* meta, const void* psi_phi
 void kb_sigmag_filtered_indices(const float* values, int num_values, float sgl0, float sgl1, float sigmag_coeff,
                                 float width, int* idx_array, int* min_keep_idx, int* max_keep_idx);
 
+/* ---- FITS ingest on the device (new).  Replaces, for the image layers, what WorkUnit.from_fits /
+ * from_sharded_fits / read_image_data_from_hdul do through astropy.io.fits (work_unit.py:489-608, 782-897, 1149-1200:
+ * hdul["SCI_i"].data.astype(np.single), the same for VAR_i, sci[mask > 0] = var[mask > 0] = nan): the file's bytes are
+ * uploaded as they are and decoded in HBM into the [T][H][W] float32 stacks kb_build_psi_phi_from_device[_ex] reads.
+ * Header cards and table rows are parsed on the host (kbmod_amd/fits_ingest.py); these entry points take what that
+ * parse yields.  All three are asynchronous on `stream`. ----------------------------------------------------------- */
+/* One tile (= one row of the tiled-image table; the reference's writer makes one tile per image row) of a
+ * tiled-compressed image HDU (FITS 4.0 section 10; work_unit.py:1108-1122 writes CompImageHDU(RICE_1, quantize_level
+ * -0.01), quantize method NO_DITHER). */
+enum { KB_FITS_TILE_SKIP = 0,   /* not decoded here (a GZIP_COMPRESSED_DATA fallback tile: the host patches it in) */
+       KB_FITS_TILE_RICE = 1 }; /* COMPRESSED_DATA holds a RICE_1 stream */
+typedef struct kb_fits_tile {
+    uint64_t offset;    /* first byte of the tile's stream, relative to heap_dev */
+    uint64_t out_index; /* index of the tile's first pixel in out_dev */
+    double zscale;      /* value = (float)((double) integer * zscale + zzero): ZSCALE / ZZERO of the row (quantised */
+    double zzero;       /* float images) or BSCALE / BZERO (integer images) */
+    uint32_t nbytes;    /* length of the stream */
+    int32_t mode;       /* KB_FITS_TILE_* */
+} kb_fits_tile;
+/* RICE_1 streams -> float32 pixels (cfitsio ricecomp.c fits_rdecomp behind astropy's CompImageHDU.data).  tile_len
+ * pixels per tile; blocksize / bytepix: the ZVALn of BLOCKSIZE / BYTEPIX (32 / 4 in the reference's files); integers equal
+ * to `blank` become NaN when has_blank (ZBLANK).  status_dev[0] = number of tiles whose stream ended before their pixels
+ * did (their output is undefined), status_dev[1] = index + 1 of one of them; read it after synchronising. */
+int kb_fits_decode_rice(const uint8_t* heap_dev, uint64_t heap_bytes, const kb_fits_tile* tiles_dev, int32_t n_tiles,
+                        int32_t tile_len, int32_t blocksize, int32_t bytepix, int32_t quantized, int32_t has_blank,
+                        int32_t blank, float* out_dev, int32_t* status_dev, void* stream);
+/* The data unit of a plain IMAGE HDU (big-endian, BITPIX 8 / 16 / 32 / -32 / -64; MSK_i and PSF_i of the reference's
+ * files, every layer of an uncompressed one) -> float32: BZERO + BSCALE * array evaluated in double (astropy's
+ * _ImageBaseHDU scaling) and rounded once, `.astype(np.single)`. */
+int kb_fits_decode_image(const uint8_t* raw_dev, int32_t bitpix, double bscale, double bzero, uint64_t n_pixels,
+                         float* out_dev, void* stream);
+/* sci[mask > 0] = var[mask > 0] = NaN (work_unit.py:1187-1190; image_stack_py.py:379-383).  var_dev may be NULL. */
+int kb_fits_apply_mask(float* sci_dev, float* var_dev, const float* mask_dev, uint64_t n_pixels, void* stream);
+
 /* ---- self-test of the wavefront primitives behind the in-search sigma-G clip (new; tests only).
  * keys_dev: [n_waves][64] uint32 -> keys_out_dev ascending per wave, src_out_dev the lane each key came
  * from (DPP / permlane-swap sorting network).  values_dev: [n_waves][64] float32, bounds_dev:

@@ -1,0 +1,332 @@
+// FITS ingest on the device: the bytes of a WorkUnit file -- SCI_i / VAR_i as tiled-compressed RICE_1
+// tables, MSK_i / PSF_i as plain image HDUs (work_unit.py:1066-1147 writes them, work_unit.py:489-608 / 1149-1200 reads
+// them back through astropy) -- go to HBM AS THEY LIE IN THE FILE and are decoded there into the [T][H][W] float32
+// science / variance stacks the psi/phi builder reads.  What crosses PCIe is the compressed file (a quarter of the
+// float32 layers at the reference's quantisation), and no decoded layer ever exists in host memory.
+//
+//   kb_fits_rice_decode_kernel   one lane per tile (= image row), one RICE block (32 pixels) per lane and round into the
+//                                wave's LDS patch, then the wave writes the 64 x 32 patch out as 128-byte row segments:
+//                                the bit-serial part runs 64 tiles wide per wave, the HBM side stays coalesced;
+//   kb_fits_image_decode_kernel  big-endian BITPIX 8 / 16 / 32 / -32 / -64 -> float32 with BSCALE / BZERO;
+//   kb_fits_apply_mask_kernel    sci[mask > 0] = var[mask > 0] = NaN (work_unit.py:1187-1190).
+//
+// Bit-exact against oracle/fits_decode.py (integers exactly; value = (float)((double) integer * ZSCALE + ZZERO), one
+// multiply and one add, separately rounded -- the build keeps -ffp-contract=off).
+#include <algorithm>
+#include <cstdint>
+#include <string>
+
+#include "kb_common.h"
+
+namespace kb {
+namespace {
+
+struct RiceArgs {
+    const uint8_t* heap;
+    uint64_t heap_bytes;
+    const kb_fits_tile* tiles;
+    float* out;
+    int32_t* status;  // [0] tiles whose stream ran past its end, [1] first such tile + 1
+    int32_t n_tiles;
+    int32_t tile_len;
+    int32_t blocksize;
+    int32_t quantized;
+    int32_t has_blank;
+    int32_t blank;
+};
+
+// MSB-first bit reader over [p, end): 64-bit window, refilled four bytes at a time (bytes past the end read as zero).
+struct BitReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t buf;
+    int avail;
+    uint64_t taken;  // bytes fetched
+    __device__ __forceinline__ uint32_t fetch32() {
+        uint32_t w;
+        if (p + 4 <= end) {
+            // (global loads need no alignment on gfx950)
+            w = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(p));
+        } else {
+            w = 0;
+            for (int k = 0; k < 4; ++k) w = (w << 8) | ((p + k < end) ? (uint32_t)p[k] : 0u);
+        }
+        p += 4;
+        taken += 4;
+        return w;
+    }
+    __device__ __forceinline__ void refill() {  // afterwards at least 33 bits are available
+        if (avail <= 32) {
+            buf |= (uint64_t)fetch32() << (32 - avail);
+            avail += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t take(int n) {  // 0 <= n <= 32, after refill()
+        const uint32_t v = n ? (uint32_t)(buf >> (64 - n)) : 0u;
+        buf = n ? (buf << n) : buf;
+        avail -= n;
+        return v;
+    }
+    __device__ __forceinline__ uint64_t bits_used() const { return taken * 8u - (uint64_t)avail; }
+};
+
+constexpr int PATCH_PITCH = 33;  // words per lane in the wave's LDS patch (odd: lanes hit distinct banks)
+
+template <int BYTEPIX>
+__global__ __launch_bounds__(256) void kb_fits_rice_decode_kernel(RiceArgs a) {
+    constexpr int FSBITS = BYTEPIX == 4 ? 5 : (BYTEPIX == 2 ? 4 : 3);
+    constexpr int FSMAX = BYTEPIX == 4 ? 25 : (BYTEPIX == 2 ? 14 : 6);
+    constexpr int BBITS = 8 * BYTEPIX;
+    constexpr uint32_t WRAP = BYTEPIX == 4 ? 0xffffffffu : ((1u << (BBITS & 31)) - 1u);
+    __shared__ int32_t patch_all[4][WAVE * PATCH_PITCH];
+    __shared__ double scale_all[4][WAVE], zero_all[4][WAVE];
+    __shared__ uint64_t first_all[4][WAVE];  // a row's first output pixel; ~0 for rows that are not decoded here
+    const int lane = (int)threadIdx.x & (WAVE - 1), wv = (int)threadIdx.x / WAVE;
+    int32_t* patch = patch_all[wv];
+    const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wv) * WAVE;
+    if (tile0 >= a.n_tiles) return;  // (whole waves leave: nothing below synchronises across waves)
+    const int64_t tile = tile0 + lane;
+    const bool live = tile < a.n_tiles;
+    kb_fits_tile td{};
+    if (live) td = a.tiles[tile];
+    const bool decode = live && td.mode == KB_FITS_TILE_RICE && td.nbytes > (uint32_t)BYTEPIX;
+    scale_all[wv][lane] = td.zscale;
+    zero_all[wv][lane] = td.zzero;
+    first_all[wv][lane] = (live && td.mode == KB_FITS_TILE_RICE) ? td.out_index : ~0ull;
+
+    BitReader br;
+    br.p = a.heap + td.offset;
+    br.end = decode ? br.p + td.nbytes : br.p;
+    br.buf = 0;
+    br.avail = 0;
+    br.taken = 0;
+    uint32_t lastpix = 0;
+    if (decode) {
+        for (int k = 0; k < BYTEPIX; ++k) lastpix = (lastpix << 8) | (uint32_t)br.p[k];
+        br.p += BYTEPIX;
+        br.taken = BYTEPIX;
+    }
+    const int nblk = (a.tile_len + a.blocksize - 1) / a.blocksize;
+    const int rows_here = (int)min((int64_t)WAVE, (int64_t)a.n_tiles - tile0);
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int i0 = blk * a.blocksize;
+        const int n = min(a.blocksize, a.tile_len - i0);
+        // the block may be wider than the 32-pixel patch (BLOCKSIZE is a file parameter): it goes out in pieces of 32
+        int done = 0;
+        uint32_t fs_code = 0;
+        if (decode) {
+            br.refill();
+            fs_code = br.take(FSBITS);
+        }
+        while (done < n) {
+            const int m = min(32, n - done);
+            if (decode) {
+                if (fs_code == 0) {  // every difference is zero
+                    for (int k = 0; k < m; ++k) patch[lane * PATCH_PITCH + k] = (int32_t)lastpix;
+                } else if (fs_code == (uint32_t)FSMAX + 1u) {  // verbatim differences
+                    for (int k = 0; k < m; ++k) {
+                        br.refill();
+                        uint32_t d = br.take(BBITS);
+                        d = (d & 1u) ? ~(d >> 1) : (d >> 1);
+                        lastpix = (lastpix + d) & WRAP;
+                        patch[lane * PATCH_PITCH + k] = (int32_t)lastpix;
+                    }
+                } else {
+                    const int fs = (int)fs_code - 1;
+                    for (int k = 0; k < m; ++k) {
+                        uint32_t zeros = 0;
+                        for (;;) {  // the unary part: zero bits up to the next one bit
+                            br.refill();
+                            const int z = br.buf ? __builtin_clzll(br.buf) : 64;
+                            if (z < br.avail) {
+                                zeros += (uint32_t)z;
+                                br.buf <<= z;  // z <= 63
+                                br.buf <<= 1;
+                                br.avail -= z + 1;
+                                break;
+                            }
+                            zeros += (uint32_t)br.avail;
+                            br.buf = 0;
+                            br.avail = 0;
+                            if (br.p >= br.end + 8) break;  // a stream without its end: flagged below
+                        }
+                        br.refill();
+                        uint32_t d = (zeros << fs) | br.take(fs);
+                        d = (d & 1u) ? ~(d >> 1) : (d >> 1);
+                        lastpix = (lastpix + d) & WRAP;
+                        patch[lane * PATCH_PITCH + k] = (int32_t)lastpix;
+                    }
+                }
+            }
+            // (one wave = one patch: the wave's own LDS writes are visible to it once they have landed)
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+            const int col = lane & 31, half = lane >> 5;
+            for (int r2 = 0; r2 < rows_here; r2 += 2) {
+                const int r = r2 + half;
+                if (r < rows_here && col < m) {
+                    const uint64_t first = first_all[wv][r];
+                    if (first != ~0ull) {
+                        int32_t iv = patch[r * PATCH_PITCH + col];
+                        if (BYTEPIX == 2) iv = (int32_t)(int16_t)iv;
+                        if (BYTEPIX == 1) iv = (int32_t)(int8_t)iv;
+                        float v;
+                        if (a.has_blank && iv == a.blank) {
+                            v = __builtin_nanf("");
+                        } else {
+                            v = (float)((double)iv * scale_all[wv][r] + zero_all[wv][r]);
+                        }
+                        a.out[first + (uint64_t)(i0 + done + col)] = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            done += m;
+        }
+    }
+    if (decode) {
+        const uint64_t used = (br.bits_used() + 7u) / 8u;
+        if (used > (uint64_t)td.nbytes) {
+            atomicAdd(&a.status[0], 1);
+            atomicCAS(&a.status[1], 0, (int32_t)(tile + 1));
+        }
+    } else if (live && td.mode == KB_FITS_TILE_RICE) {  // too short to hold its first pixel
+        atomicAdd(&a.status[0], 1);
+        atomicCAS(&a.status[1], 0, (int32_t)(tile + 1));
+    }
+}
+
+struct ImageArgs {
+    const uint8_t* raw;
+    float* out;
+    uint64_t n;
+    double bscale, bzero;
+    int32_t plain;  // BSCALE = 1, BZERO = 0
+};
+
+template <int BITPIX>
+__device__ __forceinline__ float decode_pixel(const uint8_t* raw, uint64_t i, const ImageArgs& a) {
+    if constexpr (BITPIX == -32) {
+        const uint32_t w = __builtin_bswap32(reinterpret_cast<const uint32_t*>(raw)[i]);
+        const float f = __uint_as_float(w);
+        return a.plain ? f : (float)((double)f * a.bscale + a.bzero);
+    } else if constexpr (BITPIX == -64) {
+        const uint64_t w = __builtin_bswap64(reinterpret_cast<const uint64_t*>(raw)[i]);
+        const double d = __longlong_as_double((long long)w);
+        return a.plain ? (float)d : (float)(d * a.bscale + a.bzero);
+    } else if constexpr (BITPIX == 8) {
+        return (float)((double)raw[i] * a.bscale + a.bzero);
+    } else if constexpr (BITPIX == 16) {
+        const uint16_t w = reinterpret_cast<const uint16_t*>(raw)[i];
+        const int16_t v = (int16_t)((w >> 8) | (w << 8));
+        return (float)((double)v * a.bscale + a.bzero);
+    } else {
+        const int32_t v = (int32_t)__builtin_bswap32(reinterpret_cast<const uint32_t*>(raw)[i]);
+        return (float)((double)v * a.bscale + a.bzero);
+    }
+}
+
+// One pixel per thread and trip, four trips per thread a block apart (coalesced on both sides).
+template <int BITPIX>
+__global__ __launch_bounds__(256) void kb_fits_image_decode_kernel(ImageArgs a) {
+    const uint64_t base = (uint64_t)blockIdx.x * 1024u + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint64_t i = base + (uint64_t)k * 256u;
+        if (i < a.n) a.out[i] = decode_pixel<BITPIX>(a.raw, i, a);
+    }
+}
+
+__global__ __launch_bounds__(256) void kb_fits_apply_mask_kernel(float* sci, float* var, const float* mask, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n && mask[i] > 0.0f) {
+        sci[i] = __builtin_nanf("");
+        if (var != nullptr) var[i] = __builtin_nanf("");
+    }
+}
+
+}  // namespace
+}  // namespace kb
+
+extern "C" int kb_fits_decode_rice(const uint8_t* heap_dev, uint64_t heap_bytes, const kb_fits_tile* tiles_dev,
+                                   int32_t n_tiles, int32_t tile_len, int32_t blocksize, int32_t bytepix, int32_t quantized,
+                                   int32_t has_blank, int32_t blank, float* out_dev, int32_t* status_dev, void* stream_v) {
+    using namespace kb;
+    if (n_tiles == 0) return 0;
+    KB_REQUIRE_DEVICE("the FITS tile decoder.");
+    if (heap_dev == nullptr || tiles_dev == nullptr || out_dev == nullptr || status_dev == nullptr) {
+        return fail("fits_decode_rice: null pointer");
+    }
+    if (n_tiles < 0 || tile_len <= 0 || blocksize <= 0) return fail("fits_decode_rice: invalid tile geometry");
+    if (bytepix != 1 && bytepix != 2 && bytepix != 4) return fail("fits_decode_rice: BYTEPIX must be 1, 2 or 4");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    RiceArgs a;
+    a.heap = heap_dev;
+    a.heap_bytes = heap_bytes;
+    a.tiles = tiles_dev;
+    a.out = out_dev;
+    a.status = status_dev;
+    a.n_tiles = n_tiles;
+    a.tile_len = tile_len;
+    a.blocksize = blocksize;
+    a.quantized = quantized;
+    a.has_blank = has_blank;
+    a.blank = blank;
+    KB_HIP_TRY(hipMemsetAsync(status_dev, 0, 2 * sizeof(int32_t), stream));
+    const unsigned blocks = (unsigned)(((int64_t)n_tiles + 4 * WAVE - 1) / (4 * WAVE));
+    if (bytepix == 4) {
+        hipLaunchKernelGGL(kb_fits_rice_decode_kernel<4>, dim3(blocks), dim3(256), 0, stream, a);
+    } else if (bytepix == 2) {
+        hipLaunchKernelGGL(kb_fits_rice_decode_kernel<2>, dim3(blocks), dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(kb_fits_rice_decode_kernel<1>, dim3(blocks), dim3(256), 0, stream, a);
+    }
+    KB_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int kb_fits_decode_image(const uint8_t* raw_dev, int32_t bitpix, double bscale, double bzero, uint64_t n_pixels,
+                                    float* out_dev, void* stream_v) {
+    using namespace kb;
+    if (n_pixels == 0) return 0;
+    KB_REQUIRE_DEVICE("the FITS image decoder.");
+    if (raw_dev == nullptr || out_dev == nullptr) return fail("fits_decode_image: null pointer");
+    const int width = bitpix < 0 ? -bitpix / 8 : bitpix / 8;
+    if (bitpix != 8 && bitpix != 16 && bitpix != 32 && bitpix != -32 && bitpix != -64) {
+        return fail("fits_decode_image: BITPIX " + std::to_string(bitpix) + " is not an image type this decoder reads");
+    }
+    if (reinterpret_cast<uintptr_t>(raw_dev) % (uintptr_t)width != 0) {
+        return fail("fits_decode_image: the data unit must be aligned to its element size");
+    }
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    ImageArgs a;
+    a.raw = raw_dev;
+    a.out = out_dev;
+    a.n = n_pixels;
+    a.bscale = bscale;
+    a.bzero = bzero;
+    a.plain = (bscale == 1.0 && bzero == 0.0) ? 1 : 0;
+    const dim3 grid((unsigned)((n_pixels + 1023u) / 1024u)), block(256);
+    switch (bitpix) {
+        case -32: hipLaunchKernelGGL(kb_fits_image_decode_kernel<-32>, grid, block, 0, stream, a); break;
+        case -64: hipLaunchKernelGGL(kb_fits_image_decode_kernel<-64>, grid, block, 0, stream, a); break;
+        case 8: hipLaunchKernelGGL(kb_fits_image_decode_kernel<8>, grid, block, 0, stream, a); break;
+        case 16: hipLaunchKernelGGL(kb_fits_image_decode_kernel<16>, grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL(kb_fits_image_decode_kernel<32>, grid, block, 0, stream, a); break;
+    }
+    KB_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int kb_fits_apply_mask(float* sci_dev, float* var_dev, const float* mask_dev, uint64_t n_pixels, void* stream_v) {
+    using namespace kb;
+    if (n_pixels == 0) return 0;
+    KB_REQUIRE_DEVICE("the FITS mask pass.");
+    if (sci_dev == nullptr || mask_dev == nullptr) return fail("fits_apply_mask: null pointer");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    hipLaunchKernelGGL(kb_fits_apply_mask_kernel, dim3((unsigned)((n_pixels + 255u) / 256u)), dim3(256), 0, stream, sci_dev,
+                       var_dev, mask_dev, n_pixels);
+    KB_HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -501,6 +501,25 @@ PYBIND11_MODULE(search, m) {
                     py::arg("sci_stack"), py::arg("var_stack"), py::arg("psf_kernels"), py::arg("zeroed_times"),
                     py::arg("num_bytes") = -1, py::arg("separable_psf") = false, py::arg("empty_footprint_is_zero") = false,
                     py::arg("register_host_memory") = true)
+            // stacks that already live on the current device (kbmod_amd.fits_ingest decodes WorkUnit files there)
+            .def_static(
+                    "from_device_stacks",
+                    [](uintptr_t sci_dev, uintptr_t var_dev, unsigned int T, unsigned int H, unsigned int W,
+                       const std::vector<conv_array>& psfs, std::vector<double> times, int num_bytes, bool separable_psf,
+                       bool empty_footprint_is_zero) {
+                        std::vector<Image> p = to_images(psfs);
+                        const uint32_t flags = (separable_psf ? (uint32_t)KB_BUILD_SEPARABLE : 0u) |
+                                               (empty_footprint_is_zero ? (uint32_t)KB_BUILD_EMPTY_IS_ZERO : 0u);
+                        return std::unique_ptr<StackSearch>(new StackSearch(
+                                StackSearch::DeviceStacks{}, reinterpret_cast<const float*>(sci_dev),
+                                reinterpret_cast<const float*>(var_dev), T, H, W, p, times, num_bytes, flags));
+                    },
+                    py::arg("sci_dev"), py::arg("var_dev"), py::arg("num_times"), py::arg("height"), py::arg("width"),
+                    py::arg("psf_kernels"), py::arg("zeroed_times"), py::arg("num_bytes") = -1,
+                    py::arg("separable_psf") = false, py::arg("empty_footprint_is_zero") = false,
+                    "StackSearch over science / variance stacks [T][H][W] float32 that already are in the memory of the current "
+                    "device (addresses as integers): psi/phi is built there, nothing is uploaded.  The stacks may be released "
+                    "once the call returns.")
             .def("set_search_devices", &StackSearch::set_search_devices,
                  "Devices the GPU search fans out over: the candidate list is cut into contiguous slices, one host "
                  "thread per slice on its device, per-pixel lists merged on the current device.  For up to 16 results "

@@ -186,6 +186,41 @@ public:
         timer.stop();
     }
 
+    // The same build from stacks that are ALREADY on the current device (what kbmod_amd.fits_ingest leaves there after
+    // decoding a WorkUnit file in HBM): kb_build_psi_phi_from_device_ex on the null stream, nothing crosses PCIe.
+    struct DeviceStacks {};
+    StackSearch(DeviceStacks, const float* sci_dev, const float* var_dev, unsigned int T, unsigned int H, unsigned int W,
+                std::vector<Image>& psf_kernels, std::vector<double>& zeroed_times_in, int num_bytes, uint32_t build_flags)
+            : zeroed_times(zeroed_times_in), results(0) {
+        rs_logger = logging::getLogger("kbmod.search.run_search");
+        num_imgs = T;
+        detail::require(num_imgs != 0 && H != 0 && W != 0, "No images in the to process.");
+        detail::require(sci_dev != nullptr && var_dev != nullptr, "Null device stack.");
+        check_count("PSF kernel", "PSF Kernels", psf_kernels.size());
+        check_count_times(zeroed_times.size());
+        detail::require(has_gpu(), "GPU is not available for the psi/phi build.");
+        width = W;
+        height = H;
+        set_default_parameters(num_bytes);
+        DebugTimer timer = DebugTimer("preparing Psi and Phi images", rs_logger);
+        std::vector<int32_t> dims(T);
+        std::vector<float> psf_packed;
+        for (unsigned int i = 0; i < T; ++i) {
+            detail::require(psf_kernels[i].rows == psf_kernels[i].cols, "PSF kernel must be square.");
+            dims[i] = (int32_t)psf_kernels[i].rows;
+            psf_packed.insert(psf_packed.end(), psf_kernels[i].data.begin(), psf_kernels[i].data.end());
+        }
+        kb_psi_phi_meta meta;
+        void* dev = nullptr;
+        check_status(kb_build_psi_phi_from_device_ex(sci_dev, var_dev, psf_packed.data(), dims.data(), (int32_t)T, (int32_t)H,
+                                                     (int32_t)W, num_bytes, build_flags, &meta, &dev, nullptr));
+        check_status(kb_device_synchronize());
+        psi_phi_array.adopt_device_array(meta, dev);
+        psi_phi_array.set_time_array(zeroed_times);
+        psi_phi_preloaded = false;
+        timer.stop();
+    }
+
     virtual ~StackSearch() {
         drop_replicas();
         psi_phi_array.clear();
