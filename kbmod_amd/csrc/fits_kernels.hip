@@ -35,30 +35,53 @@ struct RiceArgs {
     int32_t blank;
 };
 
-// MSB-first bit reader over [p, end): 64-bit window, refilled four bytes at a time (bytes past the end read as zero).
+// MSB-first bit reader over a tile's stream: a 64-bit window refilled 32 bits at a time out of a two-word ready queue; the
+// eight bytes behind the queue are requested from memory the moment the queue is filled, so that a load has the decoding
+// of 64 bits (about six pixels) to land in instead of stalling the lane's serial chain.  Loads may run past the tile's
+// last byte into its neighbour's (never past the heap: those bytes read as zero); a well-formed stream does not consume
+// them, and a stream that does is flagged by its bit count.
 struct BitReader {
-    const uint8_t* p;
-    const uint8_t* end;
-    uint64_t buf;
-    int avail;
-    uint64_t taken;  // bytes fetched
-    __device__ __forceinline__ uint32_t fetch32() {
-        uint32_t w;
-        if (p + 4 <= end) {
-            // (global loads need no alignment on gfx950)
-            w = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(p));
+    const uint8_t* p;         // next eight bytes to request
+    const uint8_t* heap_end;
+    uint64_t buf;             // the window, valid bits at the top
+    uint64_t ready;           // up to two big-endian words, the next one in the high half
+    uint64_t pending;         // the eight bytes behind them, as loaded
+    int avail;                // valid bits in the window
+    int n_ready;
+    uint32_t taken;           // bytes moved into the window so far
+    __device__ __forceinline__ uint64_t load8() {
+        uint64_t w;
+        if (p + 8 <= heap_end) {
+            w = *reinterpret_cast<const uint64_t*>(p);  // (global loads need no alignment on gfx950)
         } else {
             w = 0;
-            for (int k = 0; k < 4; ++k) w = (w << 8) | ((p + k < end) ? (uint32_t)p[k] : 0u);
+            for (int k = 7; k >= 0; --k) w = (w << 8) | ((p + k < heap_end) ? (uint64_t)p[k] : 0ull);
         }
-        p += 4;
-        taken += 4;
+        p += 8;
         return w;
+    }
+    __device__ __forceinline__ void start(const uint8_t* first, const uint8_t* end_of_heap) {
+        p = first;
+        heap_end = end_of_heap;
+        buf = 0;
+        ready = 0;
+        avail = 0;
+        n_ready = 0;
+        taken = 0;
+        pending = load8();
     }
     __device__ __forceinline__ void refill() {  // afterwards at least 33 bits are available
         if (avail <= 32) {
-            buf |= (uint64_t)fetch32() << (32 - avail);
+            if (n_ready == 0) {
+                ready = __builtin_bswap64(pending);
+                n_ready = 2;
+                pending = load8();
+            }
+            buf |= (ready >> 32) << (32 - avail);
+            ready <<= 32;
+            --n_ready;
             avail += 32;
+            taken += 4;
         }
     }
     __device__ __forceinline__ uint32_t take(int n) {  // 0 <= n <= 32, after refill()
@@ -67,7 +90,7 @@ struct BitReader {
         avail -= n;
         return v;
     }
-    __device__ __forceinline__ uint64_t bits_used() const { return taken * 8u - (uint64_t)avail; }
+    __device__ __forceinline__ uint64_t bits_used() const { return (uint64_t)taken * 8u - (uint64_t)avail; }
 };
 
 constexpr int PATCH_PITCH = 33;  // words per lane in the wave's LDS patch (odd: lanes hit distinct banks)
@@ -94,17 +117,12 @@ __global__ __launch_bounds__(256) void kb_fits_rice_decode_kernel(RiceArgs a) {
     zero_all[wv][lane] = td.zzero;
     first_all[wv][lane] = (live && td.mode == KB_FITS_TILE_RICE) ? td.out_index : ~0ull;
 
-    BitReader br;
-    br.p = a.heap + td.offset;
-    br.end = decode ? br.p + td.nbytes : br.p;
-    br.buf = 0;
-    br.avail = 0;
-    br.taken = 0;
+    BitReader br{};
     uint32_t lastpix = 0;
     if (decode) {
-        for (int k = 0; k < BYTEPIX; ++k) lastpix = (lastpix << 8) | (uint32_t)br.p[k];
-        br.p += BYTEPIX;
-        br.taken = BYTEPIX;
+        br.start(a.heap + td.offset, a.heap + a.heap_bytes);
+        br.refill();
+        lastpix = br.take(BBITS);  // the first pixel verbatim
     }
     const int nblk = (a.tile_len + a.blocksize - 1) / a.blocksize;
     const int rows_here = (int)min((int64_t)WAVE, (int64_t)a.n_tiles - tile0);
@@ -148,7 +166,7 @@ __global__ __launch_bounds__(256) void kb_fits_rice_decode_kernel(RiceArgs a) {
                             zeros += (uint32_t)br.avail;
                             br.buf = 0;
                             br.avail = 0;
-                            if (br.p >= br.end + 8) break;  // a stream without its end: flagged below
+                            if (br.taken > td.nbytes + 16u) break;  // a stream without its end: flagged below
                         }
                         br.refill();
                         uint32_t d = (zeros << fs) | br.take(fs);
