@@ -46,19 +46,20 @@ struct BitReader {
     uint64_t buf;             // the window, valid bits at the top
     uint64_t ready;           // up to two big-endian words, the next one in the high half
     uint64_t pending;         // the eight bytes behind them, as loaded
+    uint32_t pending_over;    // how many of those lie past the heap's end (the load was moved back by as many)
     int avail;                // valid bits in the window
     int n_ready;
     uint32_t taken;           // bytes moved into the window so far
-    __device__ __forceinline__ uint64_t load8() {
-        uint64_t w;
-        if (p + 8 <= heap_end) {
-            w = *reinterpret_cast<const uint64_t*>(p);  // (global loads need no alignment on gfx950)
-        } else {
-            w = 0;
-            for (int k = 7; k >= 0; --k) w = (w << 8) | ((p + k < heap_end) ? (uint64_t)p[k] : 0ull);
-        }
+    __device__ __forceinline__ void request8() {
+        // Branch-free, and the loaded value is not touched here (any arithmetic on it -- or a branch that makes the
+        // compiler merge it into another register -- is a wait for the load this queue exists to hide): within eight
+        // bytes of the heap's end the load is moved back to end there, and the shift that makes bytes past the end read
+        // as zero is applied when the word is promoted.  The heap holds at least eight bytes (checked by the launcher);
+        // global loads need no alignment on gfx950.
+        const int64_t over64 = (p + 8) - heap_end;
+        pending_over = over64 > 0 ? (uint32_t)(over64 < 8 ? over64 : 8) : 0u;
+        pending = *reinterpret_cast<const uint64_t*>(over64 > 8 ? heap_end - 8 : p - pending_over);
         p += 8;
-        return w;
     }
     __device__ __forceinline__ void start(const uint8_t* first, const uint8_t* end_of_heap) {
         p = first;
@@ -68,14 +69,14 @@ struct BitReader {
         avail = 0;
         n_ready = 0;
         taken = 0;
-        pending = load8();
+        request8();
     }
     __device__ __forceinline__ void refill() {  // afterwards at least 33 bits are available
         if (avail <= 32) {
             if (n_ready == 0) {
-                ready = __builtin_bswap64(pending);
+                ready = __builtin_bswap64(pending_over >= 8u ? 0ull : (pending >> (8u * pending_over)));
                 n_ready = 2;
-                pending = load8();
+                request8();
             }
             buf |= (ready >> 32) << (32 - avail);
             ready <<= 32;
@@ -93,7 +94,11 @@ struct BitReader {
     __device__ __forceinline__ uint64_t bits_used() const { return (uint64_t)taken * 8u - (uint64_t)avail; }
 };
 
-constexpr int PATCH_PITCH = 33;  // words per lane in the wave's LDS patch (odd: lanes hit distinct banks)
+#ifndef KB_FITS_PATCH_COLS
+#define KB_FITS_PATCH_COLS 32
+#endif
+constexpr int PATCH_COLS = KB_FITS_PATCH_COLS;  // pixels per lane and round (32 = one RICE block of the reference's files; 16 -- 19 KB of LDS per block, eight waves per SIMD -- measured slower: 3.86 vs 3.37 ms)
+constexpr int PATCH_PITCH = PATCH_COLS + 1;  // words per lane in the wave's LDS patch (odd: lanes hit distinct banks)
 
 template <int BYTEPIX>
 __global__ __launch_bounds__(256) void kb_fits_rice_decode_kernel(RiceArgs a) {
@@ -101,11 +106,10 @@ __global__ __launch_bounds__(256) void kb_fits_rice_decode_kernel(RiceArgs a) {
     constexpr int FSMAX = BYTEPIX == 4 ? 25 : (BYTEPIX == 2 ? 14 : 6);
     constexpr int BBITS = 8 * BYTEPIX;
     constexpr uint32_t WRAP = BYTEPIX == 4 ? 0xffffffffu : ((1u << (BBITS & 31)) - 1u);
-    __shared__ int32_t patch_all[4][WAVE * PATCH_PITCH];
-    __shared__ double scale_all[4][WAVE], zero_all[4][WAVE];
+    __shared__ float patch_all[4][WAVE * PATCH_PITCH];
     __shared__ uint64_t first_all[4][WAVE];  // a row's first output pixel; ~0 for rows that are not decoded here
     const int lane = (int)threadIdx.x & (WAVE - 1), wv = (int)threadIdx.x / WAVE;
-    int32_t* patch = patch_all[wv];
+    float* patch = patch_all[wv];
     const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wv) * WAVE;
     if (tile0 >= a.n_tiles) return;  // (whole waves leave: nothing below synchronises across waves)
     const int64_t tile = tile0 + lane;
@@ -113,9 +117,18 @@ __global__ __launch_bounds__(256) void kb_fits_rice_decode_kernel(RiceArgs a) {
     kb_fits_tile td{};
     if (live) td = a.tiles[tile];
     const bool decode = live && td.mode == KB_FITS_TILE_RICE && td.nbytes > (uint32_t)BYTEPIX;
-    scale_all[wv][lane] = td.zscale;
-    zero_all[wv][lane] = td.zzero;
     first_all[wv][lane] = (live && td.mode == KB_FITS_TILE_RICE) ? td.out_index : ~0ull;
+    // integer -> pixel value, by the lane that decoded it (it holds its row's ZSCALE / ZZERO): two double operations, each
+    // rounded, then one rounding to float -- what numpy / cfitsio compute
+    const double zscale = td.zscale, zzero = td.zzero;
+    const int has_blank = a.has_blank, blank = a.blank;
+    auto value_of = [&](uint32_t pix) -> float {
+        int32_t iv = (int32_t)pix;
+        if (BYTEPIX == 2) iv = (int32_t)(int16_t)pix;
+        if (BYTEPIX == 1) iv = (int32_t)(int8_t)pix;
+        const float v = (float)((double)iv * zscale + zzero);
+        return (has_blank && iv == blank) ? __builtin_nanf("") : v;
+    };
 
     BitReader br{};
     uint32_t lastpix = 0;
@@ -126,10 +139,11 @@ __global__ __launch_bounds__(256) void kb_fits_rice_decode_kernel(RiceArgs a) {
     }
     const int nblk = (a.tile_len + a.blocksize - 1) / a.blocksize;
     const int rows_here = (int)min((int64_t)WAVE, (int64_t)a.n_tiles - tile0);
+    float* my_row = patch + lane * PATCH_PITCH;
     for (int blk = 0; blk < nblk; ++blk) {
         const int i0 = blk * a.blocksize;
         const int n = min(a.blocksize, a.tile_len - i0);
-        // the block may be wider than the 32-pixel patch (BLOCKSIZE is a file parameter): it goes out in pieces of 32
+        // a block (BLOCKSIZE is a file parameter, 32 in the reference's files) goes out in pieces of PATCH_COLS pixels
         int done = 0;
         uint32_t fs_code = 0;
         if (decode) {
@@ -137,64 +151,82 @@ __global__ __launch_bounds__(256) void kb_fits_rice_decode_kernel(RiceArgs a) {
             fs_code = br.take(FSBITS);
         }
         while (done < n) {
-            const int m = min(32, n - done);
+            const int m = min(PATCH_COLS, n - done);
             if (decode) {
                 if (fs_code == 0) {  // every difference is zero
-                    for (int k = 0; k < m; ++k) patch[lane * PATCH_PITCH + k] = (int32_t)lastpix;
+                    const float v = value_of(lastpix);
+                    for (int k = 0; k < m; ++k) my_row[k] = v;
                 } else if (fs_code == (uint32_t)FSMAX + 1u) {  // verbatim differences
                     for (int k = 0; k < m; ++k) {
                         br.refill();
                         uint32_t d = br.take(BBITS);
                         d = (d & 1u) ? ~(d >> 1) : (d >> 1);
                         lastpix = (lastpix + d) & WRAP;
-                        patch[lane * PATCH_PITCH + k] = (int32_t)lastpix;
+                        my_row[k] = value_of(lastpix);
                     }
                 } else {
                     const int fs = (int)fs_code - 1;
                     for (int k = 0; k < m; ++k) {
-                        uint32_t zeros = 0;
-                        for (;;) {  // the unary part: zero bits up to the next one bit
-                            br.refill();
-                            const int z = br.buf ? __builtin_clzll(br.buf) : 64;
-                            if (z < br.avail) {
-                                zeros += (uint32_t)z;
-                                br.buf <<= z;  // z <= 63
-                                br.buf <<= 1;
-                                br.avail -= z + 1;
-                                break;
+                        br.refill();  // at least 33 valid bits: the top 32 of the window are all stream bits
+                        const uint32_t hi = (uint32_t)(br.buf >> 32);
+                        const int z32 = hi ? __builtin_clz(hi) : 32;
+                        const int len = z32 + 1 + fs;
+                        uint32_t d;
+                        if (len <= 32) {
+                            // the whole code -- zeros, the one bit, FS low bits -- lies in those 32 bits: 32-bit arithmetic
+                            // and ONE shift of the window (64-bit shifts are the slow instructions of this loop)
+                            const uint32_t low = fs ? ((hi << (z32 + 1)) >> (32 - fs)) : 0u;  // (fs > 0: z32 + 1 <= 31)
+                            d = ((uint32_t)z32 << fs) | low;
+                            br.buf <<= len;
+                            br.avail -= len;
+                        } else {
+                            uint32_t zeros = 0;
+                            for (;;) {  // a long unary part: zero bits up to the next one bit, window by window
+                                br.refill();
+                                const int z = br.buf ? __builtin_clzll(br.buf) : 64;
+                                if (z < br.avail) {
+                                    zeros += (uint32_t)z;
+                                    br.buf <<= z;  // z <= 63
+                                    br.buf <<= 1;
+                                    br.avail -= z + 1;
+                                    break;
+                                }
+                                zeros += (uint32_t)br.avail;
+                                br.buf = 0;
+                                br.avail = 0;
+                                if (br.taken > td.nbytes + 16u) break;  // a stream without its end: flagged below
                             }
-                            zeros += (uint32_t)br.avail;
-                            br.buf = 0;
-                            br.avail = 0;
-                            if (br.taken > td.nbytes + 16u) break;  // a stream without its end: flagged below
+                            br.refill();
+                            d = (zeros << fs) | br.take(fs);
                         }
-                        br.refill();
-                        uint32_t d = (zeros << fs) | br.take(fs);
                         d = (d & 1u) ? ~(d >> 1) : (d >> 1);
                         lastpix = (lastpix + d) & WRAP;
-                        patch[lane * PATCH_PITCH + k] = (int32_t)lastpix;
+                        my_row[k] = value_of(lastpix);
                     }
                 }
             }
             // (one wave = one patch: the wave's own LDS writes are visible to it once they have landed)
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
             __builtin_amdgcn_wave_barrier();
-            const int col = lane & 31, half = lane >> 5;
-            for (int r2 = 0; r2 < rows_here; r2 += 2) {
-                const int r = r2 + half;
-                if (r < rows_here && col < m) {
+            // the 64 x PATCH_COLS patch out: four pixels per lane, PATCH_COLS / 4 lanes per row
+            constexpr int LANES_PER_ROW = PATCH_COLS / 4, ROWS_PER_TRIP = WAVE / LANES_PER_ROW;
+            const int c0 = 4 * (lane % LANES_PER_ROW), sub = lane / LANES_PER_ROW;
+            for (int r8 = 0; r8 < rows_here; r8 += ROWS_PER_TRIP) {
+                const int r = r8 + sub;
+                if (r < rows_here && c0 < m) {
                     const uint64_t first = first_all[wv][r];
                     if (first != ~0ull) {
-                        int32_t iv = patch[r * PATCH_PITCH + col];
-                        if (BYTEPIX == 2) iv = (int32_t)(int16_t)iv;
-                        if (BYTEPIX == 1) iv = (int32_t)(int8_t)iv;
-                        float v;
-                        if (a.has_blank && iv == a.blank) {
-                            v = __builtin_nanf("");
+                        const float* src = patch + r * PATCH_PITCH + c0;
+                        float* dst = a.out + first + (uint64_t)(i0 + done + c0);
+                        const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                        if (c0 + 3 < m && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+                            *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
                         } else {
-                            v = (float)((double)iv * scale_all[wv][r] + zero_all[wv][r]);
+                            dst[0] = v0;
+                            if (c0 + 1 < m) dst[1] = v1;
+                            if (c0 + 2 < m) dst[2] = v2;
+                            if (c0 + 3 < m) dst[3] = v3;
                         }
-                        a.out[first + (uint64_t)(i0 + done + col)] = v;
                     }
                 }
             }
@@ -278,6 +310,7 @@ extern "C" int kb_fits_decode_rice(const uint8_t* heap_dev, uint64_t heap_bytes,
     }
     if (n_tiles < 0 || tile_len <= 0 || blocksize <= 0) return fail("fits_decode_rice: invalid tile geometry");
     if (bytepix != 1 && bytepix != 2 && bytepix != 4) return fail("fits_decode_rice: BYTEPIX must be 1, 2 or 4");
+    if (heap_bytes < 8) return fail("fits_decode_rice: the heap must hold at least eight bytes");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     RiceArgs a;
     a.heap = heap_dev;
