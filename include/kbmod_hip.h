@@ -71,6 +71,9 @@ typedef struct kb_search_stats {
     int32_t padded_copy_reused;   /* flag 256 was honoured: no decode-and-pad pass in this search */
     int32_t special_epochs;       /* kb_search_lds: (chunk of candidates, epoch) pairs summed per lane -- not staged, or a shift
                                      inside the guard band of a rounding boundary -- instead of by the uniform loops */
+    int32_t edge_count_tables;    /* kb_search_lds: tables of epochs per shift were built, so that tiles at the image's edge of a
+                                     stack without NO_DATA pixels take their observation counts from them instead of counting samples */
+    int32_t reserved0;
 } kb_search_stats;
 
 const char* kb_last_error(void);

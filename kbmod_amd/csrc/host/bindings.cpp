@@ -631,6 +631,7 @@ PYBIND11_MODULE(search, m) {
                 d["sigmag_literal"] = st.sigmag_literal;
                 d["kernel_name"] = std::string(st.kernel_name);
                 d["special_epochs"] = st.special_epochs;
+                d["edge_count_tables"] = st.edge_count_tables;
                 return d;
             },
                  "Measurements of the last device search: kernel and table times (HIP events), evaluations, "

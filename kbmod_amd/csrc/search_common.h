@@ -167,6 +167,12 @@ struct SearchCold {
     int fast_decode;           // uint8/uint16: the fp32-FMA decode was verified bit-identical for every code
     float* sg_scratch;         // sigma-G per-lane scratch of the literal clip, or null
     SigmaGWork sg;
+    // Observation counts of tiles at the image's edge without counting samples (kb_edge_count_kernel; null when not built):
+    // [chunk][4: x towards +, x towards -, y towards +, y towards -][d = 0 .. edge_D][WIDE_CHUNK counts as uint16, candidate c
+    // in half c & 1 of word c >> 1] = epochs of candidate c whose shift along that axis and direction is at most d pixels.
+    const uint4* edge_tab;
+    const int* edge_ok;        // device flag: every candidate's shifts grow monotonically along both axes (see there)
+    int edge_D;
 };
 
 struct SearchArgs {

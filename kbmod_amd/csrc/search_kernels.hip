@@ -67,6 +67,56 @@ __device__ __forceinline__ int uniform_shift(float v, double t, int* kind) {
     return (int)fl;
 }
 
+// Tables behind edge_counts (search_lds.h): for chunk `blockIdx.x`, per axis and direction, per distance d = 0 .. D and
+// candidate c of the chunk, the number of epochs whose integer shift along that axis and direction is at most d -- i.e. the
+// epochs at which a start pixel d pixels from that edge of the image is still on it.  Rows of C uint16 (32 bytes), laid
+// out [chunk][x+, x-, y+, y-][d][c].  *ok is cleared when some candidate's shifts do not grow monotonically in magnitude
+// with one sign along an axis: only then are the four epoch sets leading runs of the epochs and their intersection the
+// shortest of them.
+template <int C>
+__global__ __launch_bounds__(256) void kb_edge_count_kernel(const int2* __restrict__ table, int n_cands, int T, int D,
+                                                            unsigned short* __restrict__ tab, int* __restrict__ ok) {
+    const int chunk = (int)blockIdx.x;
+    const int2* tc = table + (size_t)chunk * T * C;
+    const int D1 = D + 1;
+    const int live = min(C, n_cands - chunk * C);
+    for (int i = (int)threadIdx.x; i < 2 * D1 * C; i += (int)blockDim.x) {
+        const int c = i % C, d = (i / C) % D1, axis = i / (C * D1);
+        int plus = 0, minus = 0;
+        if (c < live) {
+            for (int e = 0; e < T; ++e) {
+                const int2 s = tc[e * C + c];
+                const int v = axis ? s.y : s.x;
+                plus += (v <= d) ? 1 : 0;
+                minus += (-v <= d) ? 1 : 0;
+            }
+        }
+        unsigned short* rows = tab + ((size_t)chunk * 4 + 2 * axis) * D1 * C;
+        rows[(size_t)d * C + c] = (unsigned short)plus;
+        rows[((size_t)D1 + d) * C + c] = (unsigned short)minus;
+    }
+    if ((int)threadIdx.x < 2 * C) {
+        const int c = (int)threadIdx.x % C, axis = (int)threadIdx.x / C;
+        bool good = true;
+        if (c < live) {
+            int prev = 0, sign = 0;
+            for (int e = 0; e < T; ++e) {
+                const int2 s = tc[e * C + c];
+                const int v = axis ? s.y : s.x;
+                if (v != 0) {
+                    const int sv = v > 0 ? 1 : -1;
+                    good = good && (sign == 0 || sign == sv);
+                    sign = sv;
+                }
+                const int mag = v < 0 ? -v : v;
+                good = good && mag >= prev && mag <= D;
+                prev = mag;
+            }
+        }
+        if (!good) atomicExch(ok, 0);
+    }
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory* __restrict__ cands,
                                                              const double* __restrict__ times, int n_cands,
@@ -481,9 +531,10 @@ struct Workspace {
 // different host threads (StackSearch's fan-out), searches on one device one after the other.
 constexpr int MAX_DEVICES = 64;
 static std::mutex g_ws_mutex[MAX_DEVICES];
-static Workspace g_ws_all[MAX_DEVICES][7];  // 0: shift table + chunk info, 1: literal sigma-G scratch, 2: padded array copy (LDS kernel),
+static Workspace g_ws_all[MAX_DEVICES][8];  // 0: shift table + chunk info, 1: literal sigma-G scratch, 2: padded array copy (LDS kernel),
                             // 3: sigma-G work items + clipped values, 4: second per-pixel list buffer (sigma-G batches),
-                            // 5: cold block of the kernel arguments, 6: per-pixel lists of kb_search_lds between chunks
+                            // 5: cold block of the kernel arguments, 6: per-pixel lists of kb_search_lds between chunks,
+                            // 7: observation counts per shift for tiles at the image's edge (kb_edge_count_kernel)
 
 // What the padded copy in workspace 2 of a device was made from (flag 256 of the search entry points: the caller
 // vouches that the array has not changed since its last search; the copy is then reused when everything else that
@@ -766,6 +817,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     bool wide_store_failed = false;  // lists of 9 to 16 with wide chunks live in the list store: without it, chunks of CHUNK
     void* wide_lists = nullptr;
     int special_epochs = 0;
+    int shift_box[4] = {0, 0, 0, 0};  // staged shift box of the tables that settled: dx_min, dx_max, dy_min, dy_max
     for (bool settled = n_cands == 0; !settled;) {
         a.n_chunks = (int)((n_cands + a.chunk - 1) / a.chunk);
         which = 0;
@@ -824,6 +876,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
             KB_HIP_TRY(hipStreamSynchronize(stream));
             // (the wide-chunk instance has no path for epochs that are not staged with uniform shifts)
             wide_has_special = back[0] != 0 || back[6] != 0;
+            for (int k = 0; k < 4; ++k) shift_box[k] = back[1 + k];
             special_epochs = back[0] + back[6];
             // An unstaged epoch costs several times a staged one: above 10 % the direct kernel wins.
             const uint64_t n_epochs = (uint64_t)a.n_chunks * (uint64_t)a.T;
@@ -995,6 +1048,36 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         }
     }
 
+    // Observation counts for tiles at the image's edge out of tables instead of one vector instruction per sample
+    // (edge_counts, search_lds.h): for the wide-chunk instances with lists, when every epoch is staged with uniform
+    // shifts, the start pixels lie on the image and the shifts are small enough for the tables.  Whether a tile uses
+    // them is decided on the device: the stack must hold no NO_DATA pixel (the pad pass counts them) and the shifts
+    // must be monotone (the table kernel checks).  KBMOD_EDGE_COUNTS = 0 keeps the counting loops (tests, comparisons).
+    cold.edge_tab = nullptr;
+    cold.edge_ok = nullptr;
+    cold.edge_D = 0;
+    int edge_tables = 0;
+    if (which == 2 && a.chunk == WIDE_CHUNK && params.do_sigmag_filter == 0 && a.all_staged && shift_box[0] <= shift_box[1] &&
+        params.x_start_min >= 0 && params.y_start_min >= 0 && params.x_start_max <= a.W && params.y_start_max <= a.H) {
+        const int D = std::max(std::max(-shift_box[0], shift_box[1]), std::max(std::max(-shift_box[2], shift_box[3]), 0));
+        const char* env = std::getenv("KBMOD_EDGE_COUNTS");
+        const size_t tab_bytes = (size_t)a.n_chunks * 4 * (size_t)(D + 1) * WIDE_CHUNK * sizeof(unsigned short);
+        void* et = nullptr;
+        if (!(env != nullptr && std::atoi(env) == 0) && D <= 1023 && tab_bytes <= (256ull << 20) &&
+            try_workspace(7, tab_bytes + 64, &et)) {
+            int* ok = reinterpret_cast<int*>(static_cast<char*>(et) + tab_bytes);
+            static const int one = 1;
+            KB_HIP_TRY(hipMemcpyAsync(ok, &one, sizeof(int), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL((kb_edge_count_kernel<WIDE_CHUNK>), dim3(a.n_chunks), dim3(256), 0, stream, a.table, a.n_cands,
+                               a.T, D, reinterpret_cast<unsigned short*>(et), ok);
+            KB_HIP_TRY(hipGetLastError());
+            cold.edge_tab = reinterpret_cast<const uint4*>(et);
+            cold.edge_ok = ok;
+            cold.edge_D = D;
+            edge_tables = 1;
+        }
+    }
+
     // the cold block of the kernel arguments (search_common.h) lives in device memory
     void* cold_dev = nullptr;
     if (ensure_workspace(5, sizeof(SearchCold), &cold_dev)) return 1;
@@ -1107,6 +1190,8 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         std::snprintf(stats_out->kernel_name, sizeof(stats_out->kernel_name), "%s", g_kernel_instance);
         stats_out->padded_copy_reused = padded_reused;
         stats_out->special_epochs = which != 0 ? special_epochs : 0;
+        stats_out->edge_count_tables = edge_tables;
+        stats_out->reserved0 = 0;
         if (cold.sg.totals != nullptr) {
             unsigned long long totals[3] = {0, 0, 0};
             KB_HIP_TRY(hipMemcpyAsync(totals, cold.sg.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));

@@ -219,6 +219,41 @@ __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) 
     return p;
 }
 
+// Observation counts of a chunk's candidates for a lane of a tile at the image's edge, without counting samples.  In a
+// stack without a NO_DATA pixel a sample is NO_DATA exactly when it lies off the image, so for start pixel (x, y) and a
+// candidate with integer shifts (dx_e, dy_e) the count is the number of epochs with 0 <= x + dx_e < W and 0 <= y + dy_e < H.
+// kb_edge_count_kernel has tabulated, per candidate, axis and direction, how many epochs shift at most d pixels; when the
+// shifts of every candidate grow monotonically along both axes (its flag; any list of epochs in time order does) each of
+// those epoch sets is a leading run of the epochs, and the count is the shortest of the four runs: four 32-byte rows
+// (16 candidates each) and 24 packed minima per chunk instead of one vector instruction per sample.
+template <int C>
+__device__ __forceinline__ void edge_counts(const SearchArgs& a, const TileCoords& tq, int chunk, const uint4* edge_tab,
+                                            int edge_D, uint32_t (&cnte)[C / 2]) {
+    static_assert(C == 16, "rows of the edge tables hold 16 counts");
+    typedef unsigned short Us2 __attribute__((ext_vector_type(2)));
+    const int D1 = edge_D + 1;
+    const uint4* base = edge_tab + (size_t)chunk * 4 * D1 * 2;
+    auto clampd = [&](int d) { return min(max(d, 0), edge_D); };
+    const int d[4] = {clampd(a.W - 1 - tq.x), clampd(tq.x), clampd(a.H - 1 - tq.y), clampd(tq.y)};
+    uint32_t m[C / 2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint4 lo = base[(k * D1 + d[k]) * 2], hi = base[(k * D1 + d[k]) * 2 + 1];
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int j = 0; j < C / 2; ++j) {
+            if (k == 0) {
+                m[j] = w[j];
+            } else {
+                const Us2 r = __builtin_elementwise_min(__builtin_bit_cast(Us2, m[j]), __builtin_bit_cast(Us2, w[j]));
+                m[j] = __builtin_bit_cast(uint32_t, r);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < C / 2; ++j) cnte[j] = m[j];
+}
+
 // The whole search of one tile.  One flat software pipeline over (chunk, group): while
 // group g is summed out of one LDS buffer, group g+1 -- possibly the first group of the next
 // chunk -- is copied into the other, one slab per summed epoch: its loads are issued before
@@ -227,7 +262,7 @@ __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) 
 // every shift, the array has no NO_DATA pixel, every epoch is staged): obs_count is T.
 template <int KS, int C, int ROWS, int NB, bool CANON, bool SIGMAG, int LM, bool FAST>
 __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileCoords& tc, char* smem,
-                                                TileLists<KS, LM>& lists) {
+                                                TileLists<KS, LM>& lists, const uint4* edge_tab = nullptr, int edge_D = 0) {
     constexpr int SF = CANON ? 4 : NB;  // staged format
     using R = RawPair<SF>;
     constexpr int BYTES = 2 * fmt_bytes(SF);
@@ -640,8 +675,20 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                         ph[c] = acc[c].y;
                     }
                     static_assert(KS == 16, "pooled lists hold 16 slots");
-                    finish_chunk_pooled<C, FAST>(a, chunk, ps, ph, cntp, lists.state, lists.store, PooledLayout{(uint32_t)(ROWS * WAVE)},
-                                                 threadIdx.x);
+                    bool by_table = false;
+                    if constexpr (FAST && C == WIDE_CHUNK) {
+                        if (edge_tab != nullptr) {  // (uniform) a tile at the image's edge: counts out of the tables
+                            uint32_t cnte[C / 2];
+                            edge_counts<C>(a, tq, chunk, edge_tab, edge_D, cnte);
+                            finish_chunk_pooled<C, false>(a, chunk, ps, ph, cnte, lists.state, lists.store,
+                                                          PooledLayout{(uint32_t)(ROWS * WAVE)}, threadIdx.x);
+                            by_table = true;
+                        }
+                    }
+                    if (!by_table) {
+                        finish_chunk_pooled<C, FAST>(a, chunk, ps, ph, cntp, lists.state, lists.store,
+                                                     PooledLayout{(uint32_t)(ROWS * WAVE)}, threadIdx.x);
+                    }
                 }
             } else if (tc.row_active) {
                 float ps[C], ph[C];
@@ -651,6 +698,14 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     ps[c] = acc[c].x;
                     ph[c] = acc[c].y;
                     cnt[c] = FAST ? T : (int)((cntp[c >> 1] >> (16 * (c & 1))) & 0xffffu);
+                }
+                if constexpr (FAST && C == WIDE_CHUNK) {
+                    if (edge_tab != nullptr) {  // (uniform) a tile at the image's edge: counts out of the tables
+                        uint32_t cnte[C / 2];
+                        edge_counts<C>(a, tq, chunk, edge_tab, edge_D, cnte);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) cnt[c] = (int)((cnte[c >> 1] >> (16 * (c & 1))) & 0xffffu);
+                    }
                 }
 #ifdef KB_EXP_NO_FINISH
                 if constexpr (TileLists<KS, LM>::PACKED) {
@@ -718,12 +773,26 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
     const bool fast = a.all_staged && as_const_ints(a.n_invalid)[0] == 0 && (tc.tile_x0 + gb[0] >= 0) &&
                       (tc.tile_x0 + WAVE + gb[1] <= a.W) && (tc.tile_y0 + gb[2] >= 0) &&
                       (tc.tile_y0 + ROWS + gb[3] <= a.H);
+    // ... and if it can, only by leaving the image (no NO_DATA pixel in it, every epoch staged with uniform shifts, tables of
+    // the candidates' epochs per shift built and valid): the count-free loops + counts out of the tables (edge_counts)
+    const uint4* edge_tab = nullptr;
+    int edge_D = 0;
+    if constexpr (C == WIDE_CHUNK && !SIGMAG && (LM == LIST_REGISTER_RECORDS || LM == LIST_STORE_POOLED)) {
+        if (!fast && a.all_staged && as_const_ints(a.n_invalid)[0] == 0) {
+            const SearchCold* cold = a.cold;
+            const uint4* tab = cold->edge_tab;
+            if (tab != nullptr && as_const_ints(cold->edge_ok)[0] != 0) {
+                edge_tab = tab;
+                edge_D = cold->edge_D;
+            }
+        }
+    }
 #ifdef KB_EXP_ALL_FAST
     if (true) {
 #else
-    if (fast) {
+    if (fast || edge_tab != nullptr) {
 #endif
-        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, true>(a, tc, smem, lists);
+        lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, true>(a, tc, smem, lists, edge_tab, edge_D);
     } else {
         lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, false>(a, tc, smem, lists);
     }

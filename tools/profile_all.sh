@@ -10,3 +10,11 @@ tools/sq_build.sh ${R}_builder 32 4096 > /dev/null
 bash tools/p2.sh > gpurun_out/${R}_builder_variants.md 2>&1
 python bench.py > gpurun_out/${R}_bench_default.json 2>/dev/null
 ls gpurun_out | grep ${R}_ | head -80
+# the FITS ingest kernels (tools/fits_ingest_timing.py): kernel-trace stats + the HBM-side byte counters
+export TMPDIR=/tmp
+rm -rf /tmp/kt_fits; rocprofv3 --kernel-trace --stats -d /tmp/kt_fits -o r -- python tools/fits_ingest_timing.py > gpurun_out/${R}_fits_timing.log 2>/tmp/kt_fits.log
+python tools/rocprof_summary.py /tmp/kt_fits/r_results.db > gpurun_out/${R}_fits_kernel_stats.md
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_fits; rocprofv3 --pmc $C -d /tmp/pmc_fits -o r -- python tools/fits_ingest_timing.py > /dev/null 2>&1
+  python tools/rocprof_summary.py /tmp/pmc_fits/r_results.db /tmp/pmc_fits/r_results.db | grep -E "kb_fits|counter \||---\|---\|---\|---\|---\|---" > gpurun_out/${R}_fits_pmc_$C.md
+done
