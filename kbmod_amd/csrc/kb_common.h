@@ -48,9 +48,17 @@ struct EventTimer {
         if (active) (void)hipEventRecord(start, stream);
     }
     float end() {  // synchronises on the stop event
+        mark_end();
+        return elapsed();
+    }
+    // The two halves of end(): record the stop event now, read the time later (after work that follows has been
+    // enqueued), so that the host does not stand still in the middle of a sequence of launches.
+    void mark_end() {
+        if (active) (void)hipEventRecord(stop, stream);
+    }
+    float elapsed() {  // synchronises on the stop event
         if (!active) return 0.0f;
         float ms = 0.0f;
-        (void)hipEventRecord(stop, stream);
         (void)hipEventSynchronize(stop);
         (void)hipEventElapsedTime(&ms, start, stop);
         return ms;

@@ -76,44 +76,45 @@ __device__ __forceinline__ int uniform_shift(float v, double t, int* kind) {
 template <int C>
 __global__ __launch_bounds__(256) void kb_edge_count_kernel(const int2* __restrict__ table, int n_cands, int T, int D,
                                                             unsigned short* __restrict__ tab, int* __restrict__ ok) {
+    // Per (axis, direction, candidate): a histogram of the distance from which an epoch counts, in LDS, filled by all
+    // threads over (epoch, candidate) -- a thread per candidate walking its epochs is a chain of T dependent loads, 33 us --,
+    // then running sums over d.
+    extern __shared__ unsigned int edge_hist[];  // [2 axes][2 directions][C][D + 1]
     const int chunk = (int)blockIdx.x;
     const int2* tc = table + (size_t)chunk * T * C;
     const int D1 = D + 1;
     const int live = min(C, n_cands - chunk * C);
-    for (int i = (int)threadIdx.x; i < 2 * D1 * C; i += (int)blockDim.x) {
-        const int c = i % C, d = (i / C) % D1, axis = i / (C * D1);
-        int plus = 0, minus = 0;
-        if (c < live) {
-            for (int e = 0; e < T; ++e) {
-                const int2 s = tc[e * C + c];
-                const int v = axis ? s.y : s.x;
-                plus += (v <= d) ? 1 : 0;
-                minus += (-v <= d) ? 1 : 0;
-            }
+    for (int i = (int)threadIdx.x; i < 4 * C * D1; i += (int)blockDim.x) edge_hist[i] = 0u;
+    __syncthreads();
+    bool good = true;
+    for (int i = (int)threadIdx.x; i < T * C; i += (int)blockDim.x) {
+        const int e = i / C, c = i % C;
+        if (c >= live) continue;
+        const int2 s = tc[i];
+        const int2 before = e > 0 ? tc[i - C] : make_int2(0, 0);
+#pragma unroll
+        for (int axis = 0; axis < 2; ++axis) {
+            const int v = axis ? s.y : s.x, u = axis ? before.y : before.x;
+            const int mag = v < 0 ? -v : v, mag_before = u < 0 ? -u : u;
+            // magnitudes that never shrink and never change sign (a shrinking one would have to pass through zero)
+            good = good && mag >= mag_before && mag <= D && (long long)v * (long long)u >= 0;
+            // towards +: the epoch counts from distance max(v, 0) on; towards -: from max(-v, 0) on
+            atomicAdd(&edge_hist[((size_t)(2 * axis) * C + c) * D1 + min(max(v, 0), D)], 1u);
+            atomicAdd(&edge_hist[((size_t)(2 * axis + 1) * C + c) * D1 + min(max(-v, 0), D)], 1u);
         }
-        unsigned short* rows = tab + ((size_t)chunk * 4 + 2 * axis) * D1 * C;
-        rows[(size_t)d * C + c] = (unsigned short)plus;
-        rows[((size_t)D1 + d) * C + c] = (unsigned short)minus;
     }
-    if ((int)threadIdx.x < 2 * C) {
-        const int c = (int)threadIdx.x % C, axis = (int)threadIdx.x / C;
-        bool good = true;
-        if (c < live) {
-            int prev = 0, sign = 0;
-            for (int e = 0; e < T; ++e) {
-                const int2 s = tc[e * C + c];
-                const int v = axis ? s.y : s.x;
-                if (v != 0) {
-                    const int sv = v > 0 ? 1 : -1;
-                    good = good && (sign == 0 || sign == sv);
-                    sign = sv;
-                }
-                const int mag = v < 0 ? -v : v;
-                good = good && mag >= prev && mag <= D;
-                prev = mag;
-            }
+    if (!good) atomicExch(ok, 0);
+    __syncthreads();
+    // running sums over d, one thread per (axis, direction, candidate); rows of C counts out
+    if ((int)threadIdx.x < 4 * C) {
+        const int c = (int)threadIdx.x % C, k = (int)threadIdx.x / C;  // k = 2 * axis + direction
+        const unsigned int* h = edge_hist + ((size_t)k * C + c) * D1;
+        unsigned short* rows = tab + ((size_t)chunk * 4 + k) * D1 * C;
+        unsigned int run = 0;
+        for (int d = 0; d < D1; ++d) {
+            run += h[d];
+            rows[(size_t)d * C + c] = (unsigned short)run;
         }
-        if (!good) atomicExch(ok, 0);
     }
 }
 
@@ -923,10 +924,19 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 bool canon = meta->num_bytes == 4 || (flags & 16u) == 0;
                 const bool encoded_instance = (params.do_sigmag_filter != 0 || a.K <= 8) && lds_rows == LDS_ROWS_WIDE_K &&
                                               tables_for_encoded;  // search_lds_encoded.hip (slab pitches in its quantum)
+                // (the device's free memory is asked for only when the workspace kept from earlier searches is too small:
+                // the query costs tens of microseconds per search)
                 size_t free_b = 0, total_b = 0;
-                KB_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+                bool asked = false;
                 const uint64_t have = g_ws[2].ptr != nullptr ? g_ws[2].bytes : 0;
-                auto room_for = [&](uint64_t bytes) { return bytes <= have || bytes + (2ull << 30) <= (uint64_t)free_b + have; };
+                auto room_for = [&](uint64_t bytes) {
+                    if (bytes <= have) return true;
+                    if (!asked) {
+                        asked = true;
+                        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+                    }
+                    return bytes + (2ull << 30) <= (uint64_t)free_b + have;
+                };
                 if (canon && meta->num_bytes != 4 && !room_for(frame * 8ull + 64)) canon = false;
                 const uint64_t pair_bytes = canon ? 8ull : 2ull * (uint64_t)meta->block_size;
                 const uint64_t padded_bytes = frame * pair_bytes + 64;
@@ -984,7 +994,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 }
             }
         }
-        table_ms = table_timer.end();
+        table_timer.mark_end();  // (read behind the search: the host goes on to launch it)
         if (a.chunk == WIDE_CHUNK && which == 2 && !wide_has_special && params.do_sigmag_filter == 0 && a.K > 8) {
             const SearchArgs at = with_tile_rows(a, lds_rows);
             wide_store_failed = !try_workspace(6, (size_t)at.n_tiles * 16 * block_threads(lds_rows) * 16, &wide_lists);
@@ -1063,13 +1073,14 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         const char* env = std::getenv("KBMOD_EDGE_COUNTS");
         const size_t tab_bytes = (size_t)a.n_chunks * 4 * (size_t)(D + 1) * WIDE_CHUNK * sizeof(unsigned short);
         void* et = nullptr;
-        if (!(env != nullptr && std::atoi(env) == 0) && D <= 1023 && tab_bytes <= (256ull << 20) &&
+        if (!(env != nullptr && std::atoi(env) == 0) && D <= 200 && tab_bytes <= (256ull << 20) &&
             try_workspace(7, tab_bytes + 64, &et)) {
             int* ok = reinterpret_cast<int*>(static_cast<char*>(et) + tab_bytes);
             static const int one = 1;
             KB_HIP_TRY(hipMemcpyAsync(ok, &one, sizeof(int), hipMemcpyHostToDevice, stream));
-            hipLaunchKernelGGL((kb_edge_count_kernel<WIDE_CHUNK>), dim3(a.n_chunks), dim3(256), 0, stream, a.table, a.n_cands,
-                               a.T, D, reinterpret_cast<unsigned short*>(et), ok);
+            hipLaunchKernelGGL((kb_edge_count_kernel<WIDE_CHUNK>), dim3(a.n_chunks), dim3(256),
+                               4 * WIDE_CHUNK * (size_t)(D + 1) * sizeof(unsigned int), stream, a.table, a.n_cands, a.T, D,
+                               reinterpret_cast<unsigned short*>(et), ok);
             KB_HIP_TRY(hipGetLastError());
             cold.edge_tab = reinterpret_cast<const uint4*>(et);
             cold.edge_ok = ok;
@@ -1165,6 +1176,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     }
     KB_HIP_TRY(hipGetLastError());
     search_ms = search_timer.end();
+    table_ms = n_cands != 0 ? table_timer.elapsed() : 0.0f;
     if (which != 0 && std::getenv("KBMOD_DEBUG") != nullptr) {
         int bad = -1;
         KB_HIP_TRY(hipMemcpyAsync(&bad, a.n_invalid, sizeof(int), hipMemcpyDeviceToHost, stream));
