@@ -1059,7 +1059,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     }
 
     // Observation counts for tiles at the image's edge out of tables instead of one vector instruction per sample
-    // (edge_counts, search_lds.h): for the wide-chunk instances with lists, when every epoch is staged with uniform
+    // (edge_counts, search_lds.h): for the wide-chunk instances, when every epoch is staged with uniform
     // shifts, the start pixels lie on the image and the shifts are small enough for the tables.  Whether a tile uses
     // them is decided on the device: the stack must hold no NO_DATA pixel (the pad pass counts them) and the shifts
     // must be monotone (the table kernel checks).  KBMOD_EDGE_COUNTS = 0 keeps the counting loops (tests, comparisons).
@@ -1067,7 +1067,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     cold.edge_ok = nullptr;
     cold.edge_D = 0;
     int edge_tables = 0;
-    if (which == 2 && a.chunk == WIDE_CHUNK && params.do_sigmag_filter == 0 && a.all_staged && shift_box[0] <= shift_box[1] &&
+    if (which == 2 && a.chunk == WIDE_CHUNK && a.all_staged && shift_box[0] <= shift_box[1] &&
         params.x_start_min >= 0 && params.y_start_min >= 0 && params.x_start_max <= a.W && params.y_start_max <= a.H) {
         const int D = std::max(std::max(-shift_box[0], shift_box[1]), std::max(std::max(-shift_box[2], shift_box[3]), 0));
         const char* env = std::getenv("KBMOD_EDGE_COUNTS");

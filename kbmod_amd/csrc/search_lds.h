@@ -777,7 +777,7 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
     // the candidates' epochs per shift built and valid): the count-free loops + counts out of the tables (edge_counts)
     const uint4* edge_tab = nullptr;
     int edge_D = 0;
-    if constexpr (C == WIDE_CHUNK && !SIGMAG && (LM == LIST_REGISTER_RECORDS || LM == LIST_STORE_POOLED)) {
+    if constexpr (C == WIDE_CHUNK && (SIGMAG || LM == LIST_REGISTER_RECORDS || LM == LIST_STORE_POOLED)) {
         if (!fast && a.all_staged && as_const_ints(a.n_invalid)[0] == 0) {
             const SearchCold* cold = a.cold;
             const uint4* tab = cold->edge_tab;

@@ -132,3 +132,26 @@ def test_stable_lists_of_the_exchange_use_the_tables(orc):
         assert (rec["obs_count"][rec["cand"] >= 0] < 10).any()
     finally:
         ds.close()
+
+
+def test_sigma_g_emitting_instance_uses_the_tables(orc):
+    """In-search sigma-G: the counts only decide which trajectories are emitted for clipping (min_obs on the unclipped count)."""
+    stack = _stack(12, 96, 200, seed=10)
+    for num_bytes in (-1, 1):
+        ds = util.DeviceStack(stack, num_bytes)
+        try:
+            vx, vy = GRIDS["all directions"]
+            cfg = dict(K=4, min_obs=8, sigmag=(0.25, 0.75, 0.7413, 2.0))
+            got, st = ds.search(ds.params(**cfg), ds.candidates(vx, vy), 0)
+            assert st.edge_count_tables == 1 and ", true, 0>" in st.kernel_name.decode(), st.kernel_name
+            pp = orc.PsiPhi.from_images(stack.sci, stack.var, stack.psfs, stack.zeroed_times, num_bytes)
+            exp = pp.search_kernel_semantics(orc.make_candidates(vx, vy), util.oracle_params(pp, cfg))
+            _same(got, exp, ("sigma-G", num_bytes))
+            os.environ["KBMOD_EDGE_COUNTS"] = "0"
+            try:
+                counted, st0 = ds.search(ds.params(**cfg), ds.candidates(vx, vy), 0)
+            finally:
+                del os.environ["KBMOD_EDGE_COUNTS"]
+            assert st0.edge_count_tables == 0 and counted.cpu().numpy().tobytes() == got.cpu().numpy().tobytes()
+        finally:
+            ds.close()
