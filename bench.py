@@ -396,6 +396,8 @@ def main():
             "note": "; ".join(note),
             "kernel": instance,
             "kernel_ms": k_ms,
+            "obs_counts": ("border tiles from tables of epochs per shift (the stack has no masked pixel), none needed elsewhere"
+                           if int(last.edge_count_tables) and args.mask_fraction == 0.0 else "counted per sample where NO_DATA can occur"),
             "kernel_evals_per_s": evals_per_step_rank / (k_ms * 1e-3),
             "frac_algorithmic": alg_rate / HBM_PEAK_GBPS,
             "algorithmic_bytes_per_launch": int(last.algorithmic_bytes),

@@ -321,7 +321,9 @@ typedef struct kb_fits_tile {
 /* RICE_1 streams -> float32 pixels (cfitsio ricecomp.c fits_rdecomp behind astropy's CompImageHDU.data).  tile_len
  * pixels per tile; blocksize / bytepix: the ZVALn of BLOCKSIZE / BYTEPIX (32 / 4 in the reference's files); integers equal
  * to `blank` become NaN when has_blank (ZBLANK).  status_dev[0] = number of tiles whose stream ended before their pixels
- * did (their output is undefined), status_dev[1] = index + 1 of one of them; read it after synchronising. */
+ * did (their output is undefined), status_dev[1] = index + 1 of one of them; read it after synchronising.  heap_bytes (at
+ * least 8) bounds what is read: the decoder fetches eight bytes at a time and may read past a tile's last byte into its
+ * neighbour's, never past heap_dev + heap_bytes; every tile must lie inside the heap (the caller checks its table). */
 int kb_fits_decode_rice(const uint8_t* heap_dev, uint64_t heap_bytes, const kb_fits_tile* tiles_dev, int32_t n_tiles,
                         int32_t tile_len, int32_t blocksize, int32_t bytepix, int32_t quantized, int32_t has_blank,
                         int32_t blank, float* out_dev, int32_t* status_dev, void* stream);

@@ -365,7 +365,10 @@ def _pinned_file(paths):
     for s in sizes:
         starts.append(total)
         total += -(-s // 16) * 16
-    host = torch.empty(total + 16, dtype=torch.uint8, pin_memory=True)
+    try:
+        host = torch.empty(total + 16, dtype=torch.uint8, pin_memory=True)
+    except RuntimeError:  # no page-locked memory of that size: the upload then goes through the runtime's staging buffers
+        host = torch.empty(total + 16, dtype=torch.uint8)
     view = host.numpy()
     for p, s, o in zip(paths, sizes, starts):
         with open(p, "rb") as fh:

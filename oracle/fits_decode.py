@@ -24,8 +24,8 @@ This file restates the published algorithms those call into:
 Pinned on the reference's own data files (copied as fixtures to tests/golden/, see tests/test_oracle_fits.py):
 ``tests/data/shifted_wcs_diff_dimms_tiled.fits`` -- every one of its 4 x 2 x 50 RICE tiles ends exactly on its last byte,
 the variance layers decode to the 4.0 the reference's fake-data generator wrote (noise level 2), the science layers to
-N(0, 2^2) noise on the 0.01 grid that ``quantize_level=-0.01`` prescribes -- and ``data/small/*.fits`` (plain BITPIX -32
-HDUs).  astropy is not installed in this image, so no vector could be produced BY the reference for this path: **parity of
+N(0, 2^2) noise on the 0.01 grid that ``quantize_level=-0.01`` prescribes, the brightest source of each to flux x the file's
+own PSF_i kernel within that noise -- and ``data/small/*.fits`` (plain BITPIX -32 HDUs).  astropy is not installed in this image, so no vector could be produced BY the reference for this path: **parity of
 the RICE leg is pinned on those properties and on the published algorithm, not on reference-produced pixel values**.
 """
 

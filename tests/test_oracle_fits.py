@@ -29,6 +29,13 @@ def test_reference_workunit_file_decodes_to_what_its_writer_put_in():
         # N(0, 2^2) noise plus a few bright sources, on the 0.01 grid of quantize_level=-0.01 (work_unit.py:1111)
         assert 1.8 < np.std(sci[sci < 10]) < 2.3 and abs(np.median(sci)) < 0.2
         assert abs(psf.sum() - 1.0) < 1e-2 and psf[1, 1] == psf.max()  # a Gaussian kernel
+        # the brightest source is an inserted object: flux x the file's own PSF_i kernel (a plain HDU) + that noise -- the
+        # RICE-decoded science pixels and the trivially decoded kernel agree on it
+        y, x = np.unravel_index(np.argmax(sci), sci.shape)
+        if 1 <= y < 49 and 1 <= x < 59:
+            patch = sci[y - 1:y + 2, x - 1:x + 2].astype(np.float64)
+            flux = float((patch * psf).sum() / (psf.astype(np.float64) ** 2).sum())
+            assert flux > 100 and np.abs(patch - flux * psf).max() < 8.0, (flux, patch - flux * psf)
     sci_hdu = fd.find(hdus, "SCI_0")
     cols = fd._columns(sci_hdu[0])
     for r in range(50):
