@@ -41,8 +41,9 @@ struct RiceArgs {
 // last byte into its neighbour's (never past the heap: those bytes read as zero); a well-formed stream does not consume
 // them, and a stream that does is flagged by its bit count.
 struct BitReader {
-    const uint8_t* p;         // next eight bytes to request
-    const uint8_t* heap_end;
+    const uint8_t* base;      // where offsets count from: the tile's first byte, or the heap's last eight when the tile starts in them
+    uint32_t pos;             // offset of the next eight bytes to request
+    uint32_t lim;             // largest offset at which eight bytes may be read (the heap ends eight bytes behind it)
     uint64_t buf;             // the window, valid bits at the top
     uint64_t ready;           // up to two big-endian words, the next one in the high half
     uint64_t pending;         // the eight bytes behind them, as loaded
@@ -51,19 +52,22 @@ struct BitReader {
     int n_ready;
     uint32_t taken;           // bytes moved into the window so far
     __device__ __forceinline__ void request8() {
-        // Branch-free, and the loaded value is not touched here (any arithmetic on it -- or a branch that makes the
-        // compiler merge it into another register -- is a wait for the load this queue exists to hide): within eight
-        // bytes of the heap's end the load is moved back to end there, and the shift that makes bytes past the end read
-        // as zero is applied when the word is promoted.  The heap holds at least eight bytes (checked by the launcher);
-        // global loads need no alignment on gfx950.
-        const int64_t over64 = (p + 8) - heap_end;
-        pending_over = over64 > 0 ? (uint32_t)(over64 < 8 ? over64 : 8) : 0u;
-        pending = *reinterpret_cast<const uint64_t*>(over64 > 8 ? heap_end - 8 : p - pending_over);
-        p += 8;
+        // Branch-free, 32-bit arithmetic, and the loaded value is not touched here (any arithmetic on it -- or a branch
+        // that makes the compiler merge it into another register -- is a wait for the load this queue exists to hide):
+        // within eight bytes of the heap's end the load is moved back to end there, and the shift that makes bytes past
+        // the end read as zero is applied when the word is promoted.  Global loads need no alignment on gfx950.
+        const uint32_t at = min(pos, lim);
+        pending_over = min(pos - at, 8u);
+        pending = *reinterpret_cast<const uint64_t*>(base + at);
+        pos += 8u;
     }
     __device__ __forceinline__ void start(const uint8_t* first, const uint8_t* end_of_heap) {
-        p = first;
-        heap_end = end_of_heap;
+        // (the heap holds at least eight bytes: checked by the launcher)
+        const uint8_t* last8 = end_of_heap - 8;
+        base = first < last8 ? first : last8;
+        pos = (uint32_t)(first - base);
+        const uint64_t room = (uint64_t)(last8 - base);
+        lim = room < 0xffffff00ull ? (uint32_t)room : 0xffffff00u;
         buf = 0;
         ready = 0;
         avail = 0;
