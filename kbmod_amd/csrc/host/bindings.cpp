@@ -431,6 +431,15 @@ PYBIND11_MODULE(search, m) {
     // ---- stamp coadds on the device (filters/stamp_filters.py:72-168, core/stamp_utils.py) ----
     py::class_<DeviceImageStack>(m, "DeviceImageStack")
             .def(py::init<DeviceImageStack::FloatArray, py::object>(), py::arg("sci"), py::arg("var") = py::none())
+            .def_static(
+                    "from_device",
+                    [](uintptr_t sci_dev, uintptr_t var_dev, int T, int H, int W, py::object owner) {
+                        return std::unique_ptr<DeviceImageStack>(new DeviceImageStack(sci_dev, var_dev, T, H, W, std::move(owner)));
+                    },
+                    py::arg("sci_dev"), py::arg("var_dev"), py::arg("num_times"), py::arg("height"), py::arg("width"),
+                    py::arg("owner") = py::none(),
+                    "Stacks [T][H][W] float32 that already are in the memory of the current device (addresses as integers; "
+                    "var_dev 0 = none): used where they lie.  `owner` is kept alive with the stack.")
             .def_property_readonly("num_times", &DeviceImageStack::num_times)
             .def_property_readonly("height", &DeviceImageStack::height)
             .def_property_readonly("width", &DeviceImageStack::width)

@@ -33,19 +33,28 @@ public:
     }
     HbmBlock(const HbmBlock&) = delete;
     HbmBlock& operator=(const HbmBlock&) = delete;
-    HbmBlock(HbmBlock&& o) noexcept : ptr_(o.ptr_) { o.ptr_ = nullptr; }
+    HbmBlock(HbmBlock&& o) noexcept : ptr_(o.ptr_), owned_(o.owned_) { o.ptr_ = nullptr; }
     HbmBlock& operator=(HbmBlock&& o) noexcept {
         if (this != &o) {
             reset();
             ptr_ = o.ptr_;
+            owned_ = o.owned_;
             o.ptr_ = nullptr;
         }
         return *this;
     }
     ~HbmBlock() { reset(); }
+    // A block somebody else owns (a torch tensor, ...): used, never freed here.
+    static HbmBlock borrowed(void* dev) {
+        HbmBlock b;
+        b.ptr_ = dev;
+        b.owned_ = false;
+        return b;
+    }
     void reset() {
-        if (ptr_ != nullptr) (void)kb_free_gpu_block(ptr_);
+        if (ptr_ != nullptr && owned_) (void)kb_free_gpu_block(ptr_);
         ptr_ = nullptr;
+        owned_ = true;
     }
     template <typename T>
     T* as() const {
@@ -58,6 +67,7 @@ public:
 
 private:
     void* ptr_ = nullptr;
+    bool owned_ = true;
 };
 
 class DeviceImageStack {
@@ -80,6 +90,18 @@ public:
             }
             var_ = HbmBlock(v.data(), (uint64_t)v.size() * sizeof(float));  // sci_ is released if this throws
         }
+    }
+
+    // Stacks that already are in the memory of the current device (what kbmod_amd.fits_ingest decodes a WorkUnit file
+    // into): used where they lie; `owner` (the tensors, ...) is held for as long as this object lives.
+    DeviceImageStack(uintptr_t sci_dev, uintptr_t var_dev, int T, int H, int W, py::object owner) : owner_(std::move(owner)) {
+        if (kb_device_count() == 0) throw std::runtime_error("GPU is not available for the image stack.");
+        if (sci_dev == 0 || T < 0 || H <= 0 || W <= 0) throw std::runtime_error("expected a T x H x W science stack on the device");
+        T_ = T;
+        H_ = H;
+        W_ = W;
+        sci_ = HbmBlock::borrowed(reinterpret_cast<void*>(sci_dev));
+        if (var_dev != 0) var_ = HbmBlock::borrowed(reinterpret_cast<void*>(var_dev));
     }
 
     int num_times() const { return T_; }
@@ -153,6 +175,7 @@ public:
     }
 
 private:
+    py::object owner_;  // declared first: released last (what borrowed stacks belong to)
     HbmBlock sci_, var_;
     int T_ = 0, H_ = 0, W_ = 0;
 };

@@ -342,6 +342,13 @@ class DeviceWorkUnit:
             torch.cuda.synchronize()
         return meta, arr.value
 
+    def device_stack(self):
+        """The layers as the ``kbmod_amd.stamp_utils.DeviceStack`` the stamp / coadd stages read (append_coadds,
+        append_all_stamps) -- the same memory, no copy."""
+        from kbmod_amd.stamp_utils import DeviceStack
+
+        return DeviceStack.from_device(self.sci, self.var, zeroed_times=self.zeroed_times, times=self.times)
+
     def stack_search(self, num_bytes=-1, separable_psf=False, empty_footprint_is_zero=False):
         """A ``StackSearch`` over these layers -- built from the device-resident stacks, nothing returns to the host."""
         import torch

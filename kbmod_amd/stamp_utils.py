@@ -54,6 +54,23 @@ class DeviceStack:
         self.zeroed_times = None if zeroed_times is None else np.asarray(zeroed_times, dtype=np.float64)
         self.times = None if times is None else np.asarray(times, dtype=np.float64)
 
+    @classmethod
+    def from_device(cls, sci, var=None, zeroed_times=None, times=None):
+        """The same over stacks that already are on the device: ``sci`` / ``var`` = contiguous float32 CUDA tensors
+        [T][H][W] (e.g. ``kbmod_amd.fits_ingest.DeviceWorkUnit.sci`` / ``.var``).  Nothing is copied; the tensors are kept
+        alive with the stack."""
+        for t in (sci, var):
+            if t is not None and not (t.is_cuda and t.is_contiguous() and t.dim() == 3 and str(t.dtype) == "torch.float32"):
+                raise ValueError("expected contiguous float32 CUDA tensors [T][H][W]")
+        if var is not None and tuple(var.shape) != tuple(sci.shape):
+            raise ValueError("science and variance stacks differ in shape")
+        self = cls.__new__(cls)
+        T, H, W = (int(n) for n in sci.shape)
+        self._dev = _search.DeviceImageStack.from_device(sci.data_ptr(), 0 if var is None else var.data_ptr(), T, H, W, (sci, var))
+        self.zeroed_times = None if zeroed_times is None else np.asarray(zeroed_times, dtype=np.float64)
+        self.times = None if times is None else np.asarray(times, dtype=np.float64)
+        return self
+
     num_times = property(lambda self: self._dev.num_times)
     height = property(lambda self: self._dev.height)
     width = property(lambda self: self._dev.width)

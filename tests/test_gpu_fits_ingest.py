@@ -272,3 +272,33 @@ def test_many_tiles_property(fi):
     exp[ints == -2147483647] = np.nan
     got = out.cpu().numpy().reshape(n_tiles, W)
     assert np.array_equal(got, exp[which], equal_nan=True)
+
+
+def test_stamps_from_the_ingested_layers_without_a_copy(fi, kb, tmp_path):
+    """file -> HBM -> coadds / stamps: the DeviceStack over the decoded tensors gives what a DeviceStack uploaded from the
+    oracle-decoded host layers gives (kb_coadd_stamps / kb_extract_stamps read the same pixels)."""
+    from kbmod_amd import stamp_utils as su
+
+    rng = np.random.default_rng(31)
+    layers = _layers(rng, 6, 40, 60, bright=False)
+    data, _ = fd.write_workunit(layers)
+    path = tmp_path / "stamps.fits"
+    path.write_bytes(data)
+    wu = fi.load_workunit(str(path))
+    on_dev = wu.device_stack()
+    dec = fd.read_workunit_layers(data)
+    times = np.asarray([d[0] for d in dec])
+    ref = su.DeviceStack(np.stack([d[1] for d in dec]), np.stack([d[2] for d in dec]), zeroed_times=times - times[0], times=times)
+    assert (on_dev.num_times, on_dev.height, on_dev.width) == (6, 40, 60)
+    n = 25
+    x0, y0 = rng.integers(0, 60, n), rng.integers(0, 40, n)
+    vx, vy = rng.uniform(-8, 8, n), rng.uniform(-6, 6, n)
+    xs = su.predict_pixel_locations(on_dev.zeroed_times, x0, vx)
+    ys = su.predict_pixel_locations(on_dev.zeroed_times, y0, vy)
+    a = on_dev.coadds(xs, ys, 3, ["sum", "mean", "median", "weighted"])
+    b = ref.coadds(xs, ys, 3, ["sum", "mean", "median", "weighted"])
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert np.array_equal(on_dev.all_stamps(xs, ys, 2), ref.all_stamps(xs, ys, 2), equal_nan=True)
+    del wu  # the stack keeps the tensors alive
+    assert np.array_equal(on_dev.all_stamps(xs, ys, 2), ref.all_stamps(xs, ys, 2), equal_nan=True)
