@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void kb_fits_rice_decode_kernel(RiceArgs a) {
     auto value_of = [&](uint32_t pix) -> float {
         int32_t iv = (int32_t)pix;
         if (BYTEPIX == 2) iv = (int32_t)(int16_t)pix;
-        if (BYTEPIX == 1) iv = (int32_t)(int8_t)pix;
+        if (BYTEPIX == 1) iv = (int32_t)(pix & 0xffu);  // (8-bit FITS pixels are unsigned: cfitsio fits_rdecomp_byte)
         const float v = (float)((double)iv * zscale + zzero);
         return (has_blank && iv == blank) ? __builtin_nanf("") : v;
     };

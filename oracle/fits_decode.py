@@ -125,7 +125,8 @@ _M = 0xFFFFFFFF
 
 
 def rice_decode(data, nx, blocksize=32, bytepix=4):
-    """``nx`` integers of one tile; returns (int64 array of the BYTEPIX-wide two's-complement values, bytes consumed)."""
+    """``nx`` integers of one tile; returns (int64 array of the BYTEPIX-wide values -- two's complement for 2 and 4 bytes,
+    unsigned for 1 --, bytes consumed)."""
     fsbits, fsmax, bbits = _RICE[bytepix]
     wrap = (1 << bbits) - 1
     lastpix = int.from_bytes(data[0:bytepix], "big")
@@ -188,6 +189,8 @@ def rice_decode(data, nx, blocksize=32, bytepix=4):
                 lastpix = (lastpix + diff) & wrap
                 out[i] = lastpix
                 i += 1
+    if bytepix == 1:  # 8-bit FITS pixels are unsigned (cfitsio fits_rdecomp_byte fills an unsigned char array)
+        return out, p
     sign = 1 << (bbits - 1)
     return np.where(out >= sign, out - (1 << bbits), out), p
 

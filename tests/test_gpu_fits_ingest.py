@@ -143,7 +143,7 @@ def test_integer_tiles_through_the_c_abi(fi, bytepix):
     lib = fi._lib()
     rng = np.random.default_rng(bytepix)
     H, W = 70, 75
-    lo, hi = (-128, 127) if bytepix == 1 else (-32768, 32767)
+    lo, hi = (0, 255) if bytepix == 1 else (-32768, 32767)  # 8-bit FITS pixels are unsigned
     img = rng.integers(lo, hi, size=(H, W), endpoint=True)
     img[3] = 5
     heap, tiles = bytearray(), np.zeros(H, dtype=fi.TILE_DTYPE)

@@ -54,7 +54,7 @@ def test_reference_plain_image_file():
     assert 1.9 < sci.std() < 2.3
 
 
-@pytest.mark.parametrize("bytepix,lo,hi", [(4, -2**31, 2**31 - 1), (4, -5000, 5000), (2, -2**15, 2**15 - 1), (1, -128, 127)])
+@pytest.mark.parametrize("bytepix,lo,hi", [(4, -2**31, 2**31 - 1), (4, -5000, 5000), (2, -2**15, 2**15 - 1), (1, 0, 255)])
 @pytest.mark.parametrize("force", [None, "raw", 0, 1, 7])
 def test_rice_round_trip(bytepix, lo, hi, force):
     rng = np.random.default_rng(bytepix * 100 + (hash(str(force)) & 15))
