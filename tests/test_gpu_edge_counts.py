@@ -155,3 +155,35 @@ def test_sigma_g_emitting_instance_uses_the_tables(orc):
             assert st0.edge_count_tables == 0 and counted.cpu().numpy().tobytes() == got.cpu().numpy().tobytes()
         finally:
             ds.close()
+
+
+def test_fast_movers_beyond_the_table_cap_keep_counting(orc):
+    # shifts of more than 200 pixels: no tables (their size grows with the largest shift), same results
+    stack = util.make_stack(5, 420, 520, seed=11, noise=2.0, psf=1.0, objects=[(40, 30, 300.0, 120.0, 400.0)])
+    ds = util.DeviceStack(stack)
+    try:
+        vx = np.repeat(np.array([296.0, 304.0], dtype=np.float32), 16) + np.tile(np.arange(16, dtype=np.float32) * 0.25, 2)
+        vy = np.tile(np.array([118.0, 120.0, 122.0, 124.0], dtype=np.float32), 8)
+        cfg = dict(K=8, min_obs=2)
+        got, st = ds.search(ds.params(**cfg), ds.candidates(vx, vy), 0)
+        assert st.kernel_name.decode().startswith("kb::kb_search_lds<8, 16,"), st.kernel_name
+        assert st.edge_count_tables == 0
+        _same(got, _oracle(orc, stack, vx, vy, cfg), "fast movers")
+    finally:
+        ds.close()
+
+
+def test_sigma_g_batches_share_the_tables(orc):
+    # a work-item store too small for the candidate list: the emit runs in batches of chunks, every batch reads its rows
+    stack = _stack(12, 96, 200, seed=12)
+    ds = util.DeviceStack(stack)
+    os.environ["KBMOD_SIGMAG_CAP"] = "4096"
+    try:
+        vx, vy = fd.velocity_grid_candidates(16, -12.0, 12.0, 12, -10.0, 10.0)
+        cfg = dict(K=4, min_obs=8, sigmag=(0.25, 0.75, 0.7413, 2.0))
+        got, st = ds.search(ds.params(**cfg), ds.candidates(vx, vy), 0)
+        assert st.edge_count_tables == 1 and st.num_search_launches > 1, st.num_search_launches
+        _same(got, _oracle(orc, stack, vx, vy, cfg), "sigma-G batches")
+    finally:
+        del os.environ["KBMOD_SIGMAG_CAP"]
+        ds.close()
