@@ -371,7 +371,7 @@ def release_pinned_buffer():
     _pinned_pool.clear()
 
 
-def _pinned_file(paths):
+def _pinned_file(paths, device=None):
     """The files' bytes back to back (each padded to 16 bytes) in ONE page-locked buffer; returns (tensor, [start offsets])."""
     import torch
 
@@ -397,6 +397,15 @@ def _pinned_file(paths):
     piece = 32 << 20
     jobs = [(p, o, off, min(piece, s - off)) for p, s, o in zip(paths, sizes, starts) for off in range(0, s, piece)]
 
+    # with a device: every piece goes out on a copy stream as soon as it has been read (the DMA of one piece under the
+    # reads of the next); the caller's stream is made to wait for that stream before anything reads the bytes
+    dev = copy_stream = None
+    if device is not None and total >= (64 << 20):  # (a small file goes out in one DMA behind its read: no stream to set up)
+        dev = torch.empty(total + 16, dtype=torch.uint8, device=device)
+        dev[total:].zero_()
+        copy_stream = torch.cuda.Stream(device=device)
+        copy_stream.wait_stream(torch.cuda.current_stream(device))
+
     def read_piece(job):
         p, o, off, n = job
         fd = os.open(p, os.O_RDONLY)
@@ -409,6 +418,9 @@ def _pinned_file(paths):
                 done += got
         finally:
             os.close(fd)
+        if dev is not None:
+            with torch.cuda.device(device), torch.cuda.stream(copy_stream):
+                dev[o + off:o + off + n].copy_(host[o + off:o + off + n], non_blocking=True)
 
     if len(jobs) > 1:
         from concurrent.futures import ThreadPoolExecutor
@@ -418,6 +430,11 @@ def _pinned_file(paths):
     else:
         for job in jobs:
             read_piece(job)
+    if dev is not None:
+        torch.cuda.current_stream(device).wait_stream(copy_stream)
+        _pinned_pool["in_flight"] = copy_stream  # (kept until the loader has synchronised)
+    if device is not None:
+        return host, starts, sizes, dev
     return host, starts, sizes
 
 
@@ -461,13 +478,20 @@ def _decode_layers(lib, torch, dev_bytes, host_view, file_base, layer_hdus, out,
     return n_streams, len(patches)
 
 
+def _resolve_device(device):
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("load_workunit needs a GPU: the FITS layers are decoded on the device, there is no CPU path")
+    _lib()  # (raises when the device library is not built)
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+
 def _load(paths, plans, file_of_image, device):
     import time
 
     import torch
 
-    if not torch.cuda.is_available():
-        raise RuntimeError("load_workunit needs a GPU: the FITS layers are decoded on the device, there is no CPU path")
     lib = _lib()
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     t_start = time.perf_counter()
@@ -475,7 +499,9 @@ def _load(paths, plans, file_of_image, device):
         host, starts, sizes = plans["host"], plans["starts"], plans["sizes"]
         host_view = host.numpy()
         stream = torch.cuda.current_stream().cuda_stream
-        dev_bytes = host.to(device, non_blocking=True)
+        dev_bytes = plans.get("dev_bytes")
+        if dev_bytes is None:
+            dev_bytes = host.to(device, non_blocking=True)
         images = plans["images"]
         T = len(images)
         H, W = plans["shape"]
@@ -505,9 +531,10 @@ def load_workunit(filename, device=None):
     ``DeviceWorkUnit`` whose stacks were decoded on the device."""
     if not os.path.isfile(filename):
         raise ValueError(f"WorkUnit file {filename} not found.")  # work_unit.py:511-512
-    host, starts, sizes = _pinned_file([filename])
+    device = _resolve_device(device)
+    host, starts, sizes, dev_bytes = _pinned_file([filename], device)
     plan = workunit_plan(host.numpy()[:sizes[0]])
-    plan.update(host=host, starts=starts, sizes=sizes)
+    plan.update(host=host, starts=starts, sizes=sizes, dev_bytes=dev_bytes)
     return _load([filename], plan, [0] * len(plan["images"]), device)
 
 
@@ -526,7 +553,8 @@ def load_sharded_workunit(filename, directory, device=None):
     for i, p in enumerate(shards):
         if not os.path.isfile(p):
             raise ValueError(f"No shard provided for index {i} for {filename}")  # work_unit.py:862-863
-    host, starts, sizes = _pinned_file(shards)
+    device = _resolve_device(device)
+    host, starts, sizes, dev_bytes = _pinned_file(shards, device)
     view = host.numpy()
     merged = {"times": [], "psfs": [], "images": [], "shape": None}
     for i in range(n):
@@ -539,5 +567,5 @@ def load_sharded_workunit(filename, directory, device=None):
         merged["psfs"] += part["psfs"]
         merged["images"] += part["images"]
     merged["times"] = np.asarray(merged["times"], dtype=np.float64)
-    merged.update(host=host, starts=starts, sizes=sizes)
+    merged.update(host=host, starts=starts, sizes=sizes, dev_bytes=dev_bytes)
     return _load(shards, merged, list(range(n)), device)
