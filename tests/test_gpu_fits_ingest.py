@@ -302,3 +302,42 @@ def test_stamps_from_the_ingested_layers_without_a_copy(fi, kb, tmp_path):
     assert np.array_equal(on_dev.all_stamps(xs, ys, 2), ref.all_stamps(xs, ys, 2), equal_nan=True)
     del wu  # the stack keeps the tensors alive
     assert np.array_equal(on_dev.all_stamps(xs, ys, 2), ref.all_stamps(xs, ys, 2), equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_written_workunits(fi, tmp_path, seed):
+    """Random shapes, noise scales from 0.05 to 10^4 quanta per pixel step (every split code up to verbatim blocks), NaN and
+    mask fractions, quantisation steps, GZIP fallback rows, compressed or plain layers -- product == oracle, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    T, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 71)), int(rng.integers(1, 201))
+    quantum = float(rng.choice([0.01, 0.5, 1.0e-3]))
+    sigma = float(rng.choice([0.0005, 0.05, 2.0, 300.0, 1.0e4]))
+    compressed = bool(rng.random() < 0.8)
+    layers = []
+    for t in range(T):
+        sci = rng.normal(0, sigma, (H, W)).astype(np.float32)
+        sci[rng.random((H, W)) < rng.choice([0.0, 0.02, 0.3])] = np.nan
+        var = np.abs(rng.normal(4, sigma, (H, W))).astype(np.float32)
+        mask = (rng.random((H, W)) < rng.choice([0.0, 0.05])).astype(np.int8) if rng.random() < 0.7 else None
+        psf = np.full((3, 3), 1 / 9, np.float32) if rng.random() < 0.7 else None
+        layers.append((50000.0 + 3 * t + rng.random(), sci, var, mask, psf))
+    if compressed and H > 2 and rng.random() < 0.5:
+        # a file with GZIP fallback rows in its science layers
+        out = bytearray(fd._header_bytes([fd._card("SIMPLE", True), fd._card("BITPIX", 8), fd._card("NAXIS", 0), fd._card("NUMIMG", T)]))
+        for i, (mjd, sci, var, mask, psf) in enumerate(layers):
+            rows = tuple(int(r) for r in rng.choice(H, size=min(3, H), replace=False))
+            s, _ = fd.write_compressed_hdu(f"SCI_{i}", sci, quantum, [("MJD", float(mjd))], -2147483647, None, rows)
+            v, _ = fd.write_compressed_hdu(f"VAR_{i}", var, quantum, (), -2147483647)
+            out += s + v
+            if mask is not None:
+                out += fd.write_image_hdu(f"MSK_{i}", mask)
+            if psf is not None:
+                out += fd.write_image_hdu(f"PSF_{i}", psf)
+        data = bytes(out)
+    else:
+        data, _ = fd.write_workunit(layers, compressed=compressed, quantum=quantum)
+    path = tmp_path / "fuzz.fits"
+    path.write_bytes(data)
+    wu = fi.load_workunit(str(path))
+    check_against_oracle(wu, data)
+    assert tuple(wu.sci.shape) == (T, H, W)
