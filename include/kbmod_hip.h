@@ -272,8 +272,8 @@ int kb_merge_topk(const kb_trajectory* lists_dev, int32_t n_lists, uint64_t n_pi
                   kb_trajectory* out_dev, void* stream);
 /* Same merge on the compact records of kb_device_search_compact, gathered to one GPU as
  * lists_dev = [n_lists][n_pixels][K]; writes full trajectories (x, y from the slot and the start bounds of
- * params, vx / vy from all_cands_dev, the job-wide candidate list the records index).  The output equals
- * where a pixel's K + 1 best likelihoods are distinct the output equals what one GPU produces on the whole
+ * params, vx / vy from all_cands_dev, the job-wide candidate list the records index).  Where a pixel's
+ * K + 1 best likelihoods are distinct the output equals what one GPU produces on the whole
  * candidate list; among EQUAL likelihoods it keeps the lower list = lower candidate index, whereas the
  * reference's swap-down insertion (kernels.cu:323-330) may keep another member of the tie
  * (kb_merge_compact_exact reproduces that too). */
