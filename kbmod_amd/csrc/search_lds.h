@@ -350,7 +350,11 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 const uint32_t fg = sgpr32(max(1u, (C == 8 ? 32u : 16u) / (uint32_t)plan.E));
                 uint32_t fc = fg;
                 const uint64_t ob = sgpr64((uint64_t)(uintptr_t)(a.lds_fold + ((size_t)chunk * T + t0) * C));
+#ifdef KB_LDS_DMA
+                const uint64_t gb = sgpr64((uint64_t)(uintptr_t)first);  // (the LDS-DMA statements count from one entry earlier)
+#else
                 const uint64_t gb = sgpr64((uint64_t)(uintptr_t)(first + 1));
+#endif
                 const uint64_t tb = sgpr64((uint64_t)(uintptr_t)tile_base);
                 // (slabs are as tall as their epoch's shift box: a piece behind a slab's end copies the first slab's instead)
                 const Int4 ref0 = first[0];

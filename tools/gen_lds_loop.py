@@ -43,6 +43,12 @@ NO_GLOAD = os.environ.get("KB_GEN_NO_GLOAD") is not None
 NO_LWRITE = os.environ.get("KB_GEN_NO_LWRITE") is not None
 NO_BARRIER = os.environ.get("KB_GEN_NO_BARRIER") is not None
 NO_REFILL = os.environ.get("KB_GEN_NO_REFILL") is not None
+# STREAM statements that stage by LDS-DMA (global_load_lds_dwordx4, M0 = destination): no staging registers, no ds_write_b128,
+# no vmcnt wait inside an epoch.  A slab's bytes land whenever they arrive, so the request that used to be in flight across
+# a group change (slot 0 of the group after next: its buffer is still being read) is issued BEHIND the barrier: the request of
+# an odd epoch moves to the end of its trip.  The header then defines KB_LDS_DMA (search_lds.h passes the slab references
+# from one entry earlier: the reference of an odd epoch is now fetched in the even half of its own trip).
+DMA = os.environ.get("KB_GEN_NO_DMA") is None  # (KB_GEN_NO_DMA: the register-staged STREAM statements, for comparisons)
 
 
 class Plan:
@@ -50,11 +56,13 @@ class Plan:
         self.C = C
         if C == 8:
             self.A, self.B, self.gA, self.gB, self.addr, self.o1, self.o2 = 68, 76, 84, 92, 88, 90, 91
-            self.sregs = range(68, 96)
+            self.sregs = range(68, 98 if DMA else 96)
+            self.ws, self.m0s = 96, 97           # DMA: LDS address of the wave's piece in the slot requested next; M0 of the caller
             self.bits = [92 + c for c in range(8)]
         else:
             self.A, self.B, self.gA, self.gB, self.addr, self.o1, self.o2 = 36, 52, 68, 72, 76, 78, 79
-            self.sregs = range(36, 80)   # (s32 - s35 are the stack registers of a kernel that has scratch memory)
+            self.sregs = range(36, 82 if DMA else 80)   # (s32 - s35 are the stack registers of a kernel that has scratch memory)
+            self.ws, self.m0s = 80, 81
             self.bits = [84 + c for c in range(8)] * 2   # candidate k and k + 8 share a register (alternate bits)
         self.row = 4 * C                    # bytes of a table row (one epoch's offsets)
         self.loadx = f"s_load_dwordx{C}"
@@ -212,9 +220,84 @@ def stream(p, fast, np_):
     return s
 
 
+def dma_request(p, which, np_):
+    """The slab an even / odd epoch requests, straight into the wave's piece(s) of the slot requested next."""
+    g = p.gA if which == "A" else p.gB
+    s = ""
+    for piece in range(np_):
+        wp, go = (("%[wp]", "%[go]"), ("%[wq]", "%[gq]"))[piece]
+        if TRIM or piece == 1:
+            s += ln(f"s_cmp_lt_u32 {wp}, s{g + 2}\\n\\ts_cselect_b32 s{p.addr}, s{g}, %[dl]\\n\\ts_cselect_b32 s{p.addr + 1}, s{g + 1}, %[dh]")
+            s += ln(f"s_add_u32 s{p.addr}, %[tl], s{p.addr}\\n\\ts_addc_u32 s{p.addr + 1}, %[th], s{p.addr + 1}")
+        else:
+            s += ln(f"s_add_u32 s{p.addr}, %[tl], s{g}\\n\\ts_addc_u32 s{p.addr + 1}, %[th], s{g + 1}")
+        s += ln(f"s_mov_b32 m0, s{p.ws}" if piece == 0 else f"s_add_u32 m0, s{p.ws}, %[so]")
+        s += ln(f"s_nop 0\\n\\tglobal_load_lds_dwordx4 {go}, s[{p.addr}:{p.addr + 1}]")
+    if np_:
+        s += ln(f"s_add_u32 s{p.ws}, s{p.ws}, %[st]")
+    return s
+
+
+def dma_half(p, which, fast, np_, request, refill):
+    base = p.A if which == "A" else p.B
+    imm1 = "" if which == "A" else f" offset:{hex(p.row)}"
+    s = dma_request(p, "A", np_) if (request and which == "A") else ""
+    for b in range(p.C // 8):
+        s += reads(p, base, b, 8)
+        s += ln("s_waitcnt lgkmcnt(0)")
+        if b == p.C // 8 - 1 and refill and not NO_REFILL:
+            s += ln(f"{p.loadx} s[{base}:{base + p.C - 1}], %[ob], s{p.o1}{imm1}")
+            if np_ and which == "A":
+                # the references of the slabs the NEXT even epoch and THIS trip's odd epoch request (the base is one entry early)
+                s += ln(f"s_load_dwordx4 s[{p.gA}:{p.gA + 3}], %[gb], s{p.o2} offset:0x10")
+                s += ln(f"s_load_dwordx4 s[{p.gB}:{p.gB + 3}], %[gb], s{p.o2}")
+        s += adds(p, fast, b, 8)
+    return s
+
+
+def stream_dma(p, fast, np_):
+    s = "" if fast else zero_bits(p)
+    s += ln(f"{p.loadx} s[{p.A}:{p.A + p.C - 1}], %[ob], 0x0")
+    s += ln(f"{p.loadx} s[{p.B}:{p.B + p.C - 1}], %[ob], {hex(p.row)}")
+    if np_:
+        s += ln(f"s_load_dwordx4 s[{p.gA}:{p.gA + 3}], %[gb], 0x10")
+        s += ln(f"s_load_dwordx4 s[{p.gB}:{p.gB + 3}], %[gb], 0x20")
+    s += ln(f"s_mov_b32 s{p.o1}, {hex(2 * p.row)}\\n\\ts_mov_b32 s{p.o2}, 0x20")
+    s += ln(f"v_readfirstlane_b32 s{p.ws}, %[wd]")
+    if np_:
+        s += ln(f"s_mov_b32 m0, s{p.ws}\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 %[go], %[b0]")
+    if np_ == 2:
+        s += ln(f"s_add_u32 m0, s{p.ws}, %[so]\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 %[gq], %[b0]")
+    s += ln(f"s_add_u32 s{p.ws}, s{p.ws}, %[st]")
+    s += ln("s_waitcnt lgkmcnt(0)")
+    s += f'"s_cmp_eq_u32 %[np], 1\\n\\ts_cbranch_scc1 kb_sfin_%=_{np_}\\n"\n'
+    s += f'"kb_sloop_%=_{np_}:\\n\\t"\n'
+    s += dma_half(p, "A", fast, np_, True, True)
+    s += dma_half(p, "B", fast, np_, False, True)
+    s += advance(p)
+    s += ln(f"s_sub_u32 %[gc], %[gc], 1\\n\\ts_cmp_lg_u32 %[gc], 0\\n\\ts_cbranch_scc1 kb_snb_%=_{np_}")
+    s += ln("s_waitcnt vmcnt(0) lgkmcnt(0)" + ("" if NO_BARRIER else "\\n\\ts_barrier"))
+    s += ln(f"v_add_u32 %[rb], %[dr], %[rb]\\n\\ts_sub_u32 s{p.ws}, s{p.ws}, %[es]\\n\\ts_sub_u32 s{p.ws}, s{p.ws}, %[dr]")
+    s += ln("s_sub_u32 %[dr], 0, %[dr]\\n\\ts_mov_b32 %[gc], %[pg]")
+    if not fast:
+        s += ln(f"s_sub_u32 %[fc], %[fc], 1\\n\\ts_cmp_lg_u32 %[fc], 0\\n\\ts_cbranch_scc1 kb_snb_%=_{np_}")
+        s += flush_bits(p, True)
+        s += ln("s_mov_b32 %[fc], %[fg]")
+    s += '"\\n"\n'
+    s += f'"kb_snb_%=_{np_}:\\n\\t"\n'
+    s += dma_request(p, "B", np_)  # (the odd epoch's request: behind the barrier when the group changed)
+    s += f'"s_sub_u32 %[np], %[np], 1\\n\\ts_cmp_lg_u32 %[np], 1\\n\\ts_cbranch_scc1 kb_sloop_%=_{np_}\\n"\n'
+    s += f'"kb_sfin_%=_{np_}:\\n\\t"\n'
+    s += dma_half(p, "A", fast, np_, True, False)
+    s += dma_half(p, "B", fast, np_, False, False)
+    return s
+
+
 def combined(p, body, fast):
     """One statement for every wave: %[nq] (0, 1 or 2: the pieces of each slab this wave copies) picks the body."""
-    s = ln("s_cmp_eq_u32 %[nq], 2\\n\\ts_cbranch_scc1 kb_two_%=\\n\\ts_cmp_eq_u32 %[nq], 1\\n\\ts_cbranch_scc1 kb_one_%=")
+    dma = body is stream_dma
+    s = ln(f"s_mov_b32 s{p.m0s}, m0") if dma else ""
+    s += ln("s_cmp_eq_u32 %[nq], 2\\n\\ts_cbranch_scc1 kb_two_%=\\n\\ts_cmp_eq_u32 %[nq], 1\\n\\ts_cbranch_scc1 kb_one_%=")
     s += body(p, fast, 0)
     s += '"s_branch kb_done_%=\\n"\n"kb_one_%=:\\n\\t"\n'
     s += body(p, fast, 1)
@@ -223,6 +306,8 @@ def combined(p, body, fast):
     s += '"\\n"\n"kb_done_%=:\\n\\t"\n'
     if not fast:
         s += flush_bits(p, False)
+    if dma:
+        s += ln(f"s_mov_b32 m0, s{p.m0s}")
     s += '"s_waitcnt vmcnt(0) lgkmcnt(0)"\n'
     return s
 
@@ -265,10 +350,10 @@ def main():
            '// KB_LDS_RUN_<LOOP|STREAM> expand, inside lds_search_tile, to the statement for its C and FAST; a statement holds the',
            '// bodies for waves that copy no, one or two pieces of every slab and picks by nq; it names the variables of its call',
            '// site (acc, cntp, wd, rb, pairs, gc, dr, fc, go, gq, nq, ob, gb, b0, tl, th, wp, wq, dl, dh, st, pg, es, fg, odd).',
-           '#ifndef KB_SEARCH_LDS_ASM_H_', '#define KB_SEARCH_LDS_ASM_H_', '']
+           '#ifndef KB_SEARCH_LDS_ASM_H_', '#define KB_SEARCH_LDS_ASM_H_', ''] + (['#define KB_LDS_DMA 1', ''] if DMA else [])
     for C in (8, 16):
         p = Plan(C)
-        for family, body in (("LOOP", loop), ("STREAM", stream)):
+        for family, body in (("LOOP", loop), ("STREAM", stream_dma if DMA else stream)):
             for fast in (True, False):
                 kind = "FAST" if fast else "COUNT"
                 outs, ins = operands(p, family, fast)
