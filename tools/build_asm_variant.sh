@@ -1,5 +1,6 @@
 #!/bin/bash
-# tools/build_asm_variant.sh NAME "KB_GEN_NO_GLOAD=1 ..." ["-DKB_EXP_..."]: a device library whose hand-scheduled statements
+# tools/build_asm_variant.sh NAME "KB_GEN_NO_GLOAD=1 ..." ["-DKB_EXP_..."] (e.g. nodma "KB_GEN_NO_DMA=1": the register-staged STREAM
+# statements): a device library whose hand-scheduled statements
 # come from a variant of tools/gen_lds_loop.py (timing experiments); only search_lds.hip is recompiled.
 # -> tools/probe_bin/libkbmod_NAME.so (KBMOD_HIP_LIB=... python bench.py, tools/ab.sh)
 set -e
