@@ -33,6 +33,16 @@ writes that where the piece would have gone, behind every row the epoch's offset
 flight stay the same for every wave and epoch.
 
 Every read-write operand is early-clobber: the statements write them while inputs are still being read.
+
+Since the end of round 3 the STREAM statements stage by LDS-DMA (stream_dma below; KB_GEN_NO_DMA=1 regenerates the
+register-staged form described above, which the LOOP statements keep): a piece is requested with
+global_load_lds_dwordx4 <lane offset>, <slab address> with M0 = the LDS address of the wave's piece in the slot requested next
+(scalar s80 / s96, advanced by the slot stride per request; the caller's M0 is kept in s81 / s97), so v[100:107] and the
+second-piece registers are free: the count-free statements for chunks of 16 read all sixteen samples of an epoch into
+v[92:123] before one wait (WIDE_BATCH).  The request of an odd epoch sits at the END of its trip, behind the group change
+when there was one (slot 0 of the group after next lies in the buffer everybody reads until that barrier), and its slab
+reference is fetched in the even half of the same trip; %[gb] therefore counts from one entry earlier (KB_LDS_DMA in the
+generated header tells search_lds.h).  `s_waitcnt vmcnt(0)` stands in front of every group's barrier.
 """
 import os
 
