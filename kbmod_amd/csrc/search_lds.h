@@ -268,6 +268,8 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     constexpr int BYTES = 2 * fmt_bytes(SF);
     // the float-staged, depth-1 instances run their epochs through search_lds_asm.h
     constexpr bool HAND_SCHEDULED = CANON && (C == 8 || C == 16);
+    // (the counting statements that read sixteen samples per wait take eight more registers: not for the pooled lists)
+    [[maybe_unused]] constexpr bool KB_LDS_WIDE_COUNT = LM != LIST_STORE_POOLED;
     const int T = a.T;
 
     PairF acc[C];  // (psi_sum, phi_sum) as pairs: one v_pk_add_f32 per sample

@@ -251,13 +251,19 @@ def dma_request(p, which, np_):
 # all 16 samples of an epoch read before ONE wait in the count-free statements for chunks of 16 (the registers the staging no
 # longer needs hold them): 64 x 2048 x 2048 37.8 -> 36.6 ms, cfg2 2.41 -> 2.39 ms; KB_GEN_NO_WIDE_BATCH: two batches of eight
 WIDE_BATCH = os.environ.get("KB_GEN_NO_WIDE_BATCH") is None
+# ... and in the counting statements too (v[92:99] join their clobbers: two registers of the headline instance go to scratch
+# memory, outside the loops): a stack with 1 % masked pixels 2.71 -> 2.64 ms at cfg2, 41.3 -> 39.9 ms on 2048 x 2048; KB_GEN_NO_WIDE_COUNT
+WIDE_COUNT = os.environ.get("KB_GEN_NO_WIDE_COUNT") is None
+# (per generated statement: the counting STREAM statement for chunks of 16 exists in both forms, COUNT and COUNTW; the pooled-list
+# instance, which is short of registers, keeps COUNT -- search_lds.h: KB_LDS_WIDE_COUNT)
+CUR = {"wide_count": False}
 
 
 def dma_half(p, which, fast, np_, request, refill):
     base = p.A if which == "A" else p.B
     imm1 = "" if which == "A" else f" offset:{hex(p.row)}"
     s = dma_request(p, "A", np_) if (request and which == "A") else ""
-    nb = 16 if (WIDE_BATCH and fast and p.C == 16) else 8
+    nb = 16 if (WIDE_BATCH and (fast or CUR["wide_count"]) and p.C == 16) else 8
     saved = p.raw
     if nb == 16:
         p.raw = [92 + 2 * c for c in range(16)]  # (no staging registers: v[92:107] are free in the count-free statements)
@@ -359,6 +365,8 @@ def operands(p, family, fast):
 
 def clobbers(p, fast):
     v = [f'"v{i}"' for i in range(92, 100)] if fast else [f'"v{b}"' for b in p.bit_regs()]
+    if not fast and CUR["wide_count"] and DMA and p.C == 16:
+        v += [f'"v{i}"' for i in range(92, 100)]
     v += [f'"v{i}"' for i in range(100, 125)]
     return ", ".join(v + [f'"s{i}"' for i in p.sregs] + ['"vcc"', '"scc"', '"memory"'])
 
@@ -374,8 +382,11 @@ def main():
     for C in (8, 16):
         p = Plan(C)
         for family, body in (("LOOP", loop), ("STREAM", stream_dma if DMA else stream)):
-            for fast in (True, False):
-                kind = "FAST" if fast else "COUNT"
+            kinds = [(True, "FAST", False), (False, "COUNT", False)]
+            if family == "STREAM" and C == 16 and DMA and WIDE_BATCH and WIDE_COUNT:
+                kinds.append((False, "COUNTW", True))
+            for fast, kind, wide_count in kinds:
+                CUR["wide_count"] = wide_count
                 outs, ins = operands(p, family, fast)
                 lines = combined(p, body, fast).rstrip("\n").split("\n")
                 out.append(f'#define KB_LDS_{family}_{kind}_C{C} \\')
@@ -390,7 +401,10 @@ def main():
         out.append('    if constexpr (C == 8) { \\')
         out.append(f'        if constexpr (FAST) {{ KB_LDS_{family}_FAST_C8 }} else {{ KB_LDS_{family}_COUNT_C8 }} \\')
         out.append('    } else { \\')
-        out.append(f'        if constexpr (FAST) {{ KB_LDS_{family}_FAST_C16 }} else {{ KB_LDS_{family}_COUNT_C16 }} \\')
+        if family == "STREAM" and DMA and WIDE_BATCH and WIDE_COUNT:
+            out.append(f'        if constexpr (FAST) {{ KB_LDS_{family}_FAST_C16 }} else if constexpr (KB_LDS_WIDE_COUNT) {{ KB_LDS_{family}_COUNTW_C16 }} else {{ KB_LDS_{family}_COUNT_C16 }} \\')
+        else:
+            out.append(f'        if constexpr (FAST) {{ KB_LDS_{family}_FAST_C16 }} else {{ KB_LDS_{family}_COUNT_C16 }} \\')
         out.append('    }')
         out.append('')
     out.append('#endif')
