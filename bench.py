@@ -138,9 +138,22 @@ def main():
     ap.add_argument("--separable-psf", action="store_true",
                     help="build psi/phi with the separable PSF kernel (KB_BUILD_SEPARABLE: <= 1e-4 relative to the reference's "
                          "tap loop instead of bit-identical)")
+    ap.add_argument("--exchange", choices=["auto", "dense", "sparse"], default="auto",
+                    help="multi-GPU: what travels to rank 0.  dense = every slot of every per-rank list (one gather, hidden under "
+                         "the next search); sparse = one count byte per pixel + the records that pass min_lh (kb_sparsify_compact: "
+                         "the reference drops everything below min_lh right after its kernel, stack_search.cpp:266-270, so nothing "
+                         "that survives is lost); auto = sparse when the search has a likelihood threshold (min_lh > 0 or --sigmag)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the CPU baseline samples (both together)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc sub-runs (FETCH_SIZE, WRITE_SIZE) of this command that measure the dominant "
+                         "kernel's fabric bytes per launch; the roofline block then falls back to profiles/traffic.json")
+    ap.add_argument("--no-masked", action="store_true",
+                    help="skip the second timing on the same stack with 1 %% of the science pixels masked (reported as `masked`)")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # a profiled sub-run of this script: timing loop only
     args = ap.parse_args()
+    if args.child:
+        args.no_cpu_baseline = args.no_live_traffic = args.no_masked = True
 
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
@@ -153,6 +166,9 @@ def main():
     from kbmod_amd import fake_data as fd
 
     world = int(world_env or "1")
+    # KBMOD_FORCE_DIST=1: take the N > 1 branch -- process group, compact search, exchange, merge -- at whatever world size
+    # this is, world size 1 included (tests/test_gpu_multi.py drives the real RCCL backend that way on a single GPU).
+    dist_mode = world > 1 or os.environ.get("KBMOD_FORCE_DIST", "0") not in ("", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -167,8 +183,15 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if dist_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -229,136 +252,190 @@ def main():
                         H - ins, K, 0)
     # multi-GPU: tie-exact exchange -- every rank keeps 2 K records per pixel by stable insertion (flag 512), the merge
     # on rank 0 replays the reference's insertion (kbmod_amd/distributed.py); K > 16 or --plain-ties: K records, ties by index
-    exact_ties = world > 1 and not args.plain_ties and K <= 16
+    exact_ties = dist_mode and not args.plain_ties and K <= 16
     list_len = 2 * K if exact_ties else K
-    if world > 1:
+    # ... and in what form: a search with a likelihood threshold leaves nearly every slot empty or below it, and the
+    # reference drops those right after its kernel -- one count byte per pixel + the survivors travel instead (sparse)
+    thresholded = args.sigmag or float(params.min_lh) > 0.0
+    sparse = dist_mode and exact_ties and (args.exchange == "sparse" or (args.exchange == "auto" and thresholded))
+    if args.exchange == "sparse" and dist_mode and not exact_ties:
+        raise RuntimeError("--exchange sparse goes through the tie-exact merge (K <= 16, not --plain-ties)")
+    wire = {}
+    if dist_mode:
         rank_params = Params.from_buffer_copy(params)
         rank_params.results_per_pixel = list_len
         # two sets of exchange buffers: the records of step i are on the wire while step i + 1 fills the other set
-        records2 = [torch.empty((S * list_len, 4), dtype=torch.int32, device=dev) for _ in range(2)]  # kb_compact_result per slot
-        gathered2 = [torch.empty((world, S * list_len, 4), dtype=torch.int32, device=dev) if rank == 0 else None
-                     for _ in range(2)]
+        n_sets = 1 if sparse else 2
+        records2 = [torch.empty((S * list_len, 4), dtype=torch.int32, device=dev) for _ in range(n_sets)]  # kb_compact_result per slot
+        gathered2 = [torch.empty((world, S * list_len, 4), dtype=torch.int32, device=dev) if (rank == 0 and not sparse) else None
+                     for _ in range(n_sets)]
         results = torch.empty((S * K, 7), dtype=torch.float32, device=dev) if rank == 0 else None
+        if sparse:
+            sp_header = torch.empty(int(lib.kb_sparse_header_bytes(S)), dtype=torch.uint8, device=dev)
+            sp_packed = [None]   # sized by the first step (grown when a later one keeps more)
     else:
         results = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
 
-    kernel_ms = []
+    def run_timed(meta, arr, n_warmup, n_steps):
+        """n_warmup untimed + n_steps timed whole searches of the array at `arr`; (elapsed s, kernel ms per step, last stats)."""
+        kernel_ms = []
+        searched = [False]
+        in_flight = [None]   # the exchange of the previous step (N > 1, dense, overlapped)
+        which_set = [0]
 
-    searched = [False]
-    in_flight = [None]   # the exchange of the previous step (N > 1, overlapped)
-    which_set = [0]
+        def drain():
+            if in_flight[0] is not None:
+                in_flight[0].finish()
+                in_flight[0] = None
 
-    def drain():
-        if in_flight[0] is not None:
-            in_flight[0].finish()
-            in_flight[0] = None
+        def step(record):
+            st = Stats()
+            # Every step is a whole search: tables, decode-and-pad pass, search kernel.  --reuse-padded-copy adds flag 256
+            # from the second step on (the array has not changed since the previous search: what a StackSearch with a
+            # resident array passes), which lets the library keep the padded float copy of the last search.
+            flags = args.flags | (256 if (searched[0] and args.reuse_padded_copy) else 0)
+            searched[0] = True
+            if dist_mode:
+                b = which_set[0]
+                which_set[0] = (b + 1) % n_sets
+                records, gathered = records2[b], gathered2[b]
+                check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), rank_params, cands.data_ptr(),
+                                                        n_local, rank * n_local, records.data_ptr(), S * list_len,
+                                                        flags | (512 if exact_ties else 0), stream, C.byref(st)))
+                if sparse:
+                    # nothing to hide: the wire carries a count byte per pixel and the few records above the threshold
+                    stats = {}
+                    try:
+                        kdist.gather_and_merge_sparse(records, (ins, W - ins), (ins, H - ins), K, list_len, float(params.min_lh),
+                                                      all_cands, out=results, header=sp_header, packed=sp_packed[0], stats=stats)
+                    except RuntimeError as err:
+                        if "records kept, room for" not in str(err):
+                            raise
+                        # (the header is complete and holds the total: make room and go again)
+                        need = int(sp_header[(S + 15) // 16 * 16:].view(torch.int64)[0].item())
+                        sp_packed[0] = torch.empty((need + need // 4 + 1024, 4), dtype=torch.int32, device=dev)
+                        kdist.gather_and_merge_sparse(records, (ins, W - ins), (ins, H - ins), K, list_len, float(params.min_lh),
+                                                      all_cands, out=results, header=sp_header, packed=sp_packed[0], stats=stats)
+                    wire.update(stats)
+                else:
+                    nxt = kdist.start_gather_compact(records, (ins, W - ins), (ins, H - ins), K, all_cands, gathered=gathered,
+                                                     out=results, list_len=list_len)
+                    drain()               # the previous step's gather has had this step's search to travel in; merge it now
+                    in_flight[0] = nxt
+                    if args.no_overlap:
+                        drain()
+                    wire["wire_bytes"] = int(records.numel()) * 4
+            else:
+                check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), n_local,
+                                                       results.data_ptr(), S * K, flags, stream, C.byref(st)))
+            if record:
+                kernel_ms.append(st.search_kernel_ms)
+            return st
 
-    def step(record):
-        st = Stats()
-        # Every step is a whole search: tables, decode-and-pad pass, search kernel.  --reuse-padded-copy adds flag 256
-        # from the second step on (the array has not changed since the previous search: what a StackSearch with a
-        # resident array passes), which lets the library keep the padded float copy of the last search.
-        flags = args.flags | (256 if (searched[0] and args.reuse_padded_copy) else 0)
-        searched[0] = True
-        if world > 1:
-            b = which_set[0]
-            which_set[0] ^= 1
-            records, gathered = records2[b], gathered2[b]
-            check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), rank_params, cands.data_ptr(),
-                                                    n_local, rank * n_local, records.data_ptr(), S * list_len,
-                                                    flags | (512 if exact_ties else 0), stream, C.byref(st)))
-            nxt = kdist.start_gather_compact(records, (ins, W - ins), (ins, H - ins), K, all_cands, gathered=gathered,
-                                             out=results, list_len=list_len)
-            drain()               # the previous step's gather has had this step's search to travel in; merge it now
-            in_flight[0] = nxt
-            if args.no_overlap:
-                drain()
-        else:
-            check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), n_local,
-                                                   results.data_ptr(), S * K, flags, stream, C.byref(st)))
-        if record:
-            kernel_ms.append(st.search_kernel_ms)
-        return st
+        for _ in range(n_warmup):
+            step(False)
+        drain()
 
-    for _ in range(args.warmup):
-        step(False)
-    drain()
+        def barrier():
+            if dist_mode:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(n_steps):
+            last = step(True)
+        drain()   # the last step's gather and merge belong to the timed region
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist_mode:
+            tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, kernel_ms, last
 
-    barrier()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step(True)
-    drain()   # the last step's gather and merge belong to the timed region
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    if sparse:
+        sp_packed[0] = torch.empty((max(1024, S * list_len // 64), 4), dtype=torch.int32, device=dev)
+    elapsed, kernel_ms, last = run_timed(meta, arr, args.warmup, args.steps)
 
     evals_per_step_rank = int(last.num_evals)
     total_evals = evals_per_step_rank * world * args.steps
     value = total_evals / elapsed
     k_ms = float(np.mean(kernel_ms))
-    # kb_search_stats.kernel_variant: 0xxxx = kb_search_direct, 1xxxx / 2xxxx = kb_search_lds (encoded / float copy)
-    kernel_name = "kb_search_direct" if int(last.kernel_variant) // 10000 == 0 else "kb_search_lds"
     alg_rate = float(last.algorithmic_bytes) / (k_ms * 1e-3) / 1e9
     dtype = {-1: "f32", 4: "f32", 1: "u8", 2: "u16"}[args.num_bytes]
-
-    # measured HBM peak: a streaming device copy (4 GiB each way) timed with HIP events in this run
-    copy_gbps = C.c_double(0.0)
-    check(lib, lib.kb_measure_copy_bandwidth(4 << 30, 10, stream, C.byref(copy_gbps)))
-    # ... what a read-only stream over a block of the array's size reaches (no write traffic; for cfg2's 134 MB this is
-    # the rate at which the Infinity Cache feeds the L2s): the ceiling of the search's fabric traffic, which is 99 % reads
-    read_gbps = C.c_double(0.0)
-    check(lib, lib.kb_measure_read_bandwidth(min(int(T) * H * W * 8, 4 << 30), 20, stream, C.byref(read_gbps)))
-    # ... and the aggregate LDS read rate (ds_read_b64 on every CU): the yardstick of the sums' LDS traffic
-    lds_gbps = C.c_double(0.0)
-    check(lib, lib.kb_measure_lds_bandwidth(4096, stream, C.byref(lds_gbps)))
-
-    # fabric-side traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (it cannot be read from
-    # inside this process); attached only when workload AND kernel instance are those of the profiled run.
     instance = last.kernel_name.decode()
-    traffic = traffic_source = traffic_rejected = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            table = json.load(fh)
-        key = f"{dtype}:{T}x{H}x{W}:{n_local}" + (":sigmag" if args.sigmag else "")
-        entry = table.get(key)
-        if entry is not None and entry.get("kernel_instance") == instance:
-            traffic, traffic_source = entry["bytes"], entry["source"]
-        elif entry is not None:
-            traffic_rejected = f"profiles/traffic.json[{key}] was measured on {entry.get('kernel_instance')}, this run launched {instance}"
-    except (OSError, ValueError):
-        pass
+    is_lds_kernel = int(last.kernel_variant) // 10000 != 0   # 0xxxx = kb_search_direct, 1xxxx / 2xxxx = kb_search_lds
 
-    # Three fractions that must not be confused:
-    #  frac_algorithmic  SURVEY 8(d): 2 * block_size bytes per evaluation / kernel time / 8 TB/s.  Above 1 whenever the
-    #                    array is cache-resident or staged once for several candidates (each staged pixel serves 8
-    #                    candidates and neighbouring tiles): those "bytes" are LDS reads, not HBM bytes.
-    #  frac              bytes the fabric moved (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of the same instance) / kernel
-    #                    time / 8 TB/s -- HBM traffic when the working set exceeds the Infinity Cache, cache hits
-    #                    included when it does not (said in `note`); without a matching profile: the algorithmic rate.
-    #  frac_lds          LDS bytes the sums read / kernel time / the LDS read rate measured in this run.
+    copy_gbps, read_gbps, lds_gbps = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+    if not args.child:
+        # measured HBM peak: a streaming device copy (4 GiB each way) timed with HIP events in this run
+        check(lib, lib.kb_measure_copy_bandwidth(4 << 30, 10, stream, C.byref(copy_gbps)))
+        # ... what a read-only stream over a block of the array's size reaches (no write traffic; for cfg2's 134 MB this is
+        # the rate at which the Infinity Cache feeds the L2s): the ceiling of the search's fabric traffic, which is 99 % reads
+        check(lib, lib.kb_measure_read_bandwidth(min(int(T) * H * W * 8, 4 << 30), 20, stream, C.byref(read_gbps)))
+        # ... and the aggregate LDS read rate (ds_read_b64 on every CU): the yardstick of the sums' LDS traffic
+        check(lib, lib.kb_measure_lds_bandwidth(4096, stream, C.byref(lds_gbps)))
+
+    # Fabric-side traffic of the dominant kernel (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch; the x 2 is the gfx950
+    # correction of MI355X_MICROARCH.md, HBM section).  Counters cannot be read from inside this process, so rank 0 of a
+    # single-GPU run profiles two short sub-runs of this very command (one --pmc pass per counter, as that guide
+    # prescribes) and takes the per-dispatch average of the instance that ran here.  Without rocprofv3, or with
+    # --no-live-traffic: the stored profile of the same workload AND instance (profiles/traffic.json), said in traffic_source.
+    traffic = traffic_source = traffic_rejected = None
+    if rank == 0 and world == 1 and not dist_mode and not args.no_live_traffic:
+        live = live_traffic(sys.argv[1:], instance)
+        if "bytes" in live:
+            traffic, traffic_source = live["bytes"], live["source"]
+        else:
+            traffic_rejected = live["error"]
+    if traffic is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+                table = json.load(fh)
+            key = f"{dtype}:{T}x{H}x{W}:{n_local}" + (":sigmag" if args.sigmag else "")
+            entry = table.get(key)
+            if entry is not None and entry.get("kernel_instance") == instance:
+                traffic, traffic_source = entry["bytes"], "stored profile, not this run: " + entry["source"]
+            elif entry is not None:
+                traffic_rejected = (traffic_rejected + "; " if traffic_rejected else "") + \
+                    f"profiles/traffic.json[{key}] was measured on {entry.get('kernel_instance')}, this run launched {instance}"
+        except (OSError, ValueError):
+            pass
+
+    # What bounds the dominant kernel, and every fraction with its yardstick and its clock (all times below are
+    # kernel_ms: the HIP-event duration of the search launch on its own stream, averaged over this run's timed steps):
+    #  cache-resident arrays (the float copy fits the 256 MiB Infinity Cache: BASELINE configs[1], [2]) -- DRAM sees the array
+    #    once; the fabric bytes are Infinity-Cache hits; what the kernel is bound by is the rate at which the sums read LDS
+    #    and instructions issue.  SURVEY 8(d)'s "8 B per evaluation" ARE those LDS reads (one ds_read_b64 per sample):
+    #    achieved = algorithmic bytes / kernel_ms against the LDS read peak of the guide; frac_algorithmic, the same bytes
+    #    against the 8 TB/s of HBM, is above 1 for that reason and is not a roofline fraction.
+    #  arrays beyond the Infinity Cache (configs[3], [4]) -- bound "hbm": achieved = fabric bytes / kernel_ms against 8 TB/s.
     padded_guess = int(meta.total_array_size) * (8 // int(meta.block_size * 2) if meta.num_bytes != 4 else 1)
     cache_resident = padded_guess <= INFINITY_CACHE_BYTES
     lds_rate = float(last.lds_read_bytes) / (k_ms * 1e-3) / 1e9
-    achieved = alg_rate if traffic is None else traffic / (k_ms * 1e-3) / 1e9
+    fabric_rate = None if traffic is None else traffic / (k_ms * 1e-3) / 1e9
+    # compulsory = what any implementation must move: the array once, the candidates and times in, the result slots out
+    compulsory = int(meta.total_array_size) + n_local * 28 + T * 8 + S * K * 28
     note = []
-    if traffic is None:
-        note.append("no PMC profile of this workload and kernel instance under profiles/: achieved = algorithmic bytes / kernel "
-                    "time (can exceed the peak: staged pixels are reused out of LDS)")
+    if cache_resident and is_lds_kernel:
+        bound, achieved, peak = "lds+issue", lds_rate, LDS_PEAK_GBPS
+        note.append(f"the array's float copy ({padded_guess >> 20} MiB) lives in the 256 MiB Infinity Cache: fabric bytes are cache "
+                    "hits, DRAM traffic is about compulsory_bytes; the kernel is bound by LDS reads and instruction issue.  SURVEY "
+                    "8(d)'s 8 B per evaluation are LDS bytes here (one ds_read_b64 per sample): achieved = those bytes / kernel_ms, "
+                    "peak = the guide's LDS read rate; frac_of_measured_lds uses the ds_read_b64 rate measured in this run")
     else:
-        note.append("achieved = fabric bytes of the profiled instance / this run's kernel time")
-    if cache_resident:
-        note.append(f"the array's float copy ({padded_guess >> 20} MiB) fits the 256 MiB Infinity Cache: fabric bytes are "
-                    "cache hits, not DRAM traffic; the kernel is bound by LDS reads and instruction issue (frac_lds)")
+        bound, peak = "hbm", HBM_PEAK_GBPS
+        if fabric_rate is None:
+            achieved = alg_rate
+            note.append("no fabric-byte measurement for this workload and kernel instance: achieved = algorithmic bytes / kernel_ms "
+                        "(can exceed the peak: staged pixels are reused out of LDS)")
+        else:
+            achieved = fabric_rate
+            note.append("achieved = fabric bytes per launch (traffic) / kernel_ms")
+    note.append("clock of every rate: kernel_ms = HIP events around the search launch, un-profiled timed region of this run; "
+                "traffic = bytes per launch from PMC passes (byte counts do not depend on the profiler's slowdown)")
 
     out = {
         "metric": "trajectory-epoch evals/sec",
@@ -377,22 +454,28 @@ def main():
             "workload": f"{T}x{H}x{W} psi/phi ({'float32' if args.num_bytes in (-1, 4) else 'uint%d' % (8 * args.num_bytes)}), "
                         f"full {W}x{H} start grid x {n_local} (v,theta) candidates per GPU, K={K}, "
                         f"sigma-G {'on, min_obs %d' % (T // 2) if args.sigmag else 'off'}"
+                        + (f", min_lh {float(params.min_lh):g}" if float(params.min_lh) > 0 else "")
                         + (f", {args.mask_fraction:g} of the science pixels masked" if args.mask_fraction > 0 else ""),
             "frames": T, "height": H, "width": W, "candidates_per_gpu": n_local, "results_per_pixel": K,
-            "sharding": ("candidates (v,theta) by rank; psi/phi replicated; one RCCL gather of 16-byte records to rank 0 "
-                         f"({list_len} per pixel) + per-pixel merge, " + ("tie-exact" if exact_ties else "ties by candidate index"))
-                        if world > 1 else "none",
+            "sharding": ("candidates (v,theta) by rank; psi/phi replicated; "
+                         + (f"sparse exchange (one count byte per pixel + the records with lh >= {float(params.min_lh):g} of {list_len} "
+                            "per pixel: one RCCL gather of the headers + one message per rank) + per-pixel merge, tie-exact" if sparse
+                            else f"one RCCL gather of 16-byte records to rank 0 ({list_len} per pixel) + per-pixel merge, "
+                            + ("tie-exact" if exact_ties else "ties by candidate index")))
+                        if dist_mode else "none",
             "psi_phi_build_ms": build_ms,
         },
         "roofline": {
-            "bound": "hbm",
+            "bound": bound,
             "achieved": achieved,
-            "peak": HBM_PEAK_GBPS,
+            "peak": peak,
             "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
+            "frac": achieved / peak,
             "traffic": traffic,
             "traffic_source": traffic_source,
             "traffic_rejected": traffic_rejected,
+            "compulsory_bytes": compulsory,
+            "traffic_over_compulsory": None if traffic is None else traffic / compulsory,
             "note": "; ".join(note),
             "kernel": instance,
             "kernel_ms": k_ms,
@@ -402,20 +485,27 @@ def main():
             "frac_algorithmic": alg_rate / HBM_PEAK_GBPS,
             "algorithmic_bytes_per_launch": int(last.algorithmic_bytes),
             "algorithmic_GBps": alg_rate,
-            "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBPS,
+            "fabric_GBps": fabric_rate,
+            "fabric_frac_of_hbm_peak": None if fabric_rate is None else fabric_rate / HBM_PEAK_GBPS,
+            "fabric_frac_of_achievable": None if fabric_rate is None else fabric_rate / HBM_ACHIEVABLE_GBPS,
+            "hbm_peak_GBps": HBM_PEAK_GBPS,
             "hbm_achievable_GBps": HBM_ACHIEVABLE_GBPS,
-            "hbm_measured_copy_GBps": float(copy_gbps.value),
-            "hbm_measured_read_GBps": float(read_gbps.value),
-            "frac_of_measured_copy": achieved / float(copy_gbps.value),
-            "frac_lds": None if not last.lds_read_bytes else lds_rate / float(lds_gbps.value),
+            "hbm_measured_copy_GBps": float(copy_gbps.value) or None,
+            "hbm_measured_read_GBps": float(read_gbps.value) or None,
             "lds_read_bytes_per_launch": int(last.lds_read_bytes),
             "lds_read_GBps": lds_rate,
-            "lds_measured_peak_GBps": float(lds_gbps.value),
             "lds_guide_peak_GBps": LDS_PEAK_GBPS,
+            "lds_measured_peak_GBps": float(lds_gbps.value) or None,
+            "frac_of_guide_lds": None if not last.lds_read_bytes else lds_rate / LDS_PEAK_GBPS,
+            "frac_of_measured_lds": None if not (last.lds_read_bytes and lds_gbps.value) else lds_rate / float(lds_gbps.value),
             "psi_phi_bytes": int(meta.total_array_size),
             "cache_resident": bool(cache_resident),
         },
     }
+    if dist_mode:
+        out["exchange"] = {"form": "sparse" if sparse else "dense", "list_len": list_len, "backend": backend,
+                           "wire_bytes_per_rank": wire.get("wire_bytes"), "dense_bytes_per_rank": S * list_len * 16,
+                           "records_per_rank": wire.get("totals"), "overlapped": bool(not sparse and not args.no_overlap)}
     if build_kernel_ms is not None:
         in_out = float(T) * H * W * 8 + float(meta.total_array_size)  # sci + var in, the array out
         out["psi_phi_build"] = {"kernel": "separable strip (<= 1e-4)" if args.separable_psf else "2-D strip (bit-identical)",
@@ -426,22 +516,50 @@ def main():
         out["config"]["sigmag_work_items"] = int(last.sigmag_work_items)
         out["config"]["sigmag_trajectories_clipped"] = int(last.sigmag_trajectories)
 
-    if args.verify and world == 1:
+    if args.verify and world == 1 and not dist_mode:
         out["verify"] = verify(lib, torch, meta, arr, times, params, cands, n_local, results, S, K, ins, W, H, last, stream)
-    if args.verify and world > 1 and rank == 0:
+    if args.verify and dist_mode and rank == 0:
         # the merged lists of the job against ONE search over the job-wide candidate list on this rank's device
         single = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
         st1 = Stats()
         check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, all_cands.data_ptr(),
                                                n_local * world, single.data_ptr(), S * K, args.flags, stream, C.byref(st1)))
         torch.cuda.synchronize()
+        if sparse:
+            # the sparse exchange carries what survives the reference's post-filter (stack_search.cpp:266-270): those
+            # slots must equal the single-device search field for field, every other slot is the empty-slot placeholder
+            gone = single[:, 2] < float(params.min_lh)
+            single[gone, 0:2] = 0.0
+            single[gone, 2] = torch.finfo(torch.float32).min
+            single[gone, 3] = 0.0
+            single.view(torch.int32)[gone, 6] = 0
+            out["verify_survivors"] = int((~gone).sum().item())
         same = torch.equal(results.view(torch.int32), single.view(torch.int32))
         lh_same = torch.equal(results[:, 2].contiguous().view(torch.int32), single[:, 2].contiguous().view(torch.int32))
         out["verify"] = {"merged_equals_single_device_ok": bool(same) if exact_ties else bool(lh_same),
-                         "merged_likelihoods_equal_ok": bool(lh_same), "tie_exact": bool(exact_ties), "backend": backend}
+                         "merged_likelihoods_equal_ok": bool(lh_same), "tie_exact": bool(exact_ties), "backend": backend,
+                         "exchange": "sparse" if sparse else "dense", "world": world}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(lib, meta, arr, tcpu, vx[sl], vy[sl], args.cpu_seconds)
+    # The same workload on a stack with 1 % of its science pixels masked -- what every real survey stack looks like: then
+    # every tile of kb_search_lds counts observations per sample instead of taking them from tables.
+    if rank == 0 and world == 1 and not dist_mode and not args.no_masked and args.mask_fraction == 0.0 and T * H * W * 16 < (8 << 30):
+        sci_m, var_m, _, _ = synthetic_stack(torch, dev, T, H, W, 0.01)
+        meta_m, arr_m = Meta(), C.c_void_p()
+        check(lib, lib.kb_build_psi_phi_from_device_ex(sci_m.data_ptr(), var_m.data_ptr(), psf_all.ctypes.data, psf_dims.ctypes.data,
+                                                       T, H, W, args.num_bytes, build_flags, C.byref(meta_m), C.byref(arr_m), stream))
+        torch.cuda.synchronize()
+        del sci_m, var_m
+        el_m, k_m, last_m = run_timed(meta_m, arr_m, args.warmup, args.steps)
+        out["masked"] = {"mask_fraction": 0.01, "ms_per_step": el_m / args.steps * 1e3, "kernel_ms": float(np.mean(k_m)),
+                         "value": int(last_m.num_evals) * args.steps / el_m, "unit": "evals/s",
+                         "kernel": last_m.kernel_name.decode(), "steps": args.steps,
+                         "obs_counts": "counted per sample in every tile"}
+        lib.kb_free_gpu_block(arr_m)
+
+    if rank == 0 and world == 1 and not dist_mode and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(lib, meta, arr, tcpu, vx[sl], vy[sl], args.cpu_seconds / 2)
+        if meta.num_bytes == 4:
+            out["cpu_baseline_full_sort"] = cpu_baseline_full_sort(lib, meta, arr, tcpu, vx[sl], vy[sl], args.cpu_seconds / 2)
 
     if os.environ.get("KBMOD_EXP_PROFILE") and hasattr(lib, "kb_exp_read_profile"):
         prof = (C.c_ulonglong * 8)()
@@ -453,8 +571,57 @@ def main():
     lib.kb_free_gpu_block(arr)
     if args.verify and rank == 0 and not all(v for k, v in out["verify"].items() if k.endswith("_ok")):
         sys.exit(3)
-    if world > 1:
+    if dist_mode:
         dist.destroy_process_group()
+
+
+def live_traffic(argv, instance):
+    """Fabric bytes per launch of the search kernel instance `instance`, measured now: two short sub-runs of this command
+    under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need separate passes: MI355X_MICROARCH.md, PMC slots), per-dispatch
+    average over the launches of that instance.  bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the counters are in KiB and
+    gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes (same guide, HBM section).  {"error": ...} when rocprofv3 is
+    missing or a pass fails."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"error": "rocprofv3 not found"}
+    child = [a for a in argv if a not in ("--verify",)]
+    for flag in ("--steps", "--warmup", "--gpus", "--cpu-seconds"):
+        while flag in child:
+            i = child.index(flag)
+            del child[i:i + 2]
+    cmd_tail = [sys.executable, os.path.abspath(__file__)] + child + ["--steps", "3", "--warmup", "1", "--child"]
+    found = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="kb_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([prof, "--pmc", counter, "-d", d, "-o", "r", "--"] + cmd_tail, cwd="/tmp", env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return {"error": f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"}
+            con = sqlite3.connect(dbs[0])
+            rows = con.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? "
+                               "group by kernel_name", (counter,)).fetchall()
+            con.close()
+            hit = [(n, c, v) for n, c, v in rows if instance in n]
+            if not hit:
+                return {"error": f"no dispatch of {instance} in the --pmc {counter} pass"}
+            found[counter] = (hit[0][1], float(hit[0][2]))
+        except (subprocess.TimeoutExpired, sqlite3.Error, OSError) as err:
+            return {"error": f"--pmc {counter} pass: {err}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch, write = found["FETCH_SIZE"][1], found["WRITE_SIZE"][1]
+    return {"bytes": int((2.0 * fetch + write) * 1024), "fetch_kib": fetch, "write_kib": write,
+            "source": f"live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE sub-runs of this command, average of "
+                      f"{found['FETCH_SIZE'][0]} launches of the instance; (2 x FETCH_SIZE + WRITE_SIZE) x 1024"}
 
 
 def verify(lib, torch, meta, arr, times, params, cands, n_cands, results, S, K, ins, W, H, last, stream):
@@ -527,6 +694,46 @@ def cpu_baseline(lib, meta, arr, times, vx, vy, target_s):
         "kind": "port",
         "sample": f"{rows} of {H} start rows (full width) x {len(cands)} candidates x {T} epochs of the same stack, "
                   f"{dt:.1f} s, oracle/kbmod_oracle.c orc_search_cpu (OpenMP)",
+    }
+
+
+def cpu_baseline_full_sort(lib, meta, arr, times, vx, vy, target_s):
+    """The reference CPU search's own shape (cpu_search_algorithms.cpp:57-124: per start pixel every candidate evaluated
+    into a list, the WHOLE list sorted, its head kept), as the product's host layer restates it (search_cpu_only of
+    kbmod_amd/csrc/host/stack_search.h, OpenMP over the host cores), on a bounded window of the same stack and candidates."""
+    import kbmod_amd.search as kb
+
+    T, H, W = int(meta.num_times), int(meta.height), int(meta.width)
+    host = np.empty((T, H, W, 2), dtype=np.float32)
+    check(lib, lib.kb_copy_block_to_cpu(host.ctypes.data, arr, meta.total_array_size))
+    pp = kb.PsiPhiArray()
+    kb.fill_psi_phi_array(pp, 4, [np.ascontiguousarray(host[t, :, :, 0]) for t in range(T)],
+                          [np.ascontiguousarray(host[t, :, :, 1]) for t in range(T)], [float(t) for t in times])
+    del host
+    cands = kb.TrajectoryList([kb.Trajectory(vx=float(a), vy=float(b)) for a, b in zip(vx, vy)])
+
+    def run(rows):
+        p = kb.SearchParameters()
+        p.min_observations, p.min_lh, p.do_sigmag_filter = 0, 0.0, False
+        p.x_start_min, p.x_start_max = 0, W
+        p.y_start_min = (H - rows) // 2
+        p.y_start_max = p.y_start_min + rows
+        p.results_per_pixel = 8
+        res = kb.TrajectoryList(0)
+        t0 = time.perf_counter()
+        kb.search_cpu_only(pp, p, cands, res)
+        return time.perf_counter() - t0, rows * W * len(vx) * T
+
+    dt, ev = run(8)  # calibration
+    rows = int(max(4, min(H, target_s * (ev / dt) / (W * len(vx) * T))))
+    dt, ev = run(rows)
+    return {
+        "value": ev / dt,
+        "unit": "evals/s",
+        "cores": int(os.cpu_count() or 1),
+        "kind": "restatement",
+        "sample": f"{rows} of {H} start rows (full width) x {len(vx)} candidates x {T} epochs of the same stack, {dt:.1f} s, "
+                  "kbmod_amd.search.search_cpu_only (per-pixel full sort like cpu_search_algorithms.cpp:57-86, OpenMP)",
     }
 
 

@@ -290,6 +290,32 @@ int kb_merge_compact(const kb_compact_result* lists_dev, int32_t n_lists, kb_sea
 int kb_merge_compact_exact(const kb_compact_result* lists_dev, int32_t n_lists, int32_t list_len, kb_search_params params,
                            const kb_trajectory* all_cands_dev, uint64_t n_all_cands, kb_trajectory* out_dev, void* stream);
 
+/* ---- sparse form of the exchange (new; SURVEY 8(e): "shrink traffic by compacting lh >= min_lh first").
+ * The reference removes results below min_lh after its kernel (stack_search.cpp:266-270); its swap-down insertion
+ * (kernels.cu:323-330) never lets a smaller likelihood touch the part of a list at or above a larger one, so the entries
+ * >= min_lh of a pixel's final list are what the same insertion yields over the candidates >= min_lh alone.  Dropping
+ * the records below min_lh (and the empty slots) BEFORE the exchange therefore changes nothing that survives the
+ * reference's own post-filter.
+ * kb_sparsify_compact: dense lists [n_pixels][list_len] of kb_device_search_compact ->
+ *   header_dev  kb_sparse_header_bytes(n_pixels) bytes: uint8 counts[n_pixels] (records kept per pixel: cand >= 0 and
+ *               !(lh < min_lh), in list order), zero padding to a multiple of 16, then the uint64 total;
+ *   packed_dev  the kept records, pixel after pixel (room for packed_capacity records; an error when more are kept --
+ *               *total_out_host then still holds the number, and the header is complete).
+ * min_lh = -INFINITY keeps every non-empty slot.  Synchronises the stream. */
+#define KB_SPARSE_BLOCK 256
+uint64_t kb_sparse_header_bytes(uint64_t n_pixels);
+int kb_sparsify_compact(const kb_compact_result* lists_dev, uint64_t n_pixels, int32_t list_len, float min_lh,
+                        uint8_t* header_dev, kb_compact_result* packed_dev, uint64_t packed_capacity,
+                        uint64_t* total_out_host, void* stream);
+/* kb_merge_compact_exact on sparse lists: headers_dev = n_lists headers header_stride bytes apart (what one gather of
+ * the devices' headers leaves on the root), packed_ptrs_host[r] = device pointer to list r's records (may be NULL when
+ * its total is 0).  out_dev: [n_pixels][K] trajectories; where a record survives the post-filter the output equals
+ * kb_merge_compact_exact's on the dense lists (and hence the single-device search), every other slot is the
+ * placeholder of kernels.cu:293-301.  Synchronises the stream. */
+int kb_merge_sparse_exact(const uint8_t* headers_dev, uint64_t header_stride, const kb_compact_result* const* packed_ptrs_host,
+                          int32_t n_lists, int32_t list_len, kb_search_params params, const kb_trajectory* all_cands_dev,
+                          uint64_t n_all_cands, kb_trajectory* out_dev, void* stream);
+
 /* ---- host instantiations of the device functions ------------------------- */
 /* kernels.cu:154-242 evaluateTrajectory called with host pointers
  * (stack_search.cpp:203-204). */

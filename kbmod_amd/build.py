@@ -20,7 +20,7 @@ _INC = os.path.join(_ROOT, "include")
 _LIBDIR = os.path.join(_PKG, "lib")
 
 HIP_SOURCES = ["search_lds.hip", "search_lds_encoded.hip", "search_direct.hip", "search_kernels.hip", "sigmag_kernels.hip",
-               "result_kernels.hip", "device_memory.hip", "image_kernels.hip", "stamp_kernels.hip", "fits_kernels.hip"]
+               "result_kernels.hip", "exchange_kernels.hip", "device_memory.hip", "image_kernels.hip", "stamp_kernels.hip", "fits_kernels.hip"]
 HIP_HEADERS = ["kb_common.h", "search_math.h", "search_common.h", "search_device.h", "search_lds.h", "search_lds_asm.h", "wave_ops.h"]
 HOST_SOURCES = ["host/bindings.cpp"]
 HOST_HEADERS = ["host/common.h", "host/image_utils.h", "host/psi_phi_array.h", "host/trajectory_list.h",

@@ -67,6 +67,12 @@ def load_lib():
     lib.kb_merge_compact.argtypes = [C.c_void_p, C.c_int32, Params, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.kb_merge_compact_exact.argtypes = [C.c_void_p, C.c_int32, C.c_int32, Params, C.c_void_p, C.c_uint64, C.c_void_p,
                                            C.c_void_p]
+    lib.kb_sparse_header_bytes.restype = C.c_uint64
+    lib.kb_sparse_header_bytes.argtypes = [C.c_uint64]
+    lib.kb_sparsify_compact.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64,
+                                        C.POINTER(C.c_uint64), C.c_void_p]
+    lib.kb_merge_sparse_exact.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, Params,
+                                          C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.kb_free_gpu_block.argtypes = [C.c_void_p]
     lib.kb_copy_block_to_cpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.kb_copy_block_to_gpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]

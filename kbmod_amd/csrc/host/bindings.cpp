@@ -395,6 +395,50 @@ PYBIND11_MODULE(search, m) {
           "Host twin of kb_merge_compact_exact: per-device lists of `list_len` 16-byte records per pixel, built by stable\n"
           "insertion, merged into the K results per pixel a single device would produce (ties included).");
 
+    m.def("sparse_header_bytes", &sparse_header_bytes, "Bytes of the header of a sparse exchange list for n_pixels pixels.");
+    m.def("sparsify_compact_host",
+          [](py::array_t<uint8_t, py::array::c_style> raw, uint64_t n_pixels, int list_len, float min_lh) {
+              if ((uint64_t)raw.size() != n_pixels * (uint64_t)list_len * sizeof(kb_compact_result)) {
+                  throw std::runtime_error("sparsify_compact_host: buffer size does not match n_pixels * list_len * 16");
+              }
+              std::vector<uint8_t> header;
+              std::vector<kb_compact_result> packed;
+              sparsify_compact_host(reinterpret_cast<const kb_compact_result*>(raw.data()), n_pixels, list_len, min_lh, header,
+                                    packed);
+              py::array_t<uint8_t> h((py::ssize_t)header.size());
+              std::memcpy(h.mutable_data(), header.data(), header.size());
+              py::array_t<uint8_t> p((py::ssize_t)(packed.size() * sizeof(kb_compact_result)));
+              if (!packed.empty()) std::memcpy(p.mutable_data(), packed.data(), packed.size() * sizeof(kb_compact_result));
+              return py::make_tuple(h, p);
+          },
+          "Host twin of kb_sparsify_compact: dense per-pixel lists of 16-byte records -> (header bytes, packed record bytes);\n"
+          "keeps the records with cand >= 0 and not lh < min_lh (the reference's post-filter, stack_search.cpp:266-270).");
+    m.def("merge_sparse_exact_host",
+          [](py::array_t<uint8_t, py::array::c_style> headers, uint64_t header_stride,
+             const std::vector<py::array_t<uint8_t, py::array::c_style>>& packed, int list_len, int K, int x_min, int x_max,
+             int y_min, int y_max, const std::vector<Trajectory>& all_cands) {
+              if (x_max <= x_min || y_max <= y_min) throw std::runtime_error("merge_sparse_exact_host: invalid search bounds");
+              const uint64_t n_pixels = (uint64_t)(x_max - x_min) * (uint64_t)(y_max - y_min);
+              if ((uint64_t)headers.size() < header_stride * packed.size()) {
+                  throw std::runtime_error("merge_sparse_exact_host: header buffer shorter than n_lists * header_stride");
+              }
+              std::vector<const kb_compact_result*> ptrs;
+              for (size_t r = 0; r < packed.size(); ++r) {
+                  uint64_t total = 0;
+                  for (uint64_t pix = 0; pix < n_pixels; ++pix) total += headers.data()[r * header_stride + pix];
+                  if ((uint64_t)packed[r].size() < total * sizeof(kb_compact_result)) {
+                      throw std::runtime_error("merge_sparse_exact_host: list " + std::to_string(r) + " holds fewer records than its counts say");
+                  }
+                  ptrs.push_back(reinterpret_cast<const kb_compact_result*>(packed[r].data()));
+              }
+              std::vector<Trajectory> out = merge_sparse_exact_host(headers.data(), header_stride, ptrs, n_pixels, list_len, K,
+                                                                    x_max - x_min, x_min, y_min, all_cands.data(), all_cands.size());
+              py::array_t<uint8_t> res((py::ssize_t)(out.size() * sizeof(Trajectory)));
+              if (!out.empty()) std::memcpy(res.mutable_data(), out.data(), out.size() * sizeof(Trajectory));
+              return res;
+          },
+          "Host twin of kb_merge_sparse_exact: the tie-exact merge over sparse per-device lists (headers + packed records).");
+
     // ---- near-duplicate grid filter on the device (filters/clustering_grid.py:152-175) ----
     m.def(
             "grid_filter_indices",

@@ -273,5 +273,75 @@ inline std::vector<Trajectory> merge_compact_exact_host(const kb_compact_result*
     return out;
 }
 
+// Host twins of kb_sparsify_compact / kb_merge_sparse_exact (csrc/exchange_kernels.hip): the sparse form of the
+// exchange lists -- per pixel the number of records that survive the reference's post-filter on the likelihood
+// (stack_search.cpp:266-270: lh < min_lh goes; empty slots carry cand = -1) + those records, pixel after pixel.
+inline uint64_t sparse_header_bytes(uint64_t n_pixels) { return (n_pixels + 15) / 16 * 16 + 16; }
+
+inline void sparsify_compact_host(const kb_compact_result* lists, uint64_t n_pixels, int list_len, float min_lh,
+                                  std::vector<uint8_t>& header, std::vector<kb_compact_result>& packed) {
+    if (list_len <= 0 || list_len > kb::MERGE_EXACT_MAX_K2) throw std::runtime_error("sparsify_compact: lists of 1 to 32 records per pixel");
+    header.assign(sparse_header_bytes(n_pixels), 0);
+    packed.clear();
+    for (uint64_t pix = 0; pix < n_pixels; ++pix) {
+        int kept = 0;
+        for (int p = 0; p < list_len; ++p) {
+            const kb_compact_result& r = lists[pix * (uint64_t)list_len + p];
+            if (r.cand >= 0 && !(r.lh < min_lh)) {
+                packed.push_back(r);
+                kept += 1;
+            }
+        }
+        header[pix] = (uint8_t)kept;
+    }
+    const uint64_t total = packed.size();
+    std::memcpy(header.data() + (n_pixels + 15) / 16 * 16, &total, sizeof(uint64_t));
+}
+
+inline std::vector<Trajectory> merge_sparse_exact_host(const uint8_t* headers, uint64_t header_stride,
+                                                       const std::vector<const kb_compact_result*>& packed, uint64_t n_pixels,
+                                                       int list_len, int K, int sw, int x_min, int y_min,
+                                                       const Trajectory* all_cands, uint64_t n_all_cands) {
+    const int n_lists = (int)packed.size();
+    if (K <= 0 || list_len < K || list_len > kb::MERGE_EXACT_MAX_K2) {
+        throw std::runtime_error("merge_sparse_exact: need K <= list length <= 32");
+    }
+    if (header_stride < sparse_header_bytes(n_pixels)) throw std::runtime_error("merge_sparse_exact: header stride shorter than a header");
+    std::vector<Trajectory> out(n_pixels * (uint64_t)K);
+    std::vector<uint64_t> at(n_lists, 0);  // first record of the current pixel in every list
+    std::vector<int> heads(n_lists);
+    kb::MergedEntry merged[kb::MERGE_EXACT_MAX_K2];
+    int slots[kb::MERGE_EXACT_MAX_K2];
+    for (uint64_t pix = 0; pix < n_pixels; ++pix) {
+        auto read = [&](int r, int pos) {
+            kb_compact_result rec{-FLT_MAX, 0.0f, -1, 0};
+            if (pos < (int)headers[(uint64_t)r * header_stride + pix]) rec = packed[r][at[r] + (uint64_t)pos];
+            return rec;
+        };
+        const int n_out = kb::merge_exact_pixel(read, n_lists, list_len, K, merged, heads.data(), slots);
+        const int y_i = (int)(pix / (uint64_t)sw), x_i = (int)(pix % (uint64_t)sw);
+        for (int s = 0; s < K; ++s) {
+            Trajectory t;
+            t.x = x_i + x_min;
+            t.y = y_i + y_min;
+            t.lh = -FLT_MAX;
+            if (s < n_out && slots[s] >= 0) {
+                const uint32_t where = merged[slots[s]].at;
+                const kb_compact_result rec = read((int)(where / (uint32_t)list_len), (int)(where % (uint32_t)list_len));
+                if ((uint64_t)rec.cand < n_all_cands) {
+                    t.vx = all_cands[rec.cand].vx;
+                    t.vy = all_cands[rec.cand].vy;
+                    t.lh = rec.lh;
+                    t.flux = rec.flux;
+                    t.obs_count = rec.obs_count;
+                }
+            }
+            out[pix * K + s] = t;
+        }
+        for (int r = 0; r < n_lists; ++r) at[r] += headers[(uint64_t)r * header_stride + pix];
+    }
+    return out;
+}
+
 }  // namespace search
 #endif

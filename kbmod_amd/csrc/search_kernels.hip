@@ -1219,6 +1219,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     return 0;
 }
 void release_result_arenas();  // result_kernels.hip: the scratch arena of kb_filter_sort_results
+void release_exchange_arenas();  // exchange_kernels.hip: block totals and offsets of the sparse exchange
 }  // namespace kb
 
 extern "C" {
@@ -1244,6 +1245,7 @@ int kb_device_search_compact(const kb_psi_phi_meta* meta, const void* psi_phi_de
 int kb_release_workspaces(void) {
     using namespace kb;
     release_result_arenas();
+    release_exchange_arenas();
     int prev = 0;
     const bool have_prev = hipGetDevice(&prev) == hipSuccess;
     for (int dev = 0; dev < MAX_DEVICES; ++dev) {

@@ -35,6 +35,17 @@ Two forms of the exchange:
   to the lower candidate index: the same likelihoods in the same slots as a single-GPU
   search, possibly another member of a tie.  Half the records on the wire.
 
+And one way of putting either on the wire:
+
+* **sparse** (``gather_and_merge_sparse``; SURVEY 8(e): "compacting lh >= min_lh first"): a search with a
+  likelihood threshold fills almost no slot -- the reference drops everything below ``min_lh`` right after its kernel
+  (stack_search.cpp:266-270), and its insertion never lets a smaller likelihood touch the part of a list at or above a
+  larger one, so dropping those records before the exchange changes nothing that survives.  Every rank turns its dense
+  lists into one count byte per pixel + the surviving records (``kb_sparsify_compact``), ONE gather collects the
+  headers, the records follow as one point-to-point message per rank of exactly the size its header announced, and the
+  root runs the same tie-exact merge through the counts (``kb_merge_sparse_exact``).  BASELINE configs[3] (128 x 4096 x
+  4096, K = 8, min_lh = 10): 16.8 MB + a few MB per rank instead of 4.3 GB.
+
 torch is plumbing only here: tensors as device buffers and torch.distributed
 as the RCCL front-end.
 """
@@ -59,6 +70,10 @@ def device_lib():
     return capi.load_lib()
 
 
+def _n_pixels(x_bounds, y_bounds):
+    return (int(x_bounds[1]) - int(x_bounds[0])) * (int(y_bounds[1]) - int(y_bounds[0]))
+
+
 def _bounds(x_bounds, y_bounds, K):
     from kbmod_amd import capi
 
@@ -79,8 +94,12 @@ def merge_compact(gathered, x_bounds, y_bounds, K, all_cands, out=None):
     _check_exchange_tensors(gathered, all_cands)
     world = gathered.shape[0]
     n_slots = gathered.shape[1]
+    n_pixels = _n_pixels(x_bounds, y_bounds)
+    if n_slots != n_pixels * int(K):
+        raise ValueError(f"gathered holds {n_slots} records per list, the bounds say {n_pixels} pixels x {int(K)}")
     if out is None:
         out = torch.empty((n_slots, TRJ_FLOATS), dtype=torch.float32, device=gathered.device)
+    _check_out(out, n_pixels, K, gathered.device)
     if gathered.is_cuda:
         lib = device_lib()
         stream = torch.cuda.current_stream().cuda_stream
@@ -107,9 +126,12 @@ def merge_compact_exact(gathered, x_bounds, y_bounds, K, list_len, all_cands, ou
 
     _check_exchange_tensors(gathered, all_cands)
     world = gathered.shape[0]
-    n_pixels = gathered.shape[1] // int(list_len)
+    n_pixels = _n_pixels(x_bounds, y_bounds)  # (what kb_merge_compact_exact derives its grid from)
+    if gathered.shape[1] != n_pixels * int(list_len):
+        raise ValueError(f"gathered holds {gathered.shape[1]} records per list, the bounds say {n_pixels} pixels x {int(list_len)}")
     if out is None:
         out = torch.empty((n_pixels * K, TRJ_FLOATS), dtype=torch.float32, device=gathered.device)
+    _check_out(out, n_pixels, K, gathered.device)
     if gathered.is_cuda:
         lib = device_lib()
         stream = torch.cuda.current_stream().cuda_stream
@@ -126,6 +148,157 @@ def merge_compact_exact(gathered, x_bounds, y_bounds, K, list_len, all_cands, ou
                                           int(y_bounds[0]), int(y_bounds[1]), cands)
         out.copy_(torch.from_numpy(res.view(np.float32).reshape(out.shape)))
     return out
+
+
+def sparsify_compact(records, n_pixels, list_len, min_lh, header=None, packed=None):
+    """Dense per-pixel lists ``records`` = [n_pixels*list_len, 4] int32 (kb_compact_result) -> ``(header, packed, total)``:
+    ``header`` uint8 [kb_sparse_header_bytes(n_pixels)] (one count per pixel, then the total), ``packed`` int32 [>= total, 4]
+    (the records with cand >= 0 and not lh < min_lh, pixel after pixel), ``total`` their number.  Device tensors:
+    kb_sparsify_compact; CPU tensors: its host twin.  ``header`` / ``packed``: preallocated buffers to reuse (``packed`` must
+    have room for every record kept; without one a buffer of exactly ``total`` records is made by a second pass)."""
+    import torch
+
+    if not (records.dtype == torch.int32 and records.dim() == 2 and records.shape[1] == COMPACT_WORDS
+            and records.is_contiguous() and records.shape[0] == int(n_pixels) * int(list_len)):
+        raise ValueError("records: expected a contiguous int32 tensor [n_pixels * list_len, 4] of kb_compact_result records")
+    min_lh = float("-inf") if min_lh is None else float(min_lh)
+    if records.is_cuda:
+        import ctypes as C
+
+        lib = device_lib()
+        hb = int(lib.kb_sparse_header_bytes(int(n_pixels)))
+        if header is None:
+            header = torch.empty(hb, dtype=torch.uint8, device=records.device)
+        if not (header.dtype == torch.uint8 and header.numel() == hb and header.is_contiguous() and header.device == records.device):
+            raise ValueError(f"header: expected a contiguous uint8 tensor of {hb} bytes on the records' device")
+        stream = torch.cuda.current_stream().cuda_stream
+        total = C.c_uint64(0)
+        cap = 0 if packed is None else int(packed.shape[0])
+        if packed is not None and not (packed.dtype == torch.int32 and packed.dim() == 2 and packed.shape[1] == COMPACT_WORDS
+                                       and packed.is_contiguous() and packed.device == records.device):
+            raise ValueError("packed: expected a contiguous int32 tensor [capacity, 4] on the records' device")
+        rc = lib.kb_sparsify_compact(records.data_ptr(), int(n_pixels), int(list_len), min_lh, header.data_ptr(),
+                                     0 if packed is None else packed.data_ptr(), cap, C.byref(total), stream)
+        if rc != 0 and packed is None and total.value > 0:
+            # no buffer was offered: now that the count is known, make one of exactly that size
+            packed = torch.empty((int(total.value), COMPACT_WORDS), dtype=torch.int32, device=records.device)
+            rc = lib.kb_sparsify_compact(records.data_ptr(), int(n_pixels), int(list_len), min_lh, header.data_ptr(),
+                                         packed.data_ptr(), int(total.value), C.byref(total), stream)
+        if rc != 0:
+            raise RuntimeError(lib.kb_last_error().decode())
+        if packed is None:
+            packed = torch.empty((0, COMPACT_WORDS), dtype=torch.int32, device=records.device)
+        return header, packed, int(total.value)
+    import kbmod_amd.search as kb
+
+    raw = np.ascontiguousarray(records.numpy()).view(np.uint8).reshape(-1)
+    h, p = kb.sparsify_compact_host(raw, int(n_pixels), int(list_len), min_lh)
+    return torch.from_numpy(h), torch.from_numpy(p.view(np.int32).reshape(-1, COMPACT_WORDS)), int(p.size // 16)
+
+
+def sparse_totals(headers, n_pixels):
+    """The record totals the headers [n_lists, header_bytes] announce (int64 on the host)."""
+    at = (int(n_pixels) + 15) // 16 * 16
+    return headers[:, at:at + 8].contiguous().cpu().view(headers.shape[0], 8).numpy().view(np.int64).reshape(-1)
+
+
+def merge_sparse_exact(headers, packed_list, x_bounds, y_bounds, K, list_len, all_cands, out=None):
+    """Tie-exact merge over sparse lists: ``headers`` uint8 [n_lists, header_bytes] (one gather of the ranks' headers),
+    ``packed_list[r]`` int32 [total_r, 4] -> [S*K, 7] trajectories: wherever a record survives the likelihood filter they
+    equal ``merge_compact_exact`` on the dense lists (hence the single-device search), every other slot is the empty-slot
+    placeholder.  Device tensors: kb_merge_sparse_exact; CPU tensors: its host twin."""
+    import torch
+
+    n_lists = int(headers.shape[0])
+    n_pixels = (int(x_bounds[1]) - int(x_bounds[0])) * (int(y_bounds[1]) - int(y_bounds[0]))
+    if not (headers.dtype == torch.uint8 and headers.dim() == 2 and headers.is_contiguous() and len(packed_list) == n_lists):
+        raise ValueError("headers: expected a contiguous uint8 tensor [n_lists, header_bytes] and one record tensor per list")
+    totals = sparse_totals(headers, n_pixels)
+    for r, p in enumerate(packed_list):
+        if not (p.dtype == torch.int32 and p.dim() == 2 and p.shape[1] == COMPACT_WORDS and p.is_contiguous()
+                and p.device == headers.device and p.shape[0] >= totals[r]):
+            raise ValueError(f"packed_list[{r}]: expected a contiguous int32 tensor [>= {totals[r]}, 4] on the headers' device")
+    if not (all_cands.dtype == torch.float32 and all_cands.dim() == 2 and all_cands.shape[1] == TRJ_FLOATS
+            and all_cands.is_contiguous() and all_cands.device == headers.device):
+        raise ValueError("all_cands: expected a contiguous float32 tensor [n, 7] on the headers' device")
+    if out is None:
+        out = torch.empty((n_pixels * int(K), TRJ_FLOATS), dtype=torch.float32, device=headers.device)
+    _check_out(out, n_pixels, K, headers.device)
+    if headers.is_cuda:
+        import ctypes as C
+
+        lib = device_lib()
+        ptrs = (C.c_void_p * n_lists)(*[(p.data_ptr() if p.shape[0] else None) for p in packed_list])
+        rc = lib.kb_merge_sparse_exact(headers.data_ptr(), int(headers.shape[1]), ptrs, n_lists, int(list_len),
+                                       _bounds(x_bounds, y_bounds, K), all_cands.data_ptr(), all_cands.shape[0], out.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError(lib.kb_last_error().decode())
+    else:
+        import kbmod_amd.search as kb
+
+        cands = [kb.Trajectory(vx=float(v[0]), vy=float(v[1])) for v in all_cands.numpy()]
+        res = kb.merge_sparse_exact_host(np.ascontiguousarray(headers.numpy()).reshape(-1), int(headers.shape[1]),
+                                         [np.ascontiguousarray(p.numpy()).view(np.uint8).reshape(-1) for p in packed_list],
+                                         int(list_len), int(K), int(x_bounds[0]), int(x_bounds[1]), int(y_bounds[0]),
+                                         int(y_bounds[1]), cands)
+        out.copy_(torch.from_numpy(res.view(np.float32).reshape(out.shape)))
+    return out
+
+
+def gather_and_merge_sparse(local_records, x_bounds, y_bounds, K, list_len, min_lh, all_cands, group=None, out=None, dst=0,
+                            header=None, packed=None, stats=None):
+    """The exchange step in its sparse form: sparsify on every rank, ONE gather of the headers to global rank ``dst``, one
+    point-to-point message per rank with exactly the records its header announced (all of them in flight together: seven
+    transfers into the root, each on its own xGMI link), and the tie-exact merge there.  Returns the merged [S*K, 7]
+    trajectories on rank ``dst`` and **None on every other rank**.  ``stats``: a dict that receives ``wire_bytes`` (what this
+    rank sent: header + records) and, on the root, ``totals``."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    me = dist.get_rank()
+    n_pixels = (int(x_bounds[1]) - int(x_bounds[0])) * (int(y_bounds[1]) - int(y_bounds[0]))
+    header, packed, total = sparsify_compact(local_records.contiguous(), n_pixels, list_len, min_lh, header, packed)
+    via_host = header.is_cuda and dist.get_backend(group) != "nccl"
+    h_send = header.cpu() if via_host else header
+    p_send = packed[:total].cpu() if via_host else packed[:total]
+    if stats is not None:
+        stats["wire_bytes"] = int(header.numel()) + 16 * total
+    if me != dst:
+        dist.gather(h_send, None, dst=dst, group=group)
+        if total:
+            dist.send(p_send, dst=dst, group=group)
+        return None
+    headers = torch.empty((world, h_send.numel()), dtype=torch.uint8, device=h_send.device)
+    dist.gather(h_send, [headers[r] for r in range(world)], dst=dst, group=group)
+    totals = sparse_totals(headers, n_pixels)
+    if stats is not None:
+        stats["totals"] = [int(t) for t in totals]
+    bufs, ops = [], []
+    for r in range(world):
+        if r == me:
+            bufs.append(p_send)
+            continue
+        bufs.append(torch.empty((int(totals[r]), COMPACT_WORDS), dtype=torch.int32, device=h_send.device))
+        if totals[r]:
+            ops.append(dist.P2POp(dist.irecv, bufs[r], r, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if via_host:
+        headers = headers.to(local_records.device)
+        bufs = [b.to(local_records.device) for b in bufs]
+    return merge_sparse_exact(headers, bufs, x_bounds, y_bounds, K, list_len, all_cands, out)
+
+
+def _check_out(out, n_pixels, K, device):
+    """Raw pointers cross into the C ABI: the preallocated result buffer must be what the merge kernels write."""
+    import torch
+
+    if not (out.dtype == torch.float32 and out.dim() == 2 and tuple(out.shape) == (int(n_pixels) * int(K), TRJ_FLOATS)
+            and out.is_contiguous() and out.device == device):
+        raise ValueError(f"out: expected a contiguous float32 tensor [{int(n_pixels) * int(K)}, 7] on {device}")
 
 
 def _check_exchange_tensors(gathered, all_cands):
@@ -187,13 +360,15 @@ class ExchangeInFlight:
     and the calling stream is not held up), the merge is enqueued behind it when ``finish()`` is called.  The caller must
     leave ``local_records`` (and ``gathered``) alone until then."""
 
-    def __init__(self, work, gathered, staged, merge_args, is_root):
+    def __init__(self, work, gathered, staged, merge_args, is_root, send=None):
         self._work, self._gathered, self._staged, self._merge_args, self._is_root = work, gathered, staged, merge_args, is_root
+        self._send = send  # the tensor on the wire (possibly a host copy made here): alive until finish()
 
     def finish(self):
         if self._work is not None:
             self._work.wait()  # device backends: the current stream waits for the collective; host backends: blocks
             self._work = None
+        self._send = None
         if not self._is_root:
             return None
         if self._staged is not None:
@@ -218,14 +393,14 @@ def start_gather_compact(local_records, x_bounds, y_bounds, K, all_cands, group=
     merge_args = (x_bounds, y_bounds, K, list_len, all_cands, out)
     if not _is_root(dst, group):
         work = dist.gather(send, None, dst=dst, group=group, async_op=True)
-        return ExchangeInFlight(work, None, None, merge_args, False)
+        return ExchangeInFlight(work, None, None, merge_args, False, send)
     if gathered is None:
         gathered = torch.empty((world,) + tuple(local_records.shape), dtype=local_records.dtype,
                                device=local_records.device)
     staged = torch.empty(gathered.shape, dtype=gathered.dtype) if via_host else None
     target = staged if via_host else gathered
     work = dist.gather(send, [target[r] for r in range(world)], dst=dst, group=group, async_op=True)
-    return ExchangeInFlight(work, gathered, staged, merge_args, True)
+    return ExchangeInFlight(work, gathered, staged, merge_args, True, send)
 
 
 def merge_topk(gathered, n_pixels, K, out=None):

@@ -29,51 +29,59 @@ def _free_port():
     return p
 
 
+def _stable_rank_lists(rank, world, K):
+    """What every rank's device search leaves with flag 512 -- the top 2 K of ITS candidates by (likelihood descending,
+    candidate ascending); here the oracle evaluates every candidate and the order is imposed with a stable sort."""
+    from kbmod_amd import distributed as kdist
+    from kbmod_amd import fake_data as fd
+    from oracle import oracle as orc
+    from tests import util
+
+    st = util.make_stack(12, 24, 40, seed=21, objects=[(8, 6, 14.0, 9.0, 200.0)], mask_fraction=0.02)
+    vx, vy = fd.kbmod_v1_candidates(7, 1.0, 40.0, 5, 0.0, 1.5)  # 35 candidates: uneven split, slow ones that coincide
+    S = 24 * 40
+    pp = orc.PsiPhi.from_images(st.sci, st.var, st.psfs, st.zeroed_times)
+    lo, hi = kdist.shard_bounds(len(vx), rank, world)
+    n_local = hi - lo
+    every = pp.search_kernel_semantics(orc.make_candidates(vx[lo:hi], vy[lo:hi]),
+                                       pp.default_params(results_per_pixel=n_local)).reshape(S, n_local)
+    index = {(float(a), float(b)): i for i, (a, b) in enumerate(zip(vx, vy))}
+    rec = np.zeros((S, 2 * K), dtype=[("lh", "<f4"), ("flux", "<f4"), ("cand", "<i4"), ("obs_count", "<i4")])
+    rec["lh"], rec["cand"] = np.float32(-3.4028234663852886e38), -1
+    for p in range(S):
+        rows = [(r["lh"], index[(float(r["vx"]), float(r["vy"]))], r["flux"], r["obs_count"]) for r in every[p]
+                if r["lh"] != np.float32(-3.4028234663852886e38)]
+        rows.sort(key=lambda r: (-r[0], r[1]))
+        for s, r in enumerate(rows[:2 * K]):
+            rec[p, s] = (r[0], r[2], r[1], r[3])
+    local_t = torch.from_numpy(rec.reshape(-1).view(np.int32).reshape(S * 2 * K, 4).copy())
+    all_cands = np.zeros((len(vx), 7), dtype=np.float32)
+    all_cands[:, 0], all_cands[:, 1] = vx, vy
+    return pp, vx, vy, local_t, torch.from_numpy(all_cands)
+
+
 def _exact_worker(rank, world, port, out_dir):
-    """Tie-exact exchange: every rank keeps the top 2 K of ITS candidates by (likelihood descending, candidate
-    ascending) -- what the device search leaves with flag 512; here the oracle evaluates every candidate and the
-    order is imposed with a stable sort -- and rank 0 merges with kb_merge_compact_exact's host twin."""
+    """Tie-exact exchange: rank 0 merges the ranks' stable lists with kb_merge_compact_exact's host twin."""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from kbmod_amd import distributed as kdist
-        from kbmod_amd import fake_data as fd
         from oracle import oracle as orc
-        from tests import util
 
-        st = util.make_stack(12, 24, 40, seed=21, objects=[(8, 6, 14.0, 9.0, 200.0)], mask_fraction=0.02)
-        vx, vy = fd.kbmod_v1_candidates(7, 1.0, 40.0, 5, 0.0, 1.5)  # 35 candidates: uneven split, slow ones that coincide
         K, S = 4, 24 * 40
-        pp = orc.PsiPhi.from_images(st.sci, st.var, st.psfs, st.zeroed_times)
-        lo, hi = kdist.shard_bounds(len(vx), rank, world)
-        n_local = hi - lo
-        every = pp.search_kernel_semantics(orc.make_candidates(vx[lo:hi], vy[lo:hi]),
-                                           pp.default_params(results_per_pixel=n_local)).reshape(S, n_local)
-        index = {(float(a), float(b)): i for i, (a, b) in enumerate(zip(vx, vy))}
-        rec = np.zeros((S, 2 * K), dtype=[("lh", "<f4"), ("flux", "<f4"), ("cand", "<i4"), ("obs_count", "<i4")])
-        rec["lh"], rec["cand"] = np.float32(-3.4028234663852886e38), -1
-        for p in range(S):
-            rows = [(r["lh"], index[(float(r["vx"]), float(r["vy"]))], r["flux"], r["obs_count"]) for r in every[p]
-                    if r["lh"] != np.float32(-3.4028234663852886e38)]
-            rows.sort(key=lambda r: (-r[0], r[1]))
-            for s, r in enumerate(rows[:2 * K]):
-                rec[p, s] = (r[0], r[2], r[1], r[3])
-        local_t = torch.from_numpy(rec.reshape(-1).view(np.int32).reshape(S * 2 * K, 4).copy())
-        all_cands = np.zeros((len(vx), 7), dtype=np.float32)
-        all_cands[:, 0], all_cands[:, 1] = vx, vy
+        pp, vx, vy, local_t, all_cands = _stable_rank_lists(rank, world, K)
         if world == 3:
             # the exchange in two halves (what bench.py --gpus N overlaps with the next search): two under way at once
-            first = kdist.start_gather_compact(local_t, (0, 40), (0, 24), K, torch.from_numpy(all_cands), list_len=2 * K)
-            second = kdist.start_gather_compact(local_t.clone(), (0, 40), (0, 24), K, torch.from_numpy(all_cands),
-                                                list_len=2 * K)
+            first = kdist.start_gather_compact(local_t, (0, 40), (0, 24), K, all_cands, list_len=2 * K)
+            second = kdist.start_gather_compact(local_t.clone(), (0, 40), (0, 24), K, all_cands, list_len=2 * K)
             merged, again = first.finish(), second.finish()
             assert (again is None) == (rank != 0)
             if rank == 0:
                 assert torch.equal(merged, again)
         else:
-            merged = kdist.gather_and_merge_compact(local_t, (0, 40), (0, 24), K, torch.from_numpy(all_cands), list_len=2 * K)
+            merged = kdist.gather_and_merge_compact(local_t, (0, 40), (0, 24), K, all_cands, list_len=2 * K)
         assert (merged is None) == (rank != 0)
         if rank == 0:
             full = pp.search_kernel_semantics(orc.make_candidates(vx, vy), pp.default_params(results_per_pixel=K))
@@ -81,6 +89,35 @@ def _exact_worker(rank, world, port, out_dir):
             np.save(os.path.join(out_dir, "full.npy"), full)
             more = pp.search_kernel_semantics(orc.make_candidates(vx, vy), pp.default_params(results_per_pixel=K + 1))
             np.save(os.path.join(out_dir, "more_lh.npy"), more["lh"].reshape(S, K + 1))
+    finally:
+        dist.destroy_process_group()
+
+
+def _sparse_worker(rank, world, port, out_dir, min_lh):
+    """The sparse form of the tie-exact exchange (kbmod_amd.distributed.gather_and_merge_sparse): one count byte per pixel
+    + the records that pass min_lh, one gather of the headers, one message per rank with records, merge on rank 0."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kbmod_amd import distributed as kdist
+        from oracle import oracle as orc
+
+        K, S = 4, 24 * 40
+        pp, vx, vy, local_t, all_cands = _stable_rank_lists(rank, world, K)
+        stats = {}
+        merged = kdist.gather_and_merge_sparse(local_t, (0, 40), (0, 24), K, 2 * K, min_lh, all_cands, stats=stats)
+        assert (merged is None) == (rank != 0)
+        assert stats["wire_bytes"] >= S and (stats["wire_bytes"] - (S + 15) // 16 * 16 - 16) % 16 == 0
+        dense = kdist.gather_and_merge_compact(local_t, (0, 40), (0, 24), K, all_cands, list_len=2 * K)
+        if rank == 0:
+            assert len(stats["totals"]) == world
+            full = pp.search_kernel_semantics(orc.make_candidates(vx, vy), pp.default_params(results_per_pixel=K))
+            np.save(os.path.join(out_dir, "got.npy"), merged.numpy().reshape(-1).view(orc.TRJ_DTYPE))
+            np.save(os.path.join(out_dir, "dense.npy"), dense.numpy().reshape(-1).view(orc.TRJ_DTYPE))
+            np.save(os.path.join(out_dir, "full.npy"), full)
+            np.save(os.path.join(out_dir, "wire.npy"), np.array([stats["wire_bytes"], local_t.numel() * 4]))
     finally:
         dist.destroy_process_group()
 
@@ -171,3 +208,28 @@ def test_tie_exact_gather_and_merge(tmp_path, orc, kb, world):
     assert got.tobytes() == full.tobytes()  # every field of every slot, ties included
     more = np.load(tmp_path / "more_lh.npy")
     assert ((more[:, :-1] == more[:, 1:]) & (more[:, :-1] > np.float32(-3.0e38))).any()  # and there were ties to get right
+
+
+@pytest.mark.parametrize("world,min_lh", [(2, 6.0), (3, 2.5), (2, None)])
+def test_sparse_gather_and_merge(tmp_path, orc, kb, world, min_lh):
+    """Sparse exchange over gloo == the unsharded search followed by the reference's likelihood filter, slot for slot."""
+    mp.spawn(_sparse_worker, args=(world, _free_port(), str(tmp_path), min_lh), nprocs=world, join=True)
+    got = np.load(tmp_path / "got.npy").reshape(-1, 4)
+    dense = np.load(tmp_path / "dense.npy").reshape(-1, 4)
+    full = np.load(tmp_path / "full.npy").reshape(-1, 4)
+    assert dense.tobytes() == full.tobytes()
+    thr = -np.inf if min_lh is None else np.float32(min_lh)
+    empty = np.float32(-3.4028234663852886e38)
+    n_pass = 0
+    for p in range(full.shape[0]):
+        want = full[p][(full[p]["lh"] != empty) & ~(full[p]["lh"] < thr)]
+        n = len(want)
+        n_pass += n
+        assert got[p, :n].tobytes() == want.tobytes()          # every field of every surviving slot, ties included
+        assert (got[p, n:]["lh"] == empty).all() and (got[p, n:]["obs_count"] == 0).all()
+        assert (got[p]["x"] == full[p]["x"]).all() and (got[p]["y"] == full[p]["y"]).all()
+    wire, dense_bytes = np.load(tmp_path / "wire.npy")
+    if min_lh is not None:
+        assert 0 < n_pass < full.size // 2 and wire < dense_bytes // 2  # a thresholded search: fewer bytes than the dense lists
+    else:
+        assert n_pass > full.size // 2 and wire > dense_bytes // 2

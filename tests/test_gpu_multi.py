@@ -226,8 +226,102 @@ def test_two_ranks_on_one_gpu_through_gloo(tmp_path):
     line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
     assert line["verify"] == {"merged_equals_single_device_ok": True, "merged_likelihoods_equal_ok": True, "tie_exact": True,
-                              "backend": "gloo"}
+                              "backend": "gloo", "exchange": "dense", "world": 2}
     assert line["config"]["candidates_per_gpu"] == 32
+
+
+def _bench_line(extra_args, env_extra, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "16", "--size", "128",
+           "--vel-steps", "8", "--ang-steps", "4", "--verify", "--no-cpu-baseline", "--no-live-traffic", "--no-masked"] + extra_args
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert run.returncode == 0, run.stderr[-3000:]
+    return json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_two_ranks_on_one_gpu_sparse_exchange_through_gloo():
+    """bench.py --gpus 2 with a likelihood threshold: the sparse exchange (count byte per pixel + surviving records, one
+    gather of headers + one message per rank) end to end as two processes, merged == the single-device search after the
+    reference's post-filter."""
+    line = _bench_line(["--gpus", "2", "--min-lh", "6"], {"KBMOD_DIST_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2
+    assert line["verify"] == {"merged_equals_single_device_ok": True, "merged_likelihoods_equal_ok": True, "tie_exact": True,
+                              "backend": "gloo", "exchange": "sparse", "world": 2}
+    ex = line["exchange"]
+    assert ex["form"] == "sparse" and ex["wire_bytes_per_rank"] < ex["dense_bytes_per_rank"] // 8
+    assert 0 < line["verify_survivors"] < 128 * 128 * 8 // 4 and sum(ex["records_per_rank"]) >= line["verify_survivors"]
+
+
+@pytest.mark.parametrize("extra", [[], ["--no-overlap"], ["--min-lh", "6"], ["--sigmag", "--num-bytes", "1"]])
+def test_rccl_backend_at_world_size_one(extra):
+    """The N > 1 branch of bench.py on the REAL backend (nccl = RCCL) with the one GPU there is: KBMOD_FORCE_DIST=1 makes a
+    world of one rank initialise the process group on the device and run compact search -> dist.gather of device tensors
+    (async, finished behind the next search) / sparse exchange -> merge kernel on the RCCL-ordered stream -> --verify."""
+    line = _bench_line(["--gpus", "1"] + extra, {"KBMOD_FORCE_DIST": "1"})
+    sparse = "--min-lh" in extra or "--sigmag" in extra
+    assert line["n_gpus"] == 1
+    assert line["verify"] == {"merged_equals_single_device_ok": True, "merged_likelihoods_equal_ok": True, "tie_exact": True,
+                              "backend": "nccl", "exchange": "sparse" if sparse else "dense", "world": 1}
+    assert line["exchange"]["backend"] == "nccl" and line["exchange"]["form"] == ("sparse" if sparse else "dense")
+    assert line["exchange"]["overlapped"] == (not sparse and "--no-overlap" not in extra)
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+@pytest.mark.parametrize("cfg", [dict(K=8, min_lh=5.0), dict(K=3, min_obs=5, min_lh=1.0), dict(K=16, min_lh=8.0),
+                                 dict(K=4, min_obs=8, sigmag=(0.25, 0.75, 0.7413, 3.0)), dict(K=8, min_lh=1.0e9), dict(K=5)])
+def test_sparse_exchange_kernels(kb, ds, grid, world, cfg):
+    """kb_sparsify_compact + kb_merge_sparse_exact on the device == their host twins, byte for byte; == the dense tie-exact
+    merge and == the unsharded search wherever a slot survives the reference's post-filter (lh >= min_lh), placeholders
+    elsewhere."""
+    from kbmod_amd import distributed as kdist
+
+    torch = ds.torch
+    vx, vy = grid
+    all_cands = ds.candidates(vx, vy)
+    p = ds.params(**cfg)
+    K = p.results_per_pixel
+    S = ds.W * ds.H
+    min_lh = float(p.min_lh) if ("min_lh" in cfg or "sigmag" in cfg) else None
+    p2 = ds.params(**{**cfg, "K": 2 * K})
+    headers, packed, dense = [], [], []
+    for r in range(world):
+        lo, hi = kdist.shard_bounds(len(vx), r, world)
+        rec, _ = ds.search_compact(p2, all_cands[lo:hi], lo, 512)
+        h, pk, total = kdist.sparsify_compact(rec, S, 2 * K, min_lh)
+        hh, hp, htotal = kdist.sparsify_compact(rec.cpu(), S, 2 * K, min_lh)
+        assert total == htotal == pk.shape[0] and torch.equal(h.cpu(), hh) and torch.equal(pk.cpu(), hp)
+        # a preallocated buffer that is too small: an error that names the count, and the header is complete
+        if total > 1:
+            with pytest.raises(RuntimeError, match=f"{total} records kept, room for 1"):
+                kdist.sparsify_compact(rec, S, 2 * K, min_lh, packed=torch.empty((1, 4), dtype=torch.int32, device="cuda"))
+        headers.append(h)
+        packed.append(pk)
+        dense.append(rec)
+    headers = torch.stack(headers)
+    merged = kdist.merge_sparse_exact(headers, packed, (0, ds.W), (0, ds.H), K, 2 * K, all_cands)
+    torch.cuda.synchronize()
+    host = kdist.merge_sparse_exact(headers.cpu(), [q.cpu() for q in packed], (0, ds.W), (0, ds.H), K, 2 * K, all_cands.cpu())
+    assert torch.equal(merged.cpu().view(torch.int32), host.view(torch.int32))
+    want = kdist.merge_compact_exact(torch.stack(dense), (0, ds.W), (0, ds.H), K, 2 * K, all_cands)
+    full, _ = ds.search(p, all_cands, 0)
+    assert torch.equal(want.view(torch.int32), full.view(torch.int32))
+    if min_lh is not None:
+        gone = want[:, 2] < min_lh
+        want[gone, 0:2] = 0.0
+        want[gone, 2] = float(EMPTY)
+        want[gone, 3] = 0.0
+        want.view(torch.int32)[gone, 6] = 0
+        if cfg.get("min_lh", 0) < 1.0e8:
+            assert 0 < int((~gone).sum()) < want.shape[0]
+        else:
+            assert int((want[:, 2] != float(EMPTY)).sum()) == 0  # nothing survives: every count is zero, every slot a placeholder
+    assert torch.equal(merged.view(torch.int32), want.view(torch.int32))
 
 
 @pytest.mark.parametrize("world", [2, 5])
