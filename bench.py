@@ -276,6 +276,11 @@ def main():
     else:
         results = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
 
+    # A search with a likelihood threshold is launched the way StackSearch.search_all launches it (flag 1024): what the
+    # reference's post-filter removes anyway need not enter a list.  The sparse exchange relies on the same post-filter;
+    # the dense one carries whole lists, sub-threshold slots included, and keeps the default.
+    base_flags = args.flags | (1024 if (thresholded and (sparse or not dist_mode)) else 0)
+
     def run_timed(meta, arr, n_warmup, n_steps):
         """n_warmup untimed + n_steps timed whole searches of the array at `arr`; (elapsed s, kernel ms per step, last stats)."""
         kernel_ms = []
@@ -293,7 +298,7 @@ def main():
             # Every step is a whole search: tables, decode-and-pad pass, search kernel.  --reuse-padded-copy adds flag 256
             # from the second step on (the array has not changed since the previous search: what a StackSearch with a
             # resident array passes), which lets the library keep the padded float copy of the last search.
-            flags = args.flags | (256 if (searched[0] and args.reuse_padded_copy) else 0)
+            flags = base_flags | (256 if (searched[0] and args.reuse_padded_copy) else 0)
             searched[0] = True
             if dist_mode:
                 b = which_set[0]
@@ -517,13 +522,14 @@ def main():
         out["config"]["sigmag_trajectories_clipped"] = int(last.sigmag_trajectories)
 
     if args.verify and world == 1 and not dist_mode:
-        out["verify"] = verify(lib, torch, meta, arr, times, params, cands, n_local, results, S, K, ins, W, H, last, stream)
+        out["verify"] = verify(lib, torch, meta, arr, times, params, cands, n_local, results, S, K, ins, W, H, last, stream,
+                               base_flags & 1024)
     if args.verify and dist_mode and rank == 0:
         # the merged lists of the job against ONE search over the job-wide candidate list on this rank's device
         single = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
         st1 = Stats()
         check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, all_cands.data_ptr(),
-                                               n_local * world, single.data_ptr(), S * K, args.flags, stream, C.byref(st1)))
+                                               n_local * world, single.data_ptr(), S * K, args.flags, stream, C.byref(st1)))  # (default lists: no floor)
         torch.cuda.synchronize()
         if sparse:
             # the sparse exchange carries what survives the reference's post-filter (stack_search.cpp:266-270): those
@@ -624,8 +630,9 @@ def live_traffic(argv, instance):
                       f"{found['FETCH_SIZE'][0]} launches of the instance; (2 x FETCH_SIZE + WRITE_SIZE) x 1024"}
 
 
-def verify(lib, torch, meta, arr, times, params, cands, n_cands, results, S, K, ins, W, H, last, stream):
-    """Size-independent checks of one finished search (results = its buffer, on the device)."""
+def verify(lib, torch, meta, arr, times, params, cands, n_cands, results, S, K, ins, W, H, last, stream, list_flags=0):
+    """Size-independent checks of one finished search (results = its buffer, on the device; list_flags = the flags of that
+    search that shape its lists, passed on to the searches it is compared with)."""
     dev = results.device
     sw = W - 2 * ins
 
@@ -640,7 +647,7 @@ def verify(lib, torch, meta, arr, times, params, cands, n_cands, results, S, K, 
     out = {}
     # 1. the other kernel, same search, bit for bit
     was_lds = int(last.kernel_variant) // 10000 != 0
-    other, st = run(params, S * K, 2 if was_lds else 4)
+    other, st = run(params, S * K, (2 if was_lds else 4) | list_flags)
     out["other_kernel"] = "kb_search_direct" if int(st.kernel_variant) // 10000 == 0 else "kb_search_lds"
     out["kernels_agree_ok"] = bool(torch.equal(results.view(torch.int32), other.view(torch.int32)))
     del other
@@ -653,7 +660,7 @@ def verify(lib, torch, meta, arr, times, params, cands, n_cands, results, S, K, 
     x1, y1 = min(x0 + 96, W - ins), min(y0 + 8, H - ins)
     wp = Params.from_buffer_copy(params)
     wp.x_start_min, wp.x_start_max, wp.y_start_min, wp.y_start_max = x0, x1, y0, y1
-    win, _ = run(wp, (x1 - x0) * (y1 - y0) * K, 1)
+    win, _ = run(wp, (x1 - x0) * (y1 - y0) * K, 1 | list_flags)
     full = results.view(H - 2 * ins, sw, K, 7)[y0 - ins:y1 - ins, x0 - ins:x1 - ins].reshape(-1, 7)
     out["exact_window"] = [x0, x1, y0, y1]
     out["exact_window_ok"] = bool(torch.equal(full.contiguous().view(torch.int32), win.view(torch.int32)))

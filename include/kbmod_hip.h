@@ -189,6 +189,11 @@ int kb_generate_psi_phi_host(const float* sci_host, const float* var_host, int w
  * 512  (changes the result under ties) per-pixel lists by stable insertion -- the top K by (likelihood descending,
  *      candidate ascending) instead of the reference's swap-down order: the per-device half of the tie-exact
  *      multi-GPU exchange (kb_merge_compact_exact), not a search result of its own.
+ * 1024 the caller drops every result below params.min_lh afterwards (the reference does, stack_search.cpp:266-270; the
+ *      sparse exchange kb_sparsify_compact does): the kernels then need not insert such candidates.  The slots at or
+ *      above min_lh are exactly those of the default -- the reference's insertion never lets a smaller likelihood touch
+ *      the part of a list at or above a larger one --; which entries below min_lh a list still shows is unspecified.
+ *      (With the sigma-G filter the kernel tests min_lh itself, kernels.cu:318-320; the flag changes nothing there.)
  * The library keeps its workspaces (shift tables, sigma-G scratch, padded copy) between
  * calls; kb_release_workspaces() returns them. */
 int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,

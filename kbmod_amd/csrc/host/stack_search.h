@@ -388,11 +388,14 @@ public:
                 // flag 256: this object owns the array and has not touched it since its last search on the device
                 // (the library then reuses its padded copy when the frame geometry is the same)
                 const uint32_t unchanged = (psi_phi_preloaded && resident_searched) ? 256u : 0u;
+                // flag 1024: everything below min_lh is removed a few lines down (stack_search.cpp:266-270), so the kernels
+                // need not insert it in the first place -- same survivors, no list work on pixels nothing reaches
+                const uint32_t below_min_lh_dropped = 1024u;
                 check_status(kb_device_search_filter(
                         &psi_phi_array.get_meta_data(), psi_phi_array.get_gpu_array_ptr(),
                         psi_phi_array.get_gpu_time_array_ptr(), params,
                         reinterpret_cast<const kb_trajectory*>(candidate_list.get_gpu_list_ptr()), candidate_list.get_size(),
-                        raw.as<kb_trajectory>(), max_results, search_flags | unchanged, nullptr, &last_stats));
+                        raw.as<kb_trajectory>(), max_results, search_flags | unchanged | below_min_lh_dropped, nullptr, &last_stats));
                 resident_searched = psi_phi_preloaded;
                 candidate_list.move_to_cpu();
             }
@@ -550,7 +553,7 @@ protected:
         SearchParameters part_params = params;
         if (exact) part_params.results_per_pixel = 2 * params.results_per_pixel;
         const uint64_t part_results = max_results / params.results_per_pixel * part_params.results_per_pixel;
-        const uint32_t part_flags = search_flags | (exact ? 512u : 0u);
+        const uint32_t part_flags = search_flags | (exact ? 512u : 0u) | 1024u;  // (1024: search_all drops lh < min_lh behind the merge)
         for (int d : search_devices) {  // replicas are made here, one after the other, before the threads start
             if (d != home) (void)replica_on(d, home);
         }

@@ -107,7 +107,7 @@ __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoor
             float p = ps[c], f = ph[c];
             asm volatile("" : "+v"(p), "+v"(f), "+v"(top.lh[KS - 1]));
             const float lh = lh_from_sums(p, f);
-            if (!(cnt[c] < a.min_obs)) top.insert(lh, cand, a.stable_lists != 0);
+            if (!(cnt[c] < a.min_obs) && lh > a.min_lh) top.insert(lh, cand, a.stable_lists != 0);  // (min_lh: the lists' floor, flag 1024)
         }
     }
 }
@@ -128,7 +128,8 @@ __device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chu
         float p = ps[c], f = ph[c];
         asm volatile("" : "+v"(p), "+v"(f), "+v"(ls.threshold));
         const bool real = (chunk * C + c) < a.n_cands;  // uniform
-        const float lh = (real && !(cnt[c] < a.min_obs)) ? lh_from_sums(p, f) : -FLT_MAX;
+        float lh = (real && !(cnt[c] < a.min_obs)) ? lh_from_sums(p, f) : -FLT_MAX;
+        lh = lh > a.min_lh ? lh : -FLT_MAX;  // (min_lh: the lists' floor, flag 1024; else -FLT_MAX)
         if constexpr (RECORDS) ph[c] = flux_from_sums(p, f);
         ps[c] = lh;
         beats = beats || (lh > ls.threshold);
@@ -146,7 +147,7 @@ __device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chu
 #pragma unroll
         for (int c = 0; c < C; ++c) top.insert(ps[c], chunk * C + c, ph[c], cnt[c], a.stable_lists != 0);
         top.store(tile_list, lane_off, stride_bytes);
-        ls.threshold = top.lh[KS - 1];
+        ls.threshold = fmaxf(top.lh[KS - 1], a.min_lh);  // (never below the lists' floor, flag 1024)
     } else {
         TopK<KS> top;
         if (ls.stored) {
@@ -157,7 +158,7 @@ __device__ __forceinline__ void finish_chunk_stored(const SearchArgs& a, int chu
 #pragma unroll
         for (int c = 0; c < C; ++c) top.insert(ps[c], chunk * C + c, a.stable_lists != 0);
         top.store(tile_list, lane_off, stride_bytes);
-        ls.threshold = top.lh[KS - 1];
+        ls.threshold = fmaxf(top.lh[KS - 1], a.min_lh);
     }
     ls.stored = 1;
 }
@@ -200,7 +201,7 @@ __device__ __forceinline__ void select_by_bits(const float (&ps)[C], const float
 template <int KS, int C>
 __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int chunk, const float (&ps)[C], const float (&ph)[C],
                                                     const int (&cnt)[C], TopKPacked<KS>& top) {
-    const float floor_lh = screen_floor(top.lh[KS - 1]);
+    const float floor_lh = screen_floor(fmaxf(top.lh[KS - 1], a.min_lh));  // (min_lh: the lists' floor, flag 1024; else -FLT_MAX)
     uint32_t pending = 0;
 #pragma unroll
     for (int c = C - 1; c >= 0; --c) {  // (downwards: the mask is built by shifting)
@@ -344,7 +345,7 @@ __device__ __forceinline__ void finish_chunk_pooled(const SearchArgs& a, int chu
     }
     if (mine) {
         top.store(tile_list, lay, tid);
-        ls.threshold = top.lh[15];
+        ls.threshold = fmaxf(top.lh[15], a.min_lh);  // (never below the lists' floor, flag 1024)
         ls.stored = 1;
     }
 }
@@ -411,7 +412,7 @@ __device__ __forceinline__ void finish_chunk_records(const SearchArgs& a, int ch
         float p = ps[c], f = ph[c];
         asm volatile("" : "+v"(p), "+v"(f), "+v"(top.lh[KS - 1]));  // one candidate after the other (see finish_chunk)
         const float lh = lh_from_sums(p, f);
-        if (!(cnt[c] < a.min_obs) && lh > top.lh[KS - 1]) top.insert(lh, cand, flux_from_sums(p, f), cnt[c], a.stable_lists != 0);
+        if (!(cnt[c] < a.min_obs) && lh > top.lh[KS - 1] && lh > a.min_lh) top.insert(lh, cand, flux_from_sums(p, f), cnt[c], a.stable_lists != 0);
     }
 }
 template <int KS>

@@ -745,7 +745,14 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     a.x_start_min = params.x_start_min;
     a.y_start_min = params.y_start_min;
     a.min_obs = params.min_observations;
-    a.min_lh = params.min_lh;
+    // Sigma-G searches test `lh < min_lh` inside the kernel (kernels.cu:318-320).  Without the filter the reference inserts
+    // whatever beats a slot and drops lh < min_lh afterwards (stack_search.cpp:266-270); flag 1024 (the caller will apply
+    // that post-filter, or the sparse exchange will) lets the lists ignore such candidates from the start: `min_lh` then is
+    // the largest float below params.min_lh, a floor under every list's "likelihood to beat" -- a candidate enters only with
+    // lh > floor, i.e. lh >= min_lh.  Slots at or above min_lh are exactly those of the default (the swap-down insertion
+    // never lets a smaller value touch the part of a list at or above a larger one); -FLT_MAX = no floor.
+    a.min_lh = params.do_sigmag_filter ? params.min_lh
+                                       : ((flags & 1024u) != 0 && params.min_lh > -FLT_MAX ? std::nextafterf(params.min_lh, -INFINITY) : -FLT_MAX);
     a.psi_scale = meta->psi_scale;
     a.psi_min_val = meta->psi_min_val;
     a.phi_scale = meta->phi_scale;

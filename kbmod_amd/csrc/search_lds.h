@@ -768,7 +768,7 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
     TileLists<KS, LM> lists;
     lists.top.init();
     lists.packed.init();
-    lists.state = {-FLT_MAX, 0};
+    lists.state = {SIGMAG ? -FLT_MAX : a.min_lh, 0};  // the likelihood to beat starts at the lists' floor (flag 1024; else -FLT_MAX)
     lists.store = (SIGMAG || !TileLists<KS, LM>::STORED)
                           ? nullptr
                           : reinterpret_cast<char*>(a.lists) +

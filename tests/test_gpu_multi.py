@@ -342,3 +342,42 @@ def test_merge_topk_kernel_equals_host_twin(kb, ds, grid, world):
     assert ds.torch.equal(dev.cpu().view(ds.torch.int32), host.view(ds.torch.int32))
     full, _ = ds.search(p, ds.candidates(vx, vy), 0)
     assert np.array_equal(util.as_records(dev)["lh"], util.as_records(full)["lh"])
+
+
+def _mask_below(torch, t, min_lh):
+    """Result tensor [S*K, 7] with every slot below min_lh (and every empty one) turned into the empty-slot placeholder."""
+    t = t.clone()
+    gone = t[:, 2] < min_lh
+    t[gone, 0:2] = 0.0
+    t[gone, 2] = float(EMPTY)
+    t[gone, 3] = 0.0
+    t.view(torch.int32)[gone, 6] = 0
+    return t, int((~gone).sum())
+
+
+@pytest.mark.parametrize("stable", [0, 512])
+@pytest.mark.parametrize("flags", [2, 4, 4 | 64, 4 | 128])
+@pytest.mark.parametrize("cfg", [dict(K=8, min_lh=5.0), dict(K=16, min_lh=3.0), dict(K=4, min_obs=10, min_lh=6.0),
+                                 dict(K=32, min_lh=4.0), dict(K=8, min_lh=-2.0)])
+@pytest.mark.parametrize("which", ["chunks_of_8", "wide_chunks"])
+def test_list_floor_flag_keeps_every_survivor(ds, ds_dyadic, grid, grid_dense, which, cfg, flags, stable):
+    """Flag 1024 (nothing below min_lh need enter a list: the caller post-filters like stack_search.cpp:266-270): every slot
+    at or above min_lh is bit for bit the slot of the default search, in every kernel and list form, with the reference's
+    insertion and with stable lists."""
+    d, (vx, vy) = (ds, grid) if which == "chunks_of_8" else (ds_dyadic, grid_dense)
+    torch = d.torch
+    cands = d.candidates(vx, vy)
+    p = d.params(**cfg)
+    plain, st0 = d.search(p, cands, flags | stable)
+    floor, st1 = d.search(p, cands, flags | stable | 1024)
+    assert st0.kernel_name == st1.kernel_name
+    a, n_a = _mask_below(torch, plain, cfg["min_lh"])
+    b, n_b = _mask_below(torch, floor, cfg["min_lh"])
+    assert n_a == n_b and 0 < n_a
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    if cfg["min_lh"] > 0:
+        # ... and the lists really are spared: hardly anything below the floor is left in them (only what the approximate
+        # screen cannot decide)
+        r = util.as_records(floor)
+        below = (r["lh"] != EMPTY) & (r["lh"] < np.float32(cfg["min_lh"]))
+        assert below.sum() <= max(4, n_a // 50)

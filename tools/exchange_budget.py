@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""The multi-GPU exchange of one job, measured piece by piece on ONE GPU (no 8-GPU node needed):
+
+    python tools/exchange_budget.py --frames 128 --size 4096 --vel-steps 32 --ang-steps 2 --world 8 --min-lh 10
+
+plays every rank's part one after the other on this device -- the search of its (v, theta) slice with 2 K stable records
+per pixel (flag 512), kb_sparsify_compact -- keeps what each rank would put on the wire, then runs the root's merge over the
+`world` lists (sparse: kb_merge_sparse_exact; dense: kb_merge_compact_exact, when --dense) and checks the merged result
+against ONE search over the job-wide candidate list on the same device.  Prints one JSON object: per-rank search /
+sparsify times, bytes on the wire per rank (sparse and dense), merge times, and the step and aggregate an N-GPU run would
+see WITHOUT any overlap of exchange and search (xGMI at 153 GB/s per link into the root, one link per peer)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+XGMI_LINK_GBPS = 153.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=128)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--vel-steps", type=int, default=32)
+    ap.add_argument("--ang-steps", type=int, default=2)
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--min-lh", type=float, default=10.0)
+    ap.add_argument("--results-per-pixel", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--rank-flags", type=int, default=1024,
+                    help="extra kb_device_search_compact flags of the per-rank searches (1024: nothing below min_lh enters a list; 0 to compare)")
+    ap.add_argument("--dense", action="store_true", help="also gather and merge the dense lists (world x S x 2K x 16 bytes on this device)")
+    args = ap.parse_args()
+
+    import torch
+
+    import bench
+    from kbmod_amd import distributed as kdist
+    from kbmod_amd import fake_data as fd
+    from kbmod_amd.capi import Meta, Params, Stats, load_lib
+
+    lib = load_lib()
+    dev = torch.device("cuda", 0)
+    T, H, W, K, world = args.frames, args.size, args.size, args.results_per_pixel, args.world
+    L = 2 * K
+    S = H * W
+    sci, var, times, psf = bench.synthetic_stack(torch, dev, T, H, W)
+    psf_all = np.ascontiguousarray(np.tile(psf.ravel(), T), dtype=np.float32)
+    psf_dims = np.full(T, psf.shape[0], dtype=np.int32)
+    meta, arr = Meta(), C.c_void_p()
+    stream = torch.cuda.current_stream().cuda_stream
+    bench.check(lib, lib.kb_build_psi_phi_from_device_ex(sci.data_ptr(), var.data_ptr(), psf_all.ctypes.data, psf_dims.ctypes.data,
+                                                         T, H, W, -1, 0, C.byref(meta), C.byref(arr), stream))
+    torch.cuda.synchronize()
+    del sci, var
+
+    n_local = args.vel_steps * args.ang_steps
+    vx, vy = fd.kbmod_v1_candidates(args.vel_steps, 5.0, 40.0, args.ang_steps * world, 0.0, 1.5)
+    all_np = np.zeros((n_local * world, 7), dtype=np.float32)
+    all_np[:, 0], all_np[:, 1] = vx, vy
+    all_cands = torch.from_numpy(all_np).to(dev)
+    params = Params(0, args.min_lh, 0, 0.25, 0.75, -1.0, -1, 0, W, 0, H, K, 0)
+    rank_params = Params.from_buffer_copy(params)
+    rank_params.results_per_pixel = L
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    records = torch.empty((S * L, 4), dtype=torch.int32, device=dev)
+    packed_buf = torch.empty((max(1024, S * L // 16), 4), dtype=torch.int32, device=dev)
+    header_buf = torch.empty(int(lib.kb_sparse_header_bytes(S)), dtype=torch.uint8, device=dev)
+    headers, packed, dense_lists = [], [], []
+    search_ms, kernel_ms, sparsify_ms, wire = [], [], [], []
+    for r in range(world):
+        cands = all_cands[r * n_local:(r + 1) * n_local]
+        st = Stats()
+
+        def search():
+            bench.check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), rank_params, cands.data_ptr(),
+                                                          n_local, r * n_local, records.data_ptr(), S * L, 512 | args.rank_flags, stream, C.byref(st)))
+
+        search_ms.append(timed(search, args.reps))
+        kernel_ms.append(float(st.search_kernel_ms))
+        out = {}
+
+        def sparsify():
+            out["h"], out["p"], out["n"] = kdist.sparsify_compact(records, S, L, args.min_lh, header_buf, packed_buf)
+
+        sparsify_ms.append(timed(sparsify, args.reps))
+        headers.append(out["h"].clone())
+        packed.append(out["p"][:out["n"]].clone())
+        wire.append(int(header_buf.numel()) + 16 * out["n"])
+        if args.dense:
+            dense_lists.append(records.clone())
+    headers = torch.stack(headers)
+    results = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
+
+    merge_sparse_ms = timed(lambda: kdist.merge_sparse_exact(headers, packed, (0, W), (0, H), K, L, all_cands, out=results),
+                            args.reps)
+    merged = results.clone()
+    merge_dense_ms = None
+    if args.dense:
+        gathered = torch.stack(dense_lists)
+        del dense_lists
+        merge_dense_ms = timed(lambda: kdist.merge_compact_exact(gathered, (0, W), (0, H), K, L, all_cands, out=results), args.reps)
+        del gathered
+
+    # one search over the job-wide list on this device: the answer the merged lists must give, and the single-GPU step
+    single = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
+    st1 = Stats()
+
+    def one():
+        bench.check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, all_cands.data_ptr(),
+                                                     n_local * world, single.data_ptr(), S * K, 0, stream, C.byref(st1)))
+
+    one_all_ms = timed(one, 1)
+    gone = single[:, 2] < args.min_lh
+    survivors = int((~gone).sum().item())
+    single[gone, 0:2] = 0.0
+    single[gone, 2] = torch.finfo(torch.float32).min
+    single[gone, 3] = 0.0
+    single.view(torch.int32)[gone, 6] = 0
+    ok = bool(torch.equal(merged.view(torch.int32), single.view(torch.int32)))
+    del single
+
+    # the single-GPU step of the weak-scaling series: n_local candidates, K records per pixel, the reference's insertion
+    st0 = Stats()
+    res1 = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
+
+    def one_rank_plain():
+        bench.check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, all_cands.data_ptr(), n_local,
+                                                     res1.data_ptr(), S * K, 0, stream, C.byref(st0)))
+
+    single_gpu_ms = timed(one_rank_plain, args.reps)
+
+    dense_bytes = S * L * 16
+    wire_ms_sparse = max(wire) / (XGMI_LINK_GBPS * 1e6)
+    wire_ms_dense = dense_bytes / (XGMI_LINK_GBPS * 1e6)
+    rank_ms = max(a + b for a, b in zip(search_ms, sparsify_ms))
+    step_sparse = rank_ms + wire_ms_sparse + merge_sparse_ms
+    out = {
+        "workload": f"{T}x{H}x{W} f32, {n_local} candidates per rank x {world} ranks, K={K}, lists of {L} stable records, min_lh={args.min_lh:g}",
+        "per_rank": {"search_call_ms": search_ms, "search_kernel_ms": kernel_ms, "sparsify_ms": sparsify_ms, "wire_bytes": wire,
+                     "dense_wire_bytes": dense_bytes},
+        "root": {"merge_sparse_ms": merge_sparse_ms, "merge_dense_ms": merge_dense_ms,
+                 "merge_sparse_reads_bytes": int(sum(wire)), "merge_dense_reads_bytes": dense_bytes * world,
+                 "merge_writes_bytes": S * K * 28},
+        "verify": {"merged_equals_single_device_after_post_filter_ok": ok, "survivors": survivors},
+        "single_gpu": {"step_ms": single_gpu_ms, "kernel_ms": float(st0.search_kernel_ms), "kernel": st0.kernel_name.decode(),
+                       "job_wide_list_on_one_gpu_ms": one_all_ms},
+        "predicted_no_overlap": {
+            "xgmi_link_GBps": XGMI_LINK_GBPS,
+            "wire_ms_sparse": wire_ms_sparse, "wire_ms_dense": wire_ms_dense,
+            "step_ms_sparse": step_sparse,
+            "step_ms_dense": None if merge_dense_ms is None else max(search_ms) + wire_ms_dense + merge_dense_ms,
+            "aggregate_vs_one_gpu_sparse": world * single_gpu_ms / step_sparse,
+            "aggregate_vs_one_gpu_dense": None if merge_dense_ms is None else world * single_gpu_ms / (max(search_ms) + wire_ms_dense + merge_dense_ms),
+        },
+    }
+    print(json.dumps(out))
+    lib.kb_free_gpu_block(arr)
+    sys.exit(0 if ok else 3)
+
+
+if __name__ == "__main__":
+    main()
