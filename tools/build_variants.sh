@@ -17,7 +17,7 @@ for v in "$@"; do
     objs=""; for s in $SRCS; do objs="$objs /tmp/var_${name}_$s.o"; done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs \
       kbmod_amd/_obj/device_memory.o kbmod_amd/_obj/image_kernels.o kbmod_amd/_obj/result_kernels.o \
-      kbmod_amd/_obj/stamp_kernels.o -o tools/probe_bin/libkbmod_$name.so
+      kbmod_amd/_obj/stamp_kernels.o kbmod_amd/_obj/fits_kernels.o kbmod_amd/_obj/exchange_kernels.o -o tools/probe_bin/libkbmod_$name.so
     mkdir -p /tmp/objs_$name; for s in $SRCS; do cp /tmp/var_${name}_$s.o /tmp/objs_$name/$s.o; done
   ) &
 done
