@@ -129,6 +129,10 @@ def main():
     ap.add_argument("--reuse-padded-copy", action="store_true",
                     help="from the second step on tell the library that the array is unchanged (flag 256), as a StackSearch "
                          "with a resident array does: the decode-and-pad pass is then skipped (not the default: a step is a whole search)")
+    ap.add_argument("--remake-padded-copy", action="store_true",
+                    help="flag 2048: every step re-makes the padded canonical copy of the array (the decode-and-pad pass).  Default: "
+                         "the library keeps the copy of an array it built itself for as long as nothing writes into the array -- "
+                         "made once, by the first search (a warm-up step here), like psi/phi itself is built before the timed region")
     ap.add_argument("--no-overlap", action="store_true",
                     help="--gpus N > 1: finish every step's gather and merge before the next search starts (default: the "
                          "gather of step i travels while step i + 1 searches; all K steps complete inside the timed region)")
@@ -279,7 +283,7 @@ def main():
     # A search with a likelihood threshold is launched the way StackSearch.search_all launches it (flag 1024): what the
     # reference's post-filter removes anyway need not enter a list.  The sparse exchange relies on the same post-filter;
     # the dense one carries whole lists, sub-threshold slots included, and keeps the default.
-    base_flags = args.flags | (1024 if (thresholded and (sparse or not dist_mode)) else 0)
+    base_flags = args.flags | (1024 if (thresholded and (sparse or not dist_mode)) else 0) | (2048 if args.remake_padded_copy else 0)
 
     def run_timed(meta, arr, n_warmup, n_steps):
         """n_warmup untimed + n_steps timed whole searches of the array at `arr`; (elapsed s, kernel ms per step, last stats)."""
@@ -486,6 +490,8 @@ def main():
             "kernel_ms": k_ms,
             "obs_counts": ("border tiles from tables of epochs per shift (the stack has no masked pixel), none needed elsewhere"
                            if int(last.edge_count_tables) and args.mask_fraction == 0.0 else "counted per sample where NO_DATA can occur"),
+            "padded_copy": ("kept from the first search of this array (the library built the array and nothing has written into it)"
+                            if int(last.padded_copy_reused) else "made by this search (decode-and-pad pass inside the step)"),
             "kernel_evals_per_s": evals_per_step_rank / (k_ms * 1e-3),
             "frac_algorithmic": alg_rate / HBM_PEAK_GBPS,
             "algorithmic_bytes_per_launch": int(last.algorithmic_bytes),
@@ -737,7 +743,7 @@ def cpu_baseline_full_sort(lib, meta, arr, times, vx, vy, target_s):
     return {
         "value": ev / dt,
         "unit": "evals/s",
-        "cores": int(os.cpu_count() or 1),
+        "cores": int(kb.omp_max_threads()),
         "kind": "restatement",
         "sample": f"{rows} of {H} start rows (full width) x {len(vx)} candidates x {T} epochs of the same stack, {dt:.1f} s, "
                   "kbmod_amd.search.search_cpu_only (per-pixel full sort like cpu_search_algorithms.cpp:57-86, OpenMP)",

@@ -88,6 +88,9 @@ int kb_allocate_gpu_block(uint64_t memory_size, void** out_dev);                
 int kb_free_gpu_block(void* ptr_dev);                                                /* :105 */
 int kb_copy_block_to_gpu(const void* src_host, void* dst_dev, uint64_t memory_size); /* :112 */
 int kb_copy_block_to_cpu(void* dst_host, const void* src_dev, uint64_t memory_size); /* :124 */
+/* new: kb_copy_block_to_cpu for large result blocks -- the (pageable) destination is page-locked for the duration of the
+ * copy, one DMA at the link's rate; falls back to the plain copy where the memory cannot be registered. */
+int kb_copy_block_to_cpu_locked(void* dst_host, const void* src_dev, uint64_t memory_size);
 int kb_device_synchronize(void);
 /* new (multi-GPU fan-out inside one process): the calling thread's current device, and a copy between two devices'
  * HBM (over xGMI where the devices are peers).  Every entry point acts on the calling thread's current device; the
@@ -189,6 +192,10 @@ int kb_generate_psi_phi_host(const float* sci_host, const float* var_host, int w
  * 512  (changes the result under ties) per-pixel lists by stable insertion -- the top K by (likelihood descending,
  *      candidate ascending) instead of the reference's swap-down order: the per-device half of the tie-exact
  *      multi-GPU exchange (kb_merge_compact_exact), not a search result of its own.
+ *      An array the library built itself (kb_build_psi_phi_*: it allocated it and is its only writer) needs no vouching:
+ *      its copy stands until a library call writes into the array (kb_copy_block_to_gpu, kb_copy_block_between_gpus) or
+ *      frees it -- the canonical frame is made once per array, by its first search, not once per search.
+ * 2048 never reuse a padded copy (every search re-makes it: measurements of the pad pass, tests).
  * 1024 the caller drops every result below params.min_lh afterwards (the reference does, stack_search.cpp:266-270; the
  *      sparse exchange kb_sparsify_compact does): the kernels then need not insert such candidates.  The slots at or
  *      above min_lh are exactly those of the default -- the reference's insertion never lets a smaller likelihood touch
@@ -224,6 +231,13 @@ int kb_device_search_compact(const kb_psi_phi_meta* meta, const void* psi_phi_de
  * descending (stable).  *n_out_host receives the number kept.  Synchronises the stream. */
 int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs,
                            kb_trajectory* out_dev, uint64_t* n_out_host, void* stream);
+
+/* The same, and the validity scan of TrajectoryList::assert_valid (trajectory_list.cpp:155-164, called behind every search:
+ * stack_search.cpp:280) done while the survivors are gathered: *first_invalid_host = the lowest index in out_dev whose
+ * record has a non-finite vx / vy / lh / flux or a negative obs_count (Trajectory::is_valid, common.h), -1 when all are
+ * valid -- 2 M results: one more compare per record on the device instead of a pass over 58 MB on the host. */
+int kb_filter_sort_results_checked(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs,
+                                   kb_trajectory* out_dev, uint64_t* n_out_host, int64_t* first_invalid_host, void* stream);
 
 /* ---- psi/phi curves of result trajectories (StackSearch::get_all_psi_phi_curves,
  * stack_search.cpp:302-318): out_dev is [n][2*T] float32, psi in [0,T), phi in [T,2T), non-finite -> 0.
@@ -352,7 +366,7 @@ typedef struct kb_fits_tile {
 /* RICE_1 streams -> float32 pixels (cfitsio ricecomp.c fits_rdecomp behind astropy's CompImageHDU.data).  tile_len
  * pixels per tile; blocksize / bytepix: the ZVALn of BLOCKSIZE / BYTEPIX (32 / 4 in the reference's files); integers equal
  * to `blank` become NaN when has_blank (ZBLANK).  status_dev[0] = number of tiles whose stream ended before their pixels
- * did (their output is undefined), status_dev[1] = index + 1 of one of them; read it after synchronising.  heap_bytes (at
+ * did or holds a split code beyond FSMAX + 1 (their output is undefined), status_dev[1] = index + 1 of one of them; read it after synchronising.  heap_bytes (at
  * least 8) bounds what is read: the decoder fetches eight bytes at a time and may read past a tile's last byte into its
  * neighbour's, never past heap_dev + heap_bytes; every tile must lie inside the heap (the caller checks its table). */
 int kb_fits_decode_rice(const uint8_t* heap_dev, uint64_t heap_bytes, const kb_fits_tile* tiles_dev, int32_t n_tiles,

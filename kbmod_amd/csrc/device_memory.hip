@@ -142,6 +142,7 @@ int kb_allocate_gpu_block(uint64_t memory_size, void** out_dev) {  // kernel_mem
 
 int kb_free_gpu_block(void* ptr_dev) {  // kernel_memory.cu:105-110
     if (ptr_dev == nullptr) return kb::fail("Trying to free nullptr.");
+    kb::note_array_gone(ptr_dev);  // (a psi/phi array the library built: its padded copy dies with it)
     KB_HIP_TRY(hipFree(ptr_dev));
     return 0;
 }
@@ -149,6 +150,7 @@ int kb_free_gpu_block(void* ptr_dev) {  // kernel_memory.cu:105-110
 int kb_copy_block_to_gpu(const void* src_host, void* dst_dev, uint64_t memory_size) {  // :112-122
     if (src_host == nullptr) return kb::fail("Invalid CPU pointer");
     if (dst_dev == nullptr) return kb::fail("Invalid GPU pointer");
+    kb::note_array_written(dst_dev);
     KB_HIP_TRY(hipMemcpy(dst_dev, src_host, memory_size, hipMemcpyHostToDevice));
     return 0;
 }
@@ -157,6 +159,23 @@ int kb_copy_block_to_cpu(void* dst_host, const void* src_dev, uint64_t memory_si
     if (dst_host == nullptr) return kb::fail("Invalid CPU pointer");
     if (src_dev == nullptr) return kb::fail("Invalid GPU pointer");
     KB_HIP_TRY(hipMemcpy(dst_host, src_dev, memory_size, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// kb_copy_block_to_cpu for large blocks into pageable memory: the destination is page-locked for the duration of the copy
+// (hipHostRegister), so that the transfer is ONE DMA at the link's rate instead of the runtime's staged pageable path
+// (58.7 MB of results: 1.2 ms instead of 3.5); memory that cannot be registered -- or already is -- takes the plain copy.
+int kb_copy_block_to_cpu_locked(void* dst_host, const void* src_dev, uint64_t memory_size) {
+    if (dst_host == nullptr) return kb::fail("Invalid CPU pointer");
+    if (src_dev == nullptr) return kb::fail("Invalid GPU pointer");
+    bool locked = false;
+    if (memory_size >= (4ull << 20)) {
+        locked = hipHostRegister(dst_host, memory_size, hipHostRegisterDefault) == hipSuccess;
+        if (!locked) (void)hipGetLastError();
+    }
+    const hipError_t rc = hipMemcpy(dst_host, src_dev, memory_size, hipMemcpyDeviceToHost);
+    if (locked) (void)hipHostUnregister(dst_host);
+    if (rc != hipSuccess) return kb::fail(std::string("hipMemcpy (device to host) failed: ") + hipGetErrorString(rc));
     return 0;
 }
 
@@ -272,6 +291,7 @@ int kb_copy_block_between_gpus(void* dst_dev, int32_t dst_device, const void* sr
                                uint64_t memory_size) {
     if (dst_dev == nullptr || src_dev == nullptr) return kb::fail("Invalid GPU pointer");
     if (memory_size == 0) return 0;
+    kb::note_array_written(dst_dev);
     if (dst_device == src_device) {
         KB_HIP_TRY(hipMemcpy(dst_dev, src_dev, memory_size, hipMemcpyDeviceToDevice));
     } else {

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void kb_fits_rice_decode_kernel(RiceArgs a) {
         br.refill();
         lastpix = br.take(BBITS);  // the first pixel verbatim
     }
+    bool bad_code = false;
     const int nblk = (a.tile_len + a.blocksize - 1) / a.blocksize;
     const int rows_here = (int)min((int64_t)WAVE, (int64_t)a.n_tiles - tile0);
     float* my_row = patch + lane * PATCH_PITCH;
@@ -153,6 +154,10 @@ __global__ __launch_bounds__(256) void kb_fits_rice_decode_kernel(RiceArgs a) {
         if (decode) {
             br.refill();
             fs_code = br.take(FSBITS);
+            if (fs_code > (uint32_t)FSMAX + 1u) {  // no such split code: a corrupt stream (reported like one that ends early)
+                bad_code = true;
+                fs_code = 0;
+            }
         }
         while (done < n) {
             const int m = min(PATCH_COLS, n - done);
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256) void kb_fits_rice_decode_kernel(RiceArgs a) {
     }
     if (decode) {
         const uint64_t used = (br.bits_used() + 7u) / 8u;
-        if (used > (uint64_t)td.nbytes) {
+        if (used > (uint64_t)td.nbytes || bad_code) {
             atomicAdd(&a.status[0], 1);
             atomicCAS(&a.status[1], 0, (int32_t)(tile + 1));
         }

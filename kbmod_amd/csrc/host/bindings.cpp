@@ -5,6 +5,9 @@
 // image_utils_cpp.cpp:180-194, kernel_helpers.cpp:109-117, debug_timer.cpp:57-69,
 // logging.h:223-237), over numpy buffers instead of Eigen.
 #include <pybind11/numpy.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -56,6 +59,13 @@ PYBIND11_MODULE(search, m) {
     m.attr("HAS_CUDA") = py::bool_(HAVE_HIP_LIB);  // a HIP build: the device path exists (run_search.py:459)
     m.attr("HAS_HIP") = py::bool_(HAVE_HIP_LIB);
     m.attr("HAS_OMP") = py::bool_(HAVE_OMP);
+    m.def("omp_max_threads", []() {
+#ifdef _OPENMP
+        return omp_get_max_threads();
+#else
+        return 1;
+#endif
+    }, "Threads an OpenMP region of the host layer (search_cpu_only, ...) runs with.");
     m.attr("MAX_NUM_IMAGES") = py::int_(MAX_NUM_IMAGES);
     py::enum_<StampType>(m, "StampType")
             .value("STAMP_SUM", StampType::STAMP_SUM)
@@ -685,6 +695,12 @@ PYBIND11_MODULE(search, m) {
                 d["kernel_name"] = std::string(st.kernel_name);
                 d["special_epochs"] = st.special_epochs;
                 d["edge_count_tables"] = st.edge_count_tables;
+                const auto& h = s.last_host_times();
+                d["host_search_ms"] = h.search;
+                d["host_filter_sort_ms"] = h.filter_sort;
+                d["host_download_ms"] = h.download;
+                d["host_validate_ms"] = h.validate;
+                d["host_total_ms"] = h.total;
                 return d;
             },
                  "Measurements of the last device search: kernel and table times (HIP events), evaluations, "

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstring>
 #include <sstream>
+#include <chrono>
 #include <thread>
 
 #include "../search_math.h"
@@ -134,6 +135,11 @@ inline std::vector<float> extract_joint_psi_phi_curve(PsiPhiArray& psi_phi, cons
 
 class StackSearch {
 public:
+    // wall-clock milliseconds of the last search_all on the host: search (tables + kernels), filter + sort in HBM, download of
+    // the survivors, validity scan
+    struct HostTimes {
+        double search = 0, filter_sort = 0, download = 0, validate = 0, total = 0;
+    };
     // stack_search.cpp:37-75
     StackSearch(std::vector<Image>& sci_imgs, std::vector<Image>& var_imgs, std::vector<Image>& psf_kernels,
                 std::vector<double>& zeroed_times_in, int num_bytes = -1)
@@ -353,6 +359,11 @@ public:
         rs_logger->info(logmsg.str());
 
         DebugTimer search_timer = DebugTimer("Running search", rs_logger);
+        using Clock = std::chrono::steady_clock;
+        auto since = [](Clock::time_point t) { return std::chrono::duration<double, std::milli>(Clock::now() - t).count(); };
+        const Clock::time_point t_call = Clock::now();
+        host_ms = HostTimes{};
+        int64_t validated_on_device = -1;  // -1: not checked there; 0: all valid; i + 1: result i is not
         if (on_gpu) {
             detail::require(has_gpu(), "GPU is not available for search.");
             detail::require(psi_phi_array.get_num_times() <= MAX_NUM_IMAGES,
@@ -400,20 +411,30 @@ public:
                 candidate_list.move_to_cpu();
             }
             search_timer.stop();
+            host_ms.search = since(t_call);
+            const Clock::time_point t_filter = Clock::now();
             // stack_search.cpp:266-277 (filter by lh, filter by obs_count, sort by lh) in HBM: only the
             // survivors cross PCIe.
             DebugTimer filter_timer = DebugTimer("Filtering results by LH and min_obs", rs_logger);
             uint64_t n_kept = 0;
-            check_status(kb_filter_sort_results(raw.as<kb_trajectory>(), max_results, params.min_lh, params.min_observations,
-                                                kept.as<kb_trajectory>(), &n_kept, nullptr));
+            int64_t first_invalid = -1;  // (the validity scan of stack_search.cpp:280 rides on the gather of the survivors)
+            check_status(kb_filter_sort_results_checked(raw.as<kb_trajectory>(), max_results, params.min_lh,
+                                                        params.min_observations, kept.as<kb_trajectory>(), &n_kept, &first_invalid,
+                                                        nullptr));
             report_filtering(max_results, n_kept);
             filter_timer.stop();
+            host_ms.filter_sort = since(t_filter);
+            const Clock::time_point t_down = Clock::now();
             rs_logger->info("Clearing all data from GPU.");
-            results.resize(0);
+            // (no resize(0) first: every kept slot is overwritten by the download, and value-initialising 58.7 MB of
+            // trajectories a second time was a millisecond of cfg2's search_all)
             results.resize(n_kept);
             if (n_kept > 0) {
-                check_status(kb_copy_block_to_cpu(results.get_list().data(), kept.ptr, n_kept * sizeof(Trajectory)));
+                check_status(kb_copy_block_to_cpu_locked(results.get_list().data(), kept.ptr, n_kept * sizeof(Trajectory)));
             }
+            blocks.trim();
+            host_ms.download = since(t_down);
+            validated_on_device = first_invalid < 0 ? 0 : first_invalid + 1;
         } else {
             rs_logger->info("Running search on CPU.");
             results.resize(0);
@@ -429,7 +450,16 @@ public:
             results.sort_by_likelihood();
             sort_timer.stop();
         }
-        results.assert_valid();  // trajectory_list.cpp:152 / stack_search.cpp:280
+        const Clock::time_point t_valid = Clock::now();
+        if (!on_gpu || validated_on_device < 0) {
+            results.assert_valid();  // trajectory_list.cpp:152 / stack_search.cpp:280
+        } else if (validated_on_device > 0) {
+            const uint64_t at = (uint64_t)(validated_on_device - 1);
+            throw std::runtime_error("Invalid trajectory detected at index " + std::to_string(at) + ": " +
+                                     results.get_list()[at].to_string());
+        }
+        host_ms.validate = since(t_valid);
+        host_ms.total = since(t_call);
         core_timer.stop();
     }
 
@@ -482,6 +512,7 @@ public:
     }
     // kb_device_search_filter flags (include/kbmod_hip.h): kernel choice, self-check paths.
     void set_search_flags(uint32_t f) { search_flags = f; }
+    const HostTimes& last_host_times() const { return host_ms; }
 
 protected:
     void check_count(const char* what, const char* label, size_t n) const {
@@ -631,23 +662,38 @@ protected:
     logging::Logger* rs_logger;
     kb_search_stats last_stats{};
     uint32_t search_flags = 0;
+    HostTimes host_ms;
     bool resident_searched = false;  // the resident array has been searched on the device since it was (re)loaded
     std::vector<int> search_devices;
     // result buffers of search_all on the home device (raw per-pixel lists, filtered + sorted survivors)
     struct ResultBlocks {
         detail::DeviceBlock raw, kept;
         uint64_t bytes = 0;
+        int device = -1;  // the device the blocks live on: a later search from a thread whose current device differs gets its own
+        // Blocks beyond this are returned once a search's results have reached the host (a 4096 x 4096 search keeps
+        // 2 x 3.8 GB otherwise, which get_gpu_free_memory / validate_gpu would report as taken between searches).
+        static constexpr uint64_t kKeepBytes = 1ull << 30;
         void reserve(uint64_t need) {
-            if (need <= bytes && raw.ptr != nullptr && kept.ptr != nullptr) return;
+            const int now = kb_get_device();
+            if (need <= bytes && raw.ptr != nullptr && kept.ptr != nullptr && device == now) return;
             release();
             check_status(kb_allocate_gpu_block(std::max<uint64_t>(need, 1), &raw.ptr));
             check_status(kb_allocate_gpu_block(std::max<uint64_t>(need, 1), &kept.ptr));
             bytes = need;
+            device = now;
         }
         void release() {
+            const int now = kb_get_device();
+            const bool elsewhere = device >= 0 && now >= 0 && device != now;
+            if (elsewhere) (void)kb_set_device(device);  // a block is freed on the device it was allocated on
             if (raw.ptr != nullptr) (void)kb_free_gpu_block(raw.release());
             if (kept.ptr != nullptr) (void)kb_free_gpu_block(kept.release());
+            if (elsewhere) (void)kb_set_device(now);
             bytes = 0;
+            device = -1;
+        }
+        void trim() {
+            if (bytes > kKeepBytes) release();
         }
     } result_blocks;
     std::vector<Replica> replicas;

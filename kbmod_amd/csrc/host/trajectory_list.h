@@ -113,11 +113,18 @@ public:
 
     void assert_valid() const {  // :155-164
         host_only();
-        for (size_t i = 0; i < cpu_list.size(); ++i) {
-            if (!cpu_list[i].is_valid()) {
-                throw std::runtime_error("Invalid trajectory detected at index " + std::to_string(i) + ": " +
-                                         cpu_list[i].to_string());
-            }
+        // (the scan runs over millions of results behind every search: all cores, the lowest invalid index reported
+        // like the reference's serial loop would)
+        const int64_t n = (int64_t)cpu_list.size();
+        int64_t first_bad = n;
+        // (a small team: waking every hardware thread of a 256-thread host for 2 ms of work costs more than it returns)
+#pragma omp parallel for reduction(min : first_bad) schedule(static) num_threads(8) if (n > (1 << 16))
+        for (int64_t i = 0; i < n; ++i) {
+            if (!cpu_list[i].is_valid() && i < first_bad) first_bad = i;
+        }
+        if (first_bad < n) {
+            throw std::runtime_error("Invalid trajectory detected at index " + std::to_string(first_bad) + ": " +
+                                     cpu_list[first_bad].to_string());
         }
     }
 

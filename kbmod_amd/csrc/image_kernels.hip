@@ -1156,6 +1156,7 @@ static int build_psi_phi(const float* sci_dev, const float* var_dev, const float
     }
     KB_HIP_TRY(hipStreamSynchronize(stream));
     final_guard.p = nullptr;  // ownership passes to the caller
+    note_array_built(final_arr, meta_out->total_array_size);  // (the library's own array: kb_common.h)
     *psi_phi_dev_out = final_arr;
     return 0;
 }

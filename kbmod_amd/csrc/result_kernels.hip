@@ -43,11 +43,21 @@ __global__ __launch_bounds__(256) void kb_extract_keys_kernel(const kb_trajector
     }
 }
 
+// (first_invalid: the lowest output index whose record fails Trajectory::is_valid -- every float field finite, a non-negative
+// count: common.h:82-86, what TrajectoryList::assert_valid walks the list for on the host --, or left alone)
 __global__ __launch_bounds__(256) void kb_gather_kernel(const kb_trajectory* __restrict__ in,
                                                         const uint32_t* __restrict__ idx, uint64_t n,
-                                                        kb_trajectory* __restrict__ out) {
+                                                        kb_trajectory* __restrict__ out,
+                                                        unsigned long long* __restrict__ first_invalid) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = in[idx[i]];
+    if (i >= n) return;
+    const kb_trajectory t = in[idx[i]];
+    out[i] = t;
+    if (first_invalid != nullptr) {
+        const bool ok = __builtin_isfinite(t.vx) && __builtin_isfinite(t.vy) && __builtin_isfinite(t.lh) &&
+                        __builtin_isfinite(t.flux) && t.obs_count >= 0;
+        if (!ok) atomicMin(first_invalid, (unsigned long long)i);
+    }
 }
 
 // psi/phi curves of a list of trajectories (stack_search.cpp:22-39, :302-318): out[i][0..T) = psi,
@@ -348,8 +358,23 @@ void release_result_arenas() {
 }
 }  // namespace kb
 
+namespace kb {
+static int filter_sort_impl(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs, kb_trajectory* out_dev,
+                            uint64_t* n_out_host, int64_t* first_invalid_host, void* stream_v);
+}
 extern "C" int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs,
                                       kb_trajectory* out_dev, uint64_t* n_out_host, void* stream_v) {
+    return kb::filter_sort_impl(results_dev, n, min_lh, min_obs, out_dev, n_out_host, nullptr, stream_v);
+}
+extern "C" int kb_filter_sort_results_checked(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs,
+                                              kb_trajectory* out_dev, uint64_t* n_out_host, int64_t* first_invalid_host,
+                                              void* stream_v) {
+    if (first_invalid_host == nullptr) return kb::fail("filter_sort_results_checked: null index pointer");
+    *first_invalid_host = -1;
+    return kb::filter_sort_impl(results_dev, n, min_lh, min_obs, out_dev, n_out_host, first_invalid_host, stream_v);
+}
+static int kb::filter_sort_impl(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs,
+                                kb_trajectory* out_dev, uint64_t* n_out_host, int64_t* first_invalid_host, void* stream_v) {
     using namespace kb;
     KB_REQUIRE_DEVICE("the result filter.");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
@@ -395,11 +420,30 @@ extern "C" int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t
     const unsigned blocks = (unsigned)((kept + 255) / 256);
     hipLaunchKernelGGL(kb_extract_keys_kernel, dim3(blocks), dim3(256), 0, stream, compact, (uint64_t)kept, keys_in, idx_in);
     KB_HIP_TRY(hipGetLastError());
-    size_t sort_bytes = tmp2_bytes;  // (sized for n >= kept records)
+    // rocprim picks its sort (block / merge / onesweep) by the element count and each lays out its own temporary storage:
+    // ask again for `kept` elements -- a host-only call -- instead of assuming the size for n covers every smaller count
+    size_t sort_bytes = 0;
+    KB_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, sort_bytes, static_cast<float*>(nullptr), static_cast<float*>(nullptr),
+                                              static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), kept, 0, 32,
+                                              stream));
+    if (sort_bytes > tmp_all) return fail("filter_sort_results: sorting " + std::to_string(kept) + " records needs more temporary storage (" +
+                                          std::to_string(sort_bytes) + " bytes) than sorting all " + std::to_string(n));
     KB_HIP_TRY(rocprim::radix_sort_pairs_desc(tmp, sort_bytes, keys_in, keys_out, idx_in, idx_out, kept, 0, 32, stream));
     // ---- 3. gather the 28-byte records in sorted order ----
-    hipLaunchKernelGGL(kb_gather_kernel, dim3(blocks), dim3(256), 0, stream, compact, idx_out, (uint64_t)kept, out_dev);
+    unsigned long long* bad_dev = nullptr;
+    if (first_invalid_host != nullptr) {
+        bad_dev = reinterpret_cast<unsigned long long*>(base + rec_bytes + 64);  // (behind the survivor count)
+        KB_HIP_TRY(hipMemsetAsync(bad_dev, 0xff, sizeof(unsigned long long), stream));
+    }
+    hipLaunchKernelGGL(kb_gather_kernel, dim3(blocks), dim3(256), 0, stream, compact, idx_out, (uint64_t)kept, out_dev, bad_dev);
     KB_HIP_TRY(hipGetLastError());
+    if (first_invalid_host != nullptr) {
+        unsigned long long bad = ~0ull;
+        KB_HIP_TRY(hipMemcpyAsync(&bad, bad_dev, sizeof(bad), hipMemcpyDeviceToHost, stream));
+        KB_HIP_TRY(hipStreamSynchronize(stream));
+        *first_invalid_host = bad == ~0ull ? -1 : (int64_t)bad;
+        return 0;
+    }
     KB_HIP_TRY(hipStreamSynchronize(stream));
     return 0;
 }

@@ -557,6 +557,58 @@ struct PaddedKey {
 };
 static PaddedKey g_padded_key[MAX_DEVICES];
 
+// ---- arrays built (hence owned) by the library: kb_common.h ----
+struct OwnedArray {
+    const char* ptr;
+    uint64_t bytes;
+};
+static std::mutex g_owned_mutex;
+static std::vector<OwnedArray> g_owned;
+static void forget_padded_copies_of(const char* lo, const char* hi) {  // (g_owned_mutex held)
+    for (int dev = 0; dev < MAX_DEVICES; ++dev) {
+        const char* src = static_cast<const char*>(g_padded_key[dev].src);
+        // (no device lock: a search of that very array cannot be running while it is rebuilt, written or freed)
+        if (g_padded_key[dev].valid && src >= lo && src < hi) g_padded_key[dev].valid = false;
+    }
+}
+void note_array_built(const void* p, uint64_t bytes) {
+    std::lock_guard<std::mutex> lock(g_owned_mutex);
+    const char* c = static_cast<const char*>(p);
+    forget_padded_copies_of(c, c + bytes);
+    for (OwnedArray& o : g_owned) {
+        if (o.ptr == c) {
+            o.bytes = bytes;
+            return;
+        }
+    }
+    g_owned.push_back(OwnedArray{c, bytes});
+}
+void note_array_written(const void* p) {
+    std::lock_guard<std::mutex> lock(g_owned_mutex);
+    const char* c = static_cast<const char*>(p);
+    for (const OwnedArray& o : g_owned) {
+        if (c >= o.ptr && c < o.ptr + o.bytes) forget_padded_copies_of(o.ptr, o.ptr + o.bytes);
+    }
+}
+void note_array_gone(const void* p) {
+    std::lock_guard<std::mutex> lock(g_owned_mutex);
+    const char* c = static_cast<const char*>(p);
+    for (size_t i = 0; i < g_owned.size(); ++i) {
+        if (g_owned[i].ptr == c) {
+            forget_padded_copies_of(c, c + g_owned[i].bytes);
+            g_owned.erase(g_owned.begin() + (long)i);
+            return;
+        }
+    }
+}
+bool array_is_library_owned(const void* p) {
+    std::lock_guard<std::mutex> lock(g_owned_mutex);
+    for (const OwnedArray& o : g_owned) {
+        if (o.ptr == static_cast<const char*>(p)) return true;
+    }
+    return false;
+}
+
 static int current_device_slot() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -806,7 +858,10 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     int which = 0;
     int padded_reused = 0;
     uint64_t padded_copy_bytes = 0;
-    const bool want_lds = (flags & 2u) == 0 && (flags & 1u) == 0 && a.K <= 32 &&
+    // (the offset tables of the hand-scheduled instances are indexed with 32-bit byte offsets: a candidate list x epochs beyond
+    // that goes to kb_search_direct, which reads none of them, instead of failing)
+    const bool fold_fits = ((uint64_t)n_cands + 2 * WIDE_CHUNK) * (uint64_t)a.T * sizeof(int) <= 0x7fff0000ull;
+    const bool want_lds = (flags & 2u) == 0 && (flags & 1u) == 0 && a.K <= 32 && fold_fits &&
                           (n_cands >= 8 || (flags & 4u) != 0);
     // Candidates per chunk.  WIDE_CHUNK for the two instances of kb_search_lds built for it -- float staging; lists of up to
     // 8 as packed records in registers, or none (the in-search sigma-G filter) -- when everything known before the tables
@@ -833,13 +888,13 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         const size_t off_bytes = ((size_t)a.n_chunks * a.T * a.chunk + 4 * a.chunk) * sizeof(int);  // + prefetch slack
         const size_t box_bytes = (size_t)a.n_chunks * a.T * sizeof(EpochBox);
         const size_t org_bytes = ((size_t)a.n_chunks * a.T + SLAB_REF_SLACK) * sizeof(SlabRef);
-        const size_t fold_bytes = ((size_t)a.n_chunks * a.T + SLAB_REF_SLACK) * a.chunk * sizeof(int);
+        const size_t fold_bytes = want_lds ? ((size_t)a.n_chunks * a.T + SLAB_REF_SLACK) * a.chunk * sizeof(int) : 0;  // (read by kb_search_lds only)
         const size_t chunk_bytes = (size_t)a.n_chunks * sizeof(ChunkInfo);
         // NO_DATA pixel counter [1], unstaged (chunk, epoch) counter [1], staged shift box + tallest slab [5],
         // per-lane (chunk, epoch) counter [1]
         const size_t inv_bytes = 8 * sizeof(int);
         void* ws = nullptr;
-        if (fold_bytes > 0x7fff0000ull) return fail("deviceSearchFilter: candidate list x epochs too long for the offset tables");
+        if (fold_bytes > 0x7fffff00ull) return fail("deviceSearchFilter: candidate list x epochs too long for the offset tables");
         if (ensure_workspace(0, table_bytes + off_bytes + box_bytes + chunk_bytes + inv_bytes + org_bytes + fold_bytes + 64, &ws)) return 1;
         char* wsc = reinterpret_cast<char*>(ws);
         a.table = reinterpret_cast<const int2*>(wsc);
@@ -983,8 +1038,12 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                     key.py0 = py0;
                     key.valid = true;
                     PaddedKey& have_key = g_padded_key[current_device_slot()];
-                    if ((flags & 256u) != 0 && have_key.same(key)) {
-                        padded_reused = 1;  // the caller vouches for the array: the copy (and its counter) stand
+                    // The copy (and its NO_DATA counter) of the previous search stands when nothing that determines it has
+                    // changed and the array is known to be the same bits: the caller vouches for it (flag 256), or the library
+                    // built the array itself and no library call has written into it since (kb_common.h).  Flag 2048: never.
+                    const bool unchanged = (flags & 256u) != 0 || array_is_library_owned(psi_phi_dev);
+                    if (unchanged && (flags & 2048u) == 0 && have_key.same(key)) {
+                        padded_reused = 1;
                     } else {
                         have_key.valid = false;
                         KB_HIP_TRY(hipMemsetAsync(n_invalid, 0, sizeof(int), stream));

@@ -137,7 +137,7 @@ _TFORM_BYTES = {"L": 1, "X": 1, "B": 1, "I": 2, "J": 4, "K": 8, "A": 1, "E": 4, 
 
 
 def table_columns(header):
-    """{column name: (byte offset within a row, type code, repeat)} of a BINTABLE header."""
+    """{column name: (byte offset within a row, type code, repeat, heap element type of a P / Q column)} of a BINTABLE header."""
     cols, off = {}, 0
     for c in range(1, int(header["TFIELDS"]) + 1):
         form = str(header[f"TFORM{c}"]).strip()
@@ -148,7 +148,9 @@ def table_columns(header):
         code = form[k]
         if code not in _TFORM_BYTES:
             raise ValueError(f"unknown TFORM{c} = {form!r}")
-        cols[str(header.get(f"TTYPE{c}", f"COL{c}")).strip().upper()] = (off, code, repeat)
+        # (variable-length columns, rPt / rQt: the letter behind the descriptor code names the heap elements)
+        elem = form[k + 1] if code in "PQ" and k + 1 < len(form) else ""
+        cols[str(header.get(f"TTYPE{c}", f"COL{c}")).strip().upper()] = (off, code, repeat, elem)
         off += (-(-repeat // 8) if code == "X" else repeat * _TFORM_BYTES[code])
     if off != int(header["NAXIS1"]):
         raise ValueError(f"table columns add up to {off} bytes per row, NAXIS1 says {header['NAXIS1']}")
@@ -196,6 +198,14 @@ class CompressedLayout:
         self.columns = table_columns(h)
         if "COMPRESSED_DATA" not in self.columns or self.columns["COMPRESSED_DATA"][1] != "P":
             raise ValueError(f"HDU {name}: no COMPRESSED_DATA column of 32-bit array descriptors")
+        # a descriptor counts heap ELEMENTS: bytes for the 1PB cfitsio / astropy write, 2 or 4 bytes each for 1PI / 1PJ
+        self.heap_elem_bytes = {}
+        for col in ("COMPRESSED_DATA", "GZIP_COMPRESSED_DATA"):
+            if col in self.columns:
+                elem = self.columns[col][3]
+                if elem not in ("B", "I", "J"):
+                    raise ValueError(f"HDU {name}: {col} is a column of {elem!r} elements (expected 1PB, 1PI or 1PJ)")
+                self.heap_elem_bytes[col] = {"B": 1, "I": 2, "J": 4}[elem]
         self.bscale, self.bzero = float(h.get("BSCALE", 1.0)), float(h.get("BZERO", 0.0))
         self.zscale_key, self.zzero_key = h.get("ZSCALE"), h.get("ZZERO")
         self.blank = h.get("ZBLANK", h.get("BLANK") if not self.quantized else None)
@@ -214,7 +224,7 @@ class CompressedLayout:
 
         desc = column("COMPRESSED_DATA", ">i4", 8)
         t = np.zeros(self.n_rows, dtype=TILE_DTYPE)
-        t["nbytes"] = desc[:, 0] * 1  # (P descriptors of B arrays: the count is in bytes)
+        t["nbytes"] = desc[:, 0] * self.heap_elem_bytes["COMPRESSED_DATA"]  # (the descriptor counts elements)
         t["offset"] = base + self.theap + desc[:, 1].astype(np.int64)
         t["out_index"] = out_index0 + np.arange(self.n_rows, dtype=np.uint64) * np.uint64(self.width)
         t["mode"] = TILE_RICE
@@ -233,7 +243,7 @@ class CompressedLayout:
                 raise ValueError(f"HDU {hdu.name}: empty tiles and no GZIP_COMPRESSED_DATA column")
             gz = column("GZIP_COMPRESSED_DATA", ">i4", 8)
             for r in empty:
-                n, ho = int(gz[r, 0]), int(gz[r, 1])
+                n, ho = int(gz[r, 0]) * self.heap_elem_bytes["GZIP_COMPRESSED_DATA"], int(gz[r, 1])
                 if n == 0:
                     raise ValueError(f"HDU {hdu.name}: tile {int(r)} holds no data")
                 start = base + self.theap + ho

@@ -137,3 +137,52 @@ def test_empty_footprint_is_zero_equals_the_oracle_device_flavour(kb, orc):
         exp = np.array([[[pp.read(t, r, c) for c in range(W)] for r in range(H)] for t in range(T)], dtype=np.float32)
         assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), flavour
     assert got[0, 5, 5, 0] == 0.0  # (the device flavour writes 0 there, the CPU flavour NaN)
+
+
+def test_padded_copy_of_a_library_built_array_is_made_once(kb, orc):
+    """An array kb_build_psi_phi_* built is the library's own: the padded canonical copy its first search makes stands for the
+    following searches without the caller's flag 256 -- until a library call writes into the array, the array is freed (and
+    another takes its address), or flag 2048 asks for a fresh copy.  Results never change, only whether the pad pass ran."""
+    import ctypes as C
+
+    import torch
+
+    from kbmod_amd import capi
+
+    st = util.make_stack(16, 70, 130, seed=77, objects=[(20, 30, 15.0, 6.0, 300.0)], mask_fraction=0.01, times=np.arange(16) / 16.0)
+    vx, vy = fd.kbmod_v1_candidates(8, 5.0, 20.0, 8, 0.0, 0.5)
+    d = util.DeviceStack(st)
+    cands = d.candidates(vx, vy)
+    p = d.params(K=8)
+    first, s1 = d.search(p, cands, 4)
+    again, s2 = d.search(p, cands, 4)
+    fresh, s3 = d.search(p, cands, 4 | 2048)
+    assert (s1.padded_copy_reused, s2.padded_copy_reused, s3.padded_copy_reused) == (0, 1, 0)
+    assert torch.equal(first, again) and torch.equal(first, fresh)
+    # another geometry (start bounds that move the frame): a new copy, then kept again
+    p2 = d.params(K=8, xb=(-12, 100), yb=(3, 60))
+    _, s4 = d.search(p2, cands, 4)
+    _, s5 = d.search(p2, cands, 4)
+    assert (s4.padded_copy_reused, s5.padded_copy_reused) == (0, 1)
+    # a library call writes into the array: a bright trajectory-long streak at row 40 -- the next search must see it
+    T, H, W = d.T, d.H, d.W
+    host = np.empty((T, H, W, 2), dtype=np.float32)
+    capi.check(d.lib.kb_copy_block_to_cpu(host.ctypes.data, d.arr, host.nbytes))
+    host[:, 40, 50, 0] += 500.0
+    _, s6 = d.search(p, cands, 4)
+    assert s6.padded_copy_reused == 0      # (the geometry changed back)
+    _, s7 = d.search(p, cands, 4)
+    assert s7.padded_copy_reused == 1
+    capi.check(d.lib.kb_copy_block_to_gpu(host.ctypes.data, d.arr, host.nbytes))
+    changed, s8 = d.search(p, cands, 4)
+    assert s8.padded_copy_reused == 0 and not torch.equal(changed, first)
+    direct, _ = d.search(p, cands, 2)      # kb_search_direct reads the array itself
+    assert torch.equal(changed, direct)
+    # freed and rebuilt (most likely at the same address): nothing of the old array's copy is taken over
+    d.close()
+    st2 = util.make_stack(16, 70, 130, seed=78, objects=[(60, 20, -9.0, 12.0, 300.0)], times=np.arange(16) / 16.0)
+    d2 = util.DeviceStack(st2)
+    one, s9 = d2.search(p, cands, 4)
+    two, _ = d2.search(p, cands, 2)
+    assert s9.padded_copy_reused == 0 and torch.equal(one, two)
+    d2.close()

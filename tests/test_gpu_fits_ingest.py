@@ -341,3 +341,44 @@ def test_fuzz_written_workunits(fi, tmp_path, seed):
     wu = fi.load_workunit(str(path))
     check_against_oracle(wu, data)
     assert tuple(wu.sci.shape) == (T, H, W)
+
+
+def test_corrupt_split_code_is_reported(fi):
+    """A RICE block whose 5-bit split code exceeds FSMAX + 1 = 26 does not exist in a valid stream: the tile is flagged through
+    status_dev (the host raises), not decoded into garbage."""
+    import torch
+
+    lib = fi._lib()
+    W = 32
+    good = fd.rice_encode(np.arange(W), 32, 4, None)
+    bad = bytearray(good)
+    bad[4] |= 0xF8  # the five bits behind the first pixel: split code 31
+    heap = bytes(good) + bytes(bad) + bytes(8)
+    tiles = np.zeros(2, dtype=fi.TILE_DTYPE)
+    tiles[0] = (0, 0, 1.0, 0.0, len(good), fi.TILE_RICE)
+    tiles[1] = (len(good), W, 1.0, 0.0, len(bad), fi.TILE_RICE)
+    heap_dev = torch.from_numpy(np.frombuffer(heap, dtype=np.uint8).copy()).cuda()
+    tiles_dev = torch.from_numpy(tiles.view(np.uint8).reshape(-1).copy()).cuda()
+    out = torch.zeros(2 * W, dtype=torch.float32, device="cuda")
+    status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    rc = lib.kb_fits_decode_rice(heap_dev.data_ptr(), len(heap), tiles_dev.data_ptr(), 2, W, 32, 4, 0, 0, 0, out.data_ptr(),
+                                 status.data_ptr(), None)
+    assert rc == 0, lib.kb_last_error()
+    torch.cuda.synchronize()
+    assert status.cpu().tolist() == [1, 2]
+    assert np.array_equal(out.cpu().numpy()[:W], np.arange(W, dtype=np.float32))
+
+
+def test_heap_element_type_of_the_descriptor_column(fi, tmp_path):
+    """COMPRESSED_DATA descriptors count heap ELEMENTS: 1PB (what cfitsio / astropy write) is bytes; anything but B / I / J
+    is refused by name instead of being read as bytes."""
+    img = np.random.default_rng(3).normal(0, 2, (20, 40)).astype(np.float32)
+    sci, _ = fd.write_compressed_hdu("SCI_0", img, extra=[("MJD", 1.0)])
+    var, _ = fd.write_compressed_hdu("VAR_0", np.full((20, 40), 4.0, np.float32))
+    head = fd._header_bytes([fd._card("SIMPLE", True), fd._card("BITPIX", 8), fd._card("NAXIS", 0), fd._card("NUMIMG", 1)])
+    data = head + sci + var
+    assert data.count(b"'1PB") >= 2
+    path = tmp_path / "pe.fits"
+    path.write_bytes(data.replace(b"'1PB", b"'1PE", 1))
+    with pytest.raises(ValueError, match="column of 'E' elements"):
+        fi.load_workunit(str(path))

@@ -69,3 +69,47 @@ def test_on_search_results(cg, kb):
     res, idx = cg.apply_trajectory_grid_filter(trjs, 5, float(st.zeroed_times[-1]))
     assert idx == _oracle(trjs, 5, float(st.zeroed_times[-1])) and 0 < len(idx) < len(trjs)
     assert idx[0] == 0  # the list is sorted by likelihood: its head always survives
+
+
+def test_filter_sort_results_checked_through_the_c_abi():
+    """kb_filter_sort_results / _checked on a crafted result buffer: survivors of (lh >= min_lh, obs >= min_obs) in stable
+    descending likelihood order (stack_search.cpp:266-277, trajectory_list.cpp:96-126) and the lowest index of a record that
+    fails Trajectory::is_valid (the scan of trajectory_list.cpp:155-164), -1 when there is none."""
+    import ctypes as C
+
+    import torch
+
+    from kbmod_amd import capi
+
+    lib = capi.load_lib()
+    lib.kb_filter_sort_results.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+    lib.kb_filter_sort_results_checked.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_uint64),
+                                                   C.POINTER(C.c_int64), C.c_void_p]
+    dt = np.dtype([("vx", "<f4"), ("vy", "<f4"), ("lh", "<f4"), ("flux", "<f4"), ("x", "<i4"), ("y", "<i4"), ("obs", "<i4")])
+    rng = np.random.default_rng(5)
+    for n in (1, 1000, 300_000):
+        rec = np.zeros(n, dtype=dt)
+        rec["lh"] = np.round(rng.normal(5, 3, n), 1)     # many equal likelihoods: the sort must be stable
+        rec["obs"] = rng.integers(0, 20, n)
+        rec["x"] = np.arange(n)
+        rec["flux"] = rng.normal(0, 1, n)
+        keep = ~(rec["lh"] < np.float32(4.0)) & ~(rec["obs"] < 5)
+        want = rec[keep][np.argsort(-rec["lh"][keep], kind="stable")]
+        d = torch.from_numpy(rec.view(np.uint8)).cuda()
+        out = torch.zeros_like(d)
+        cnt, bad = C.c_uint64(0), C.c_int64(7)
+        capi.check(lib.kb_filter_sort_results(d.data_ptr(), n, 4.0, 5, out.data_ptr(), C.byref(cnt), None))
+        assert cnt.value == len(want) and out.cpu().numpy().view(dt)[:len(want)].tobytes() == want.tobytes()
+        out.zero_()
+        capi.check(lib.kb_filter_sort_results_checked(d.data_ptr(), n, 4.0, 5, out.data_ptr(), C.byref(cnt), C.byref(bad), None))
+        assert cnt.value == len(want) and bad.value == -1
+        assert out.cpu().numpy().view(dt)[:len(want)].tobytes() == want.tobytes()
+        if len(want) > 10:
+            # an infinite flux and (further down the sorted list) a negative count: the first one in OUTPUT order is reported
+            i_a, i_b = int(want["x"][len(want) // 3]), int(want["x"][len(want) // 2])
+            rec2 = rec.copy()
+            rec2["flux"][i_a] = np.inf
+            rec2["vx"][i_b] = np.nan
+            d2 = torch.from_numpy(rec2.view(np.uint8)).cuda()
+            capi.check(lib.kb_filter_sort_results_checked(d2.data_ptr(), n, 4.0, 5, out.data_ptr(), C.byref(cnt), C.byref(bad), None))
+            assert bad.value == len(want) // 3 and cnt.value == len(want)

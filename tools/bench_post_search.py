@@ -175,7 +175,50 @@ def bench_grid_filter(n=2_000_000):
                       "equals_oracle_on_sample": same}))
 
 
+def bench_filter_sort(n=2_097_152, keep_fraction=1.0):
+    """kb_filter_sort_results (stack_search.cpp:266-281 in HBM) on n result slots: select + radix sort of (lh, index) + gather.
+    Algorithmic bytes: 28 read + 28 written per kept record, 28 read per dropped one."""
+    import torch
+
+    from bench import check, load_lib
+
+    lib = load_lib()
+    lib.kb_filter_sort_results.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+    rng = np.random.default_rng(9)
+    rec = np.zeros(n, dtype=[("vx", "f4"), ("vy", "f4"), ("lh", "f4"), ("flux", "f4"), ("x", "i4"), ("y", "i4"), ("obs", "i4")])
+    rec["lh"] = rng.normal(5, 3, n)
+    rec["obs"] = 64
+    min_lh = float(np.quantile(rec["lh"], 1.0 - keep_fraction)) if keep_fraction < 1.0 else -1.0e30
+    dev = torch.device("cuda", 0)
+    d = torch.from_numpy(rec.view(np.uint8)).to(dev)
+    out = torch.empty_like(d)
+    cnt = C.c_uint64(0)
+
+    def step():
+        check(lib, lib.kb_filter_sort_results(d.data_ptr(), n, min_lh, 0, out.data_ptr(), C.byref(cnt), None))
+
+    step()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(5):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / 5
+    kept = int(cnt.value)
+    got = out.cpu().numpy().view(rec.dtype)[:kept]
+    order = np.argsort(-rec["lh"][rec["lh"] >= min_lh], kind="stable")
+    same = bool(np.array_equal(got["lh"], rec["lh"][rec["lh"] >= min_lh][order]))
+    alg = n * 28 + kept * 28
+    print(json.dumps({"kernel": "kb_filter_sort_results (select + radix sort + gather)", "slots": n, "kept": kept, "ms": ms,
+                      "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                   "frac": alg / (ms * 1e-3) / 1e9 / 8000.0, "frac_of_achievable": alg / (ms * 1e-3) / 1e9 / 6300.0},
+                      "sorted_like_numpy_stable": same}))
+
+
 if __name__ == "__main__":
     main()
     bench_coadds()
     bench_grid_filter()
+    bench_filter_sort()
+    bench_filter_sort(keep_fraction=0.02)

@@ -27,7 +27,7 @@ def main(paths):
         print("| kernel | counter | dispatches | avg | min | max |")
         print("|---|---|---|---|---|---|")
         q = ("select kernel_name, counter_name, count(*), avg(value), min(value), max(value) "
-             "from counters_collection where kernel_name like '%kb::%' group by kernel_name, counter_name")
+             "from counters_collection where (kernel_name like '%kb::%' or kernel_name like '%rocprim%') group by kernel_name, counter_name")
         for k, c, n, a, lo, hi in con.execute(q):
             print(f"| `{short(k)}` | {c} | {n} | {a:.6g} | {lo:.6g} | {hi:.6g} |")
 

@@ -23,4 +23,7 @@ for min_lh in (0.0, 10.0):
         s.search_all(cands, True)
         t1 = time.perf_counter()
         n = s.get_number_total_results()
-        print(f"min_lh {min_lh}: search_all {1e3 * (t1 - t0):.2f} ms, {n} results kept, kernel {s.last_search_stats()['search_kernel_ms']:.2f} ms")
+        st = s.last_search_stats()
+        print(f"min_lh {min_lh}: search_all {1e3 * (t1 - t0):.2f} ms, {n} results kept, kernel {st['search_kernel_ms']:.2f} ms; inside the call: "
+              f"search {st['host_search_ms']:.2f} + filter/sort {st['host_filter_sort_ms']:.2f} + download {st['host_download_ms']:.2f} + "
+              f"validity scan {st['host_validate_ms']:.2f} = {st['host_total_ms']:.2f} ms")
