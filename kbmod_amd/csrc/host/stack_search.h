@@ -589,7 +589,15 @@ protected:
             if (d != home) (void)replica_on(d, home);
         }
         check_status(kb_set_device(home));
-        detail::DeviceBlock gathered((uint64_t)n_parts * part_results * sizeof(kb_compact_result));
+        // What travels to the home device.  Tie-exact lists go in their sparse form (kb_sparsify_compact: one count byte per
+        // pixel + the records search_all's post-filter would keep, a few MB instead of S x 2K x 16 bytes per device for a
+        // search with a likelihood threshold); lists of 17 .. 32 as they are.
+        const uint64_t n_pixels = max_results / params.results_per_pixel;
+        const uint64_t header_bytes = kb_sparse_header_bytes(n_pixels);
+        detail::DeviceBlock gathered(exact ? 1 : (uint64_t)n_parts * part_results * sizeof(kb_compact_result));
+        detail::DeviceBlock headers(exact ? (uint64_t)n_parts * header_bytes : 1);
+        std::vector<detail::DeviceBlock> packed_home(n_parts);  // (sized by what each part keeps)
+        std::vector<const kb_compact_result*> packed_ptrs(n_parts, nullptr);
         detail::DeviceBlock all_cands(n * sizeof(Trajectory));
         check_status(kb_copy_block_to_gpu(cands.data(), all_cands.ptr, n * sizeof(Trajectory)));
 
@@ -619,8 +627,36 @@ protected:
                 // (the stats path returns without a final stream synchronisation: a fault inside the kernels must
                 // surface here, on the device it happened on, not in a later call)
                 check_status(kb_device_synchronize());
-                check_status(kb_copy_block_between_gpus(gathered.as<kb_compact_result>() + (uint64_t)part * part_results, home,
-                                                        records.ptr, device, part_results * sizeof(kb_compact_result)));
+                if (exact) {
+                    detail::DeviceBlock header(header_bytes);
+                    uint64_t kept = 0, room = std::max<uint64_t>(1024, part_results / 16);
+                    detail::DeviceBlock packed(room * sizeof(kb_compact_result));
+                    int rc = kb_sparsify_compact(records.as<const kb_compact_result>(), n_pixels,
+                                                 (int32_t)part_params.results_per_pixel, params.min_lh, header.as<uint8_t>(),
+                                                 packed.as<kb_compact_result>(), room, &kept, nullptr);
+                    if (rc != 0 && kept > room) {  // more survivors than guessed: the count is known now
+                        detail::DeviceBlock larger(kept * sizeof(kb_compact_result));
+                        std::swap(packed.ptr, larger.ptr);
+                        room = kept;
+                        rc = kb_sparsify_compact(records.as<const kb_compact_result>(), n_pixels,
+                                                 (int32_t)part_params.results_per_pixel, params.min_lh, header.as<uint8_t>(),
+                                                 packed.as<kb_compact_result>(), room, &kept, nullptr);
+                    }
+                    check_status(rc);
+                    check_status(kb_copy_block_between_gpus(headers.as<uint8_t>() + (uint64_t)part * header_bytes, home, header.ptr,
+                                                            device, header_bytes));
+                    if (kept > 0) {
+                        check_status(kb_set_device(home));
+                        detail::DeviceBlock at_home(kept * sizeof(kb_compact_result));
+                        check_status(kb_set_device(device));
+                        check_status(kb_copy_block_between_gpus(at_home.ptr, home, packed.ptr, device, kept * sizeof(kb_compact_result)));
+                        std::swap(packed_home[part].ptr, at_home.ptr);
+                        packed_ptrs[part] = packed_home[part].as<const kb_compact_result>();
+                    }
+                } else {
+                    check_status(kb_copy_block_between_gpus(gathered.as<kb_compact_result>() + (uint64_t)part * part_results, home,
+                                                            records.ptr, device, part_results * sizeof(kb_compact_result)));
+                }
             } catch (const std::exception& e) {
                 errors[part] = e.what();
             }
@@ -632,9 +668,9 @@ protected:
         check_status(kb_set_device(home));
         for (const std::string& e : errors) detail::require(e.empty(), e);
         if (exact) {
-            check_status(kb_merge_compact_exact(gathered.as<const kb_compact_result>(), n_parts,
-                                                (int32_t)part_params.results_per_pixel, params,
-                                                all_cands.as<const kb_trajectory>(), n, merged, nullptr));
+            check_status(kb_merge_sparse_exact(headers.as<const uint8_t>(), header_bytes, packed_ptrs.data(), n_parts,
+                                               (int32_t)part_params.results_per_pixel, params,
+                                               all_cands.as<const kb_trajectory>(), n, merged, nullptr));
         } else {
             check_status(kb_merge_compact(gathered.as<const kb_compact_result>(), n_parts, params,
                                           all_cands.as<const kb_trajectory>(), n, merged, nullptr));
