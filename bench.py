@@ -492,6 +492,7 @@ def main():
                            if int(last.edge_count_tables) and args.mask_fraction == 0.0 else "counted per sample where NO_DATA can occur"),
             "padded_copy": ("kept from the first search of this array (the library built the array and nothing has written into it)"
                             if int(last.padded_copy_reused) else "made by this search (decode-and-pad pass inside the step)"),
+            "env_overrides": int(last.env_overrides),   # KBMOD_* switches set in this process (0: none; include/kbmod_hip.h)
             "kernel_evals_per_s": evals_per_step_rank / (k_ms * 1e-3),
             "frac_algorithmic": alg_rate / HBM_PEAK_GBPS,
             "algorithmic_bytes_per_launch": int(last.algorithmic_bytes),

@@ -73,7 +73,9 @@ typedef struct kb_search_stats {
                                      inside the guard band of a rounding boundary -- instead of by the uniform loops */
     int32_t edge_count_tables;    /* kb_search_lds: tables of epochs per shift were built, so that tiles at the image's edge of a
                                      stack without NO_DATA pixels take their observation counts from them instead of counting samples */
-    int32_t reserved0;
+    int32_t env_overrides;        /* bit i: environment switch i was set while this search chose its kernels (they exist for tests
+                                     and comparisons and change the kernel instance, never the result): 0 KBMOD_CHUNK, 1 KBMOD_LIST_MODE,
+                                     2 KBMOD_EDGE_COUNTS, 3 KBMOD_UNSTAGED_LIMIT, 4 KBMOD_SIGMAG_CAP, 5 KBMOD_DEBUG */
 } kb_search_stats;
 
 const char* kb_last_error(void);

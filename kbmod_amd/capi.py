@@ -32,7 +32,7 @@ class Stats(C.Structure):
                 ("algorithmic_bytes", C.c_uint64), ("kernel_variant", C.c_int32), ("num_search_launches", C.c_int32),
                 ("sigmag_work_items", C.c_uint64), ("sigmag_trajectories", C.c_uint64), ("lds_read_bytes", C.c_uint64),
                 ("sigmag_literal", C.c_uint64), ("kernel_name", C.c_char * 96), ("padded_copy_reused", C.c_int32),
-                ("special_epochs", C.c_int32), ("edge_count_tables", C.c_int32), ("reserved0", C.c_int32)]
+                ("special_epochs", C.c_int32), ("edge_count_tables", C.c_int32), ("env_overrides", C.c_int32)]
 
 
 def lib_path():

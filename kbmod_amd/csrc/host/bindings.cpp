@@ -695,6 +695,7 @@ PYBIND11_MODULE(search, m) {
                 d["kernel_name"] = std::string(st.kernel_name);
                 d["special_epochs"] = st.special_epochs;
                 d["edge_count_tables"] = st.edge_count_tables;
+                d["env_overrides"] = st.env_overrides;
                 const auto& h = s.last_host_times();
                 d["host_search_ms"] = h.search;
                 d["host_filter_sort_ms"] = h.filter_sort;

@@ -1269,7 +1269,11 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         stats_out->padded_copy_reused = padded_reused;
         stats_out->special_epochs = which != 0 ? special_epochs : 0;
         stats_out->edge_count_tables = edge_tables;
-        stats_out->reserved0 = 0;
+        // the environment switches (tests, comparisons) that were set while this search chose its kernels: never silent
+        static const char* const kSwitches[] = {"KBMOD_CHUNK", "KBMOD_LIST_MODE", "KBMOD_EDGE_COUNTS", "KBMOD_UNSTAGED_LIMIT",
+                                                "KBMOD_SIGMAG_CAP", "KBMOD_DEBUG"};
+        stats_out->env_overrides = 0;
+        for (int i = 0; i < 6; ++i) stats_out->env_overrides |= std::getenv(kSwitches[i]) != nullptr ? (1 << i) : 0;
         if (cold.sg.totals != nullptr) {
             unsigned long long totals[3] = {0, 0, 0};
             KB_HIP_TRY(hipMemcpyAsync(totals, cold.sg.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));

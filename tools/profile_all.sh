@@ -18,3 +18,24 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_fits; rocprofv3 --pmc $C -d /tmp/pmc_fits -o r -- python tools/fits_ingest_timing.py > /dev/null 2>&1
   python tools/rocprof_summary.py /tmp/pmc_fits/r_results.db /tmp/pmc_fits/r_results.db | grep -E "kb_fits|counter \||---\|---\|---\|---\|---\|---" > gpurun_out/${R}_fits_pmc_$C.md
 done
+# round 4 additions: the multi-GPU exchange budget measured on this one GPU (cfg4 and cfg2 with a likelihood threshold), the
+# RCCL path at world size 1, the issue model, the post-search kernels, StackSearch.search_all end to end, other configurations
+python tools/exchange_budget.py --dense > gpurun_out/${R}_exchange_budget_cfg4.json 2>/dev/null
+python tools/exchange_budget.py --rank-flags 0 > gpurun_out/${R}_exchange_budget_cfg4_nofloor.json 2>/dev/null
+python tools/exchange_budget.py --frames 64 --size 512 --vel-steps 32 --ang-steps 32 --dense > gpurun_out/${R}_exchange_budget_cfg2_lh10.json 2>/dev/null
+KBMOD_FORCE_DIST=1 python bench.py --gpus 1 --frames 128 --size 4096 --vel-steps 32 --ang-steps 2 --min-lh 10 --steps 5 --verify --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${R}_cfg4_rccl_world1_bench_line.json
+KBMOD_FORCE_DIST=1 python bench.py --gpus 1 --steps 10 --verify --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${R}_cfg2_rccl_world1_bench_line.json
+(cd tools/ubench && ./ubench) > gpurun_out/${R}_ubench_issue_model.log 2>&1
+bash tools/profile_post.sh ${R}
+{
+  echo "# ms per step, kernel ms, evals/s (python bench.py --steps 20 --warmup 3 ...)"
+  for ARGS in "--mask-fraction 0.01" "--inset 64" "--size 2048" "--min-lh 10" "--flags 128" "--remake-padded-copy" \
+              "--frames 128 --size 4096 --vel-steps 32 --ang-steps 2 --remake-padded-copy --steps 5" \
+              "--frames 512 --size 2048 --vel-steps 64 --ang-steps 64 --num-bytes 2 --flags 16 --steps 2 --warmup 1"; do
+    python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --no-masked $ARGS 2>/dev/null | python -c "
+import sys, json
+for line in sys.stdin:
+    if line.startswith('{'):
+        d = json.loads(line); print('$ARGS |', round(d['ms_per_step'], 3), '|', round(d['roofline']['kernel_ms'], 3), '|', '%.3e' % d['value'], '|', d['roofline']['kernel'])"
+  done
+} > gpurun_out/${R}_other_configs.log

@@ -13,6 +13,6 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" \
            "GRBM_GUI_ACTIVE"; do
   rm -rf /tmp/sq_$TAG
-  rocprofv3 --pmc $grp -d /tmp/sq_$TAG -o r -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /tmp/sq_$TAG.log 2>&1
+  rocprofv3 --pmc $grp -d /tmp/sq_$TAG -o r -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic --no-masked "$@" > /tmp/sq_$TAG.log 2>&1
   python tools/rocprof_summary.py /tmp/sq_$TAG/r_results.db /tmp/sq_$TAG/r_results.db | grep -E "kb_search|kb_sigmag" >> gpurun_out/${TAG}_sq.md
 done

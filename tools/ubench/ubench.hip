@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include "ubench_asm.h"
 
 typedef float PairF __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) int* ConstIntPtr;
@@ -143,6 +144,57 @@ __global__ __launch_bounds__(1024) void loop_kernel(float* out, const int* table
             sbase += stride >> 1;
             if ((it & 3) == 3) sbase = sbase0;
         }
+    } else if constexpr (MODE == 8 || MODE == 9 || MODE == 10) {
+        // MODE 8: sixteen samples per wait (the wide-chunk loop): 16 x (v_add, ds_read_b64); wait; 16 x v_pk_add
+        // MODE 9: TWO START-PIXEL ROWS PER WAVE: 8 v_add, 16 ds_read_b64 (the second row's read at an immediate offset from the
+        //         same address register); wait; 16 v_pk_add -- run with half the waves
+        // MODE 10: two rows per wave, sixteen candidates: 16 v_add, 32 ds_read_b64; wait; 32 v_pk_add (half the waves, 64 accumulators)
+        constexpr int NA = MODE == 10 ? 32 : 16;
+        PairF acc2[NA];
+#pragma unroll
+        for (int c = 0; c < NA; ++c) acc2[c] = PairF{0.0f, 0.0f};
+        int o2[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) o2[c] = tab[c & 7] + (c >> 3) * 40;
+        for (int it = 0; it < iters; ++it) {
+            PairF raw[NA];
+            if constexpr (MODE == 8) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) raw[c] = *(LdsPair)(base + o2[c]);
+            } else if constexpr (MODE == 9) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t ad = base + o2[c];
+                    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:704" : "=&v"(raw[c]), "=&v"(raw[c + 8]) : "v"(ad) : "memory");
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const uint32_t ad = base + o2[c];
+                    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:704" : "=&v"(raw[c]), "=&v"(raw[c + 16]) : "v"(ad) : "memory");
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+            for (int c = 0; c < NA; ++c) { asm volatile("" : "+v"(raw[c])); acc2[c] += raw[c]; }
+            base += stride;
+            if ((it & 3) == 3) base = base0;
+        }
+#pragma unroll
+        for (int c = 0; c < NA; ++c) acc[c & 7] += acc2[c];
+    } else if constexpr (MODE >= 11 && MODE <= 14) {
+        // asm-exact loops (ubench_asm.h): 11 today's mix, 12 two rows x 8 candidates, 13 two rows x 16 candidates, 14 four rows x 8
+        int so[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) so[c] = __builtin_amdgcn_readfirstlane(tab[c & 7] + (c >> 3) * 48);
+        uint32_t b = base;
+        float r = 0.0f;
+        const int n = __builtin_amdgcn_readfirstlane(iters);
+        if constexpr (MODE == 11) { KB_UB_TODAY(b, n, so, r) }
+        if constexpr (MODE == 12) { KB_UB_ROWS2(b, n, so, r) }
+        if constexpr (MODE == 13) { KB_UB_ROWS2W(b, n, so, r) }
+        if constexpr (MODE == 14) { KB_UB_ROWS4(b, n, so, r) }
+        acc[0].x += r;
     } else if constexpr (MODE == 6) {
         PairF one = PairF{1.0f, (float)lane};
         for (int it = 0; it < iters; ++it) {
@@ -198,5 +250,18 @@ int main() {
         run<3>("3 offsets from LDS, counted waits", threads, iters, 576, out, table, cyc);
         run<4>("4 ds_read_addtid_b32 x2, M0", threads, iters, 288, out, table, cyc);
     }
+    // the same number of evaluations every line: 16 waves x 8192 iterations x 8 samples per CU
+    run<0>("0  8 cand x 1 row, 16 waves/CU", 1024, iters, 576, out, table, cyc);
+    run<8>("8  16 cand x 1 row, 16 waves/CU (today)", 1024, iters / 2, 576, out, table, cyc);
+    run<9>("9  8 cand x 2 rows, 8 waves/CU", 512, iters, 576, out, table, cyc);
+    run<10>("10 16 cand x 2 rows, 8 waves/CU", 512, iters / 2, 576, out, table, cyc);
+    run<11>("11 asm: 16 cand x 1 row (today), 16 waves", 1024, iters / 2, 576, out, table, cyc);
+    run<12>("12 asm: 8 cand x 2 rows, 16 waves", 1024, iters / 2, 576, out, table, cyc);
+    run<13>("13 asm: 16 cand x 2 rows (2 batches), 16 waves", 1024, iters / 4, 576, out, table, cyc);
+    run<14>("14 asm: 8 cand x 4 rows (2 batches), 16 waves", 1024, iters / 4, 576, out, table, cyc);
+    run<12>("12 asm: 8 cand x 2 rows, 8 waves", 512, iters, 576, out, table, cyc);
+    run<13>("13 asm: 16 cand x 2 rows (2 batches), 8 waves", 512, iters / 2, 576, out, table, cyc);
+    run<9>("9  8 cand x 2 rows, 16 waves/CU", 1024, iters / 2, 576, out, table, cyc);
+    run<10>("10 16 cand x 2 rows, 16 waves/CU", 1024, iters / 4, 576, out, table, cyc);
     return 0;
 }
