@@ -59,6 +59,7 @@ NO_REFILL = os.environ.get("KB_GEN_NO_REFILL") is not None
 # an odd epoch moves to the end of its trip.  The header then defines KB_LDS_DMA (search_lds.h passes the slab references
 # from one entry earlier: the reference of an odd epoch is now fetched in the even half of its own trip).
 DMA = os.environ.get("KB_GEN_NO_DMA") is None  # (KB_GEN_NO_DMA: the register-staged STREAM statements, for comparisons)
+BURST_REGS = DMA and os.environ.get("KB_GEN_BURST") is not None  # (two more scalar registers in the clobber lists: see BURST)
 
 
 class Plan:
@@ -66,13 +67,15 @@ class Plan:
         self.C = C
         if C == 8:
             self.A, self.B, self.gA, self.gB, self.addr, self.o1, self.o2 = 68, 76, 84, 92, 88, 90, 91
-            self.sregs = range(68, 98 if DMA else 96)
+            self.sregs = range(68, (100 if BURST_REGS else 98) if DMA else 96)
             self.ws, self.m0s = 96, 97           # DMA: LDS address of the wave's piece in the slot requested next; M0 of the caller
+            self.bc, self.bo = 98, 99            # BURST: requests left in a burst (pairs), running offset into the slab references
             self.bits = [92 + c for c in range(8)]
         else:
             self.A, self.B, self.gA, self.gB, self.addr, self.o1, self.o2 = 36, 52, 68, 72, 76, 78, 79
-            self.sregs = range(36, 82 if DMA else 80)   # (s32 - s35 are the stack registers of a kernel that has scratch memory)
+            self.sregs = range(36, (84 if BURST_REGS else 82) if DMA else 80)   # (s32 - s35 are the stack registers of a kernel that has scratch memory)
             self.ws, self.m0s = 80, 81
+            self.bc, self.bo = 82, 83
             self.bits = [84 + c for c in range(8)] * 2   # candidate k and k + 8 share a register (alternate bits)
         self.row = 4 * C                    # bytes of a table row (one epoch's offsets)
         self.loadx = f"s_load_dwordx{C}"
@@ -259,10 +262,39 @@ WIDE_COUNT = os.environ.get("KB_GEN_NO_WIDE_COUNT") is None
 CUR = {"wide_count": False}
 
 
+# Timing experiment (KB_GEN_BURST=1; measured slower, not the default): a whole group's slabs requested in ONE burst right behind
+# the group change (every slot of the buffer just read is free from that barrier on) instead of one request per epoch, so that
+# the last request of a group has a whole group to land in and a CU holds a group's worth of bytes in flight.  Same bits
+# (`bench.py --verify` clean on cfg2, a masked stack, cfg3 and a 128-epoch stack), but cfg2 2.37 -> 2.56 ms and the cfg4 share
+# 21.5 -> 23.3 ms (tools/ab.sh "noburst burst"): the references of a burst come by scalar loads that every wave of the tile waits
+# for at the one moment when nobody else has work (right behind the barrier) -- and the HBM-resident configuration gained
+# nothing relative to the cache-resident one, i.e. bytes in flight are not what binds it.
+BURST = DMA and os.environ.get("KB_GEN_BURST") is not None
+
+
+def dma_burst(p, np_, first):
+    """Requests for the %[pg] * 2 slabs of the group staged next; their references are read in pairs from %[gb] + s{o2} - 0x20
+    (+ 0x0 in the prologue: `first`), where the running offset stands one trip ahead of the epochs done."""
+    if not np_:
+        return ""
+    tag = f"kb_burst{'p' if first else 'g'}_%=_{np_}"
+    s = ln(f"s_mov_b32 s{p.bc}, %[pg]")
+    s += ln(f"s_mov_b32 s{p.bo}, 0x0" if first else f"s_sub_u32 s{p.bo}, s{p.o2}, 0x20")
+    s += '"\\n"\n'
+    s += f'"{tag}:\\n\\t"\n'
+    s += ln(f"s_load_dwordx4 s[{p.gA}:{p.gA + 3}], %[gb], s{p.bo}")
+    s += ln(f"s_load_dwordx4 s[{p.gB}:{p.gB + 3}], %[gb], s{p.bo} offset:0x10")
+    s += ln("s_waitcnt lgkmcnt(0)")
+    s += dma_request(p, "A", np_)
+    s += dma_request(p, "B", np_)
+    s += ln(f"s_add_u32 s{p.bo}, s{p.bo}, 0x20\\n\\ts_sub_u32 s{p.bc}, s{p.bc}, 1\\n\\ts_cmp_lg_u32 s{p.bc}, 0\\n\\ts_cbranch_scc1 {tag}")
+    return s
+
+
 def dma_half(p, which, fast, np_, request, refill):
     base = p.A if which == "A" else p.B
     imm1 = "" if which == "A" else f" offset:{hex(p.row)}"
-    s = dma_request(p, "A", np_) if (request and which == "A") else ""
+    s = dma_request(p, "A", np_) if (request and which == "A" and not BURST) else ""
     nb = 16 if (WIDE_BATCH and (fast or CUR["wide_count"]) and p.C == 16) else 8
     saved = p.raw
     if nb == 16:
@@ -272,7 +304,7 @@ def dma_half(p, which, fast, np_, request, refill):
         s += ln("s_waitcnt lgkmcnt(0)")
         if b == p.C // nb - 1 and refill and not NO_REFILL:
             s += ln(f"{p.loadx} s[{base}:{base + p.C - 1}], %[ob], s{p.o1}{imm1}")
-            if np_ and which == "A":
+            if np_ and which == "A" and not BURST:
                 # the references of the slabs the NEXT even epoch and THIS trip's odd epoch request (the base is one entry early)
                 s += ln(f"s_load_dwordx4 s[{p.gA}:{p.gA + 3}], %[gb], s{p.o2} offset:0x10")
                 s += ln(f"s_load_dwordx4 s[{p.gB}:{p.gB + 3}], %[gb], s{p.o2}")
@@ -285,16 +317,19 @@ def stream_dma(p, fast, np_):
     s = "" if fast else zero_bits(p)
     s += ln(f"{p.loadx} s[{p.A}:{p.A + p.C - 1}], %[ob], 0x0")
     s += ln(f"{p.loadx} s[{p.B}:{p.B + p.C - 1}], %[ob], {hex(p.row)}")
-    if np_:
+    if np_ and not BURST:
         s += ln(f"s_load_dwordx4 s[{p.gA}:{p.gA + 3}], %[gb], 0x10")
         s += ln(f"s_load_dwordx4 s[{p.gB}:{p.gB + 3}], %[gb], 0x20")
     s += ln(f"s_mov_b32 s{p.o1}, {hex(2 * p.row)}\\n\\ts_mov_b32 s{p.o2}, 0x20")
     s += ln(f"v_readfirstlane_b32 s{p.ws}, %[wd]")
-    if np_:
-        s += ln(f"s_mov_b32 m0, s{p.ws}\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 %[go], %[b0]")
-    if np_ == 2:
-        s += ln(f"s_add_u32 m0, s{p.ws}, %[so]\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 %[gq], %[b0]")
-    s += ln(f"s_add_u32 s{p.ws}, s{p.ws}, %[st]")
+    if BURST:
+        s += dma_burst(p, np_, True)  # the whole first staged group (the references start AT %[gb] in this form)
+    else:
+        if np_:
+            s += ln(f"s_mov_b32 m0, s{p.ws}\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 %[go], %[b0]")
+        if np_ == 2:
+            s += ln(f"s_add_u32 m0, s{p.ws}, %[so]\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 %[gq], %[b0]")
+        s += ln(f"s_add_u32 s{p.ws}, s{p.ws}, %[st]")
     s += ln("s_waitcnt lgkmcnt(0)")
     s += f'"s_cmp_eq_u32 %[np], 1\\n\\ts_cbranch_scc1 kb_sfin_%=_{np_}\\n"\n'
     s += f'"kb_sloop_%=_{np_}:\\n\\t"\n'
@@ -305,16 +340,19 @@ def stream_dma(p, fast, np_):
     s += ln("s_waitcnt vmcnt(0) lgkmcnt(0)" + ("" if NO_BARRIER else "\\n\\ts_barrier"))
     s += ln(f"v_add_u32 %[rb], %[dr], %[rb]\\n\\ts_sub_u32 s{p.ws}, s{p.ws}, %[es]\\n\\ts_sub_u32 s{p.ws}, s{p.ws}, %[dr]")
     s += ln("s_sub_u32 %[dr], 0, %[dr]\\n\\ts_mov_b32 %[gc], %[pg]")
+    if BURST:
+        s += dma_burst(p, np_, False)  # the group after next, into the buffer everybody has just left
     if not fast:
         s += ln(f"s_sub_u32 %[fc], %[fc], 1\\n\\ts_cmp_lg_u32 %[fc], 0\\n\\ts_cbranch_scc1 kb_snb_%=_{np_}")
         s += flush_bits(p, True)
         s += ln("s_mov_b32 %[fc], %[fg]")
     s += '"\\n"\n'
     s += f'"kb_snb_%=_{np_}:\\n\\t"\n'
-    s += dma_request(p, "B", np_)  # (the odd epoch's request: behind the barrier when the group changed)
+    if not BURST:
+        s += dma_request(p, "B", np_)  # (the odd epoch's request: behind the barrier when the group changed)
     s += f'"s_sub_u32 %[np], %[np], 1\\n\\ts_cmp_lg_u32 %[np], 1\\n\\ts_cbranch_scc1 kb_sloop_%=_{np_}\\n"\n'
     s += f'"kb_sfin_%=_{np_}:\\n\\t"\n'
-    s += dma_half(p, "A", fast, np_, True, False)
+    s += dma_half(p, "A", fast, np_, not BURST, False)
     s += dma_half(p, "B", fast, np_, False, False)
     return s
 
@@ -378,7 +416,7 @@ def main():
            '// KB_LDS_RUN_<LOOP|STREAM> expand, inside lds_search_tile, to the statement for its C and FAST; a statement holds the',
            '// bodies for waves that copy no, one or two pieces of every slab and picks by nq; it names the variables of its call',
            '// site (acc, cntp, wd, rb, pairs, gc, dr, fc, go, gq, nq, ob, gb, b0, tl, th, wp, wq, dl, dh, st, pg, es, fg, odd).',
-           '#ifndef KB_SEARCH_LDS_ASM_H_', '#define KB_SEARCH_LDS_ASM_H_', ''] + (['#define KB_LDS_DMA 1', ''] if DMA else [])
+           '#ifndef KB_SEARCH_LDS_ASM_H_', '#define KB_SEARCH_LDS_ASM_H_', ''] + (['#define KB_LDS_DMA 1', ''] if DMA else []) + (['#define KB_LDS_BURST 1', ''] if BURST else [])
     for C in (8, 16):
         p = Plan(C)
         for family, body in (("LOOP", loop), ("STREAM", stream_dma if DMA else stream)):
