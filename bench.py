@@ -238,6 +238,14 @@ def main():
     # takes the r-th contiguous slice of an N*1024 candidate (v, theta) grid ----
     vx, vy = fd.kbmod_v1_candidates(args.vel_steps, args.min_vel, args.max_vel, args.ang_steps * world, args.min_ang,
                                     args.max_ang)
+    if world > 1:
+        # The job-wide list in rank-major order with the angles dealt boustrophedon: rank r searches angle rows r, 2 N - 1 - r, 2 N + r, ... of the
+        # N * ang_steps-row grid (back and forth, so that every rank pairs flat rows with steep ones).  A chunk still holds the speeds of ONE angle (what its slab width follows), but every rank
+        # gets the same mix of flat and steep trajectories -- with contiguous angle bands the rank with the steepest band set
+        # the step (cfg4: 17.0 ... 22.5 ms per rank).  The merged result is checked against one search over THIS list.
+        order = np.array([j * world + (r if j % 2 == 0 else world - 1 - r) for r in range(world) for j in range(args.ang_steps)])
+        vx = vx.reshape(args.ang_steps * world, args.vel_steps)[order].reshape(-1)
+        vy = vy.reshape(args.ang_steps * world, args.vel_steps)[order].reshape(-1)
     n_local = args.vel_steps * args.ang_steps
     sl = slice(rank * n_local, (rank + 1) * n_local)
     all_np = np.zeros((n_local * world, 7), dtype=np.float32)
@@ -466,7 +474,7 @@ def main():
                         + (f", min_lh {float(params.min_lh):g}" if float(params.min_lh) > 0 else "")
                         + (f", {args.mask_fraction:g} of the science pixels masked" if args.mask_fraction > 0 else ""),
             "frames": T, "height": H, "width": W, "candidates_per_gpu": n_local, "results_per_pixel": K,
-            "sharding": ("candidates (v,theta) by rank; psi/phi replicated; "
+            "sharding": ("candidates (v,theta) by rank (angle rows dealt boustrophedon); psi/phi replicated; "
                          + (f"sparse exchange (one count byte per pixel + the records with lh >= {float(params.min_lh):g} of {list_len} "
                             "per pixel: one RCCL gather of the headers + one message per rank) + per-pixel merge, tie-exact" if sparse
                             else f"one RCCL gather of 16-byte records to rank 0 ({list_len} per pixel) + per-pixel merge, "

@@ -826,7 +826,13 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         const bool list_fits = params.do_sigmag_filter != 0 || params.results_per_pixel <= 32;  // (kb_search_large_k beyond)
         const int64_t tall_tiles = (int64_t)a.tiles_x * ((sh + LDS_ROWS_TALL - 1) / LDS_ROWS_TALL);
         const bool keep_encoded = meta->num_bytes != 4 && (flags & 16u) != 0;
-        if (list_fits && !keep_encoded && ((tall_tiles >= 128 && (flags & 128u) == 0) || (flags & 64u) != 0)) {
+        // A short candidate list (up to four chunks of 16) is mostly list-filling: the first chunks of a search insert in
+        // nearly every round, the sixteen waves of a 64 x 16 tile then wait at every group change for the wave with the most
+        // rounds.  Two 64 x 8 workgroups per CU have separate barriers and overlap one tile's finish with the other's sums, which
+        // is worth more there than the taller tile's smaller apron: 128 x 4096 x 4096 with 32 / 64 / 128 / 256 candidates 10.5 /
+        // 20.2 / 40.4 / 78.8 ms against 12.7 / 22.1 / 40.4 / 74.8 ms (profiles/r04_tile_height.log).  The sigma-G emit keeps no list.
+        const bool short_list = n_cands <= 64 && params.do_sigmag_filter == 0;
+        if (list_fits && !keep_encoded && ((tall_tiles >= 128 && (flags & 128u) == 0 && !short_list) || (flags & 64u) != 0)) {
             lds_rows = LDS_ROWS_TALL;
         }
     }

@@ -36,6 +36,10 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--rank-flags", type=int, default=1024,
                     help="extra kb_device_search_compact flags of the per-rank searches (1024: nothing below min_lh enters a list; 0 to compare)")
+    ap.add_argument("--contiguous", action="store_true", help="contiguous angle bands per rank (default: angle rows dealt boustrophedon)")
+    ap.add_argument("--single-flags", type=int, default=0,
+                    help="flags of the single-GPU step the aggregate is quoted against (1024: with the list floor, what "
+                         "StackSearch.search_all and bench.py pass for a thresholded search)")
     ap.add_argument("--dense", action="store_true", help="also gather and merge the dense lists (world x S x 2K x 16 bytes on this device)")
     args = ap.parse_args()
 
@@ -63,6 +67,11 @@ def main():
 
     n_local = args.vel_steps * args.ang_steps
     vx, vy = fd.kbmod_v1_candidates(args.vel_steps, 5.0, 40.0, args.ang_steps * world, 0.0, 1.5)
+    if not args.contiguous:
+        # angle rows dealt boustrophedon (bench.py --gpus N): every rank gets the same mix of flat and steep trajectories
+        order = np.array([j * world + (r if j % 2 == 0 else world - 1 - r) for r in range(world) for j in range(args.ang_steps)])
+        vx = vx.reshape(args.ang_steps * world, args.vel_steps)[order].reshape(-1)
+        vy = vy.reshape(args.ang_steps * world, args.vel_steps)[order].reshape(-1)
     all_np = np.zeros((n_local * world, 7), dtype=np.float32)
     all_np[:, 0], all_np[:, 1] = vx, vy
     all_cands = torch.from_numpy(all_np).to(dev)
@@ -142,9 +151,17 @@ def main():
 
     def one_rank_plain():
         bench.check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, all_cands.data_ptr(), n_local,
-                                                     res1.data_ptr(), S * K, 0, stream, C.byref(st0)))
+                                                     res1.data_ptr(), S * K, args.single_flags, stream, C.byref(st0)))
 
     single_gpu_ms = timed(one_rank_plain, args.reps)
+    # ... and the same with the list floor (flag 1024): what a single GPU does for a thresholded search through StackSearch
+    st2 = Stats()
+
+    def one_rank_floor():
+        bench.check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, all_cands.data_ptr(), n_local,
+                                                     res1.data_ptr(), S * K, 1024, stream, C.byref(st2)))
+
+    single_gpu_floor_ms = timed(one_rank_floor, args.reps)
 
     dense_bytes = S * L * 16
     wire_ms_sparse = max(wire) / (XGMI_LINK_GBPS * 1e6)
@@ -160,13 +177,14 @@ def main():
                  "merge_writes_bytes": S * K * 28},
         "verify": {"merged_equals_single_device_after_post_filter_ok": ok, "survivors": survivors},
         "single_gpu": {"step_ms": single_gpu_ms, "kernel_ms": float(st0.search_kernel_ms), "kernel": st0.kernel_name.decode(),
-                       "job_wide_list_on_one_gpu_ms": one_all_ms},
+                       "step_ms_with_list_floor": single_gpu_floor_ms, "job_wide_list_on_one_gpu_ms": one_all_ms},
         "predicted_no_overlap": {
             "xgmi_link_GBps": XGMI_LINK_GBPS,
             "wire_ms_sparse": wire_ms_sparse, "wire_ms_dense": wire_ms_dense,
             "step_ms_sparse": step_sparse,
             "step_ms_dense": None if merge_dense_ms is None else max(search_ms) + wire_ms_dense + merge_dense_ms,
             "aggregate_vs_one_gpu_sparse": world * single_gpu_ms / step_sparse,
+            "aggregate_vs_one_gpu_with_list_floor_sparse": world * single_gpu_floor_ms / step_sparse,
             "aggregate_vs_one_gpu_dense": None if merge_dense_ms is None else world * single_gpu_ms / (max(search_ms) + wire_ms_dense + merge_dense_ms),
         },
     }
