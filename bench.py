@@ -623,7 +623,7 @@ def live_traffic(argv, instance):
         d = tempfile.mkdtemp(prefix="kb_pmc_", dir="/tmp")
         try:
             r = subprocess.run([prof, "--pmc", counter, "-d", d, "-o", "r", "--"] + cmd_tail, cwd="/tmp", env=env,
-                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
             dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 return {"error": f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"}
