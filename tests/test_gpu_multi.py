@@ -272,7 +272,7 @@ def test_rccl_backend_at_world_size_one(extra):
     assert line["exchange"]["overlapped"] == (not sparse and "--no-overlap" not in extra)
 
 
-@pytest.mark.parametrize("world", [1, 3, 8])
+@pytest.mark.parametrize("world", [1, 3, 8, 11])  # (11: the merge instance for more than eight lists)
 @pytest.mark.parametrize("cfg", [dict(K=8, min_lh=5.0), dict(K=3, min_obs=5, min_lh=1.0), dict(K=16, min_lh=8.0),
                                  dict(K=4, min_obs=8, sigmag=(0.25, 0.75, 0.7413, 3.0)), dict(K=8, min_lh=1.0e9), dict(K=5)])
 def test_sparse_exchange_kernels(kb, ds, grid, world, cfg):
