@@ -381,3 +381,24 @@ def test_list_floor_flag_keeps_every_survivor(ds, ds_dyadic, grid, grid_dense, w
         r = util.as_records(floor)
         below = (r["lh"] != EMPTY) & (r["lh"] < np.float32(cfg["min_lh"]))
         assert below.sum() <= max(4, n_a // 50)
+
+
+def test_exchange_budget_tool_at_reduced_size():
+    """tools/exchange_budget.py (the 8-rank exchange measured piece by piece on one GPU; DESIGN.md section 5's table) on a stack
+    small enough for the suite: every rank's sparse lists merged == one search over the job-wide list after the post-filter,
+    sparse bytes on the wire far below dense, and the pieces it reports are all there."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "exchange_budget.py"), "--frames", "32", "--size", "512",
+                          "--vel-steps", "16", "--ang-steps", "2", "--world", "4", "--min-lh", "8", "--reps", "1", "--dense"],
+                         capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["verify"]["merged_equals_single_device_after_post_filter_ok"] is True and d["verify"]["survivors"] > 0
+    assert max(d["per_rank"]["wire_bytes"]) < d["per_rank"]["dense_wire_bytes"] // 8
+    assert len(d["per_rank"]["search_call_ms"]) == 4 and d["root"]["merge_sparse_ms"] > 0 and d["root"]["merge_dense_ms"] > 0
+    assert d["predicted_no_overlap"]["aggregate_vs_one_gpu_sparse"] > 1.0
