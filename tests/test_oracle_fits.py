@@ -36,6 +36,13 @@ def test_reference_workunit_file_decodes_to_what_its_writer_put_in():
             patch = sci[y - 1:y + 2, x - 1:x + 2].astype(np.float64)
             flux = float((patch * psf).sum() / (psf.astype(np.float64) ** 2).sum())
             assert flux > 100 and np.abs(patch - flux * psf).max() < 8.0, (flux, patch - flux * psf)
+    # What the reference's own test knows about this file (tests/test_reprojection.py:118-131: the WorkUnit loaded through
+    # astropy, image 0 reprojected onto its own WCS -- the "no-op case" --, "make sure the PSF for the object hasn't been warped":
+    # an object sits at [5][53] of the first science layer; the variance is 4.0).  The reprojection rescales the peak (115.5
+    # there), so only WHERE the object is carries over: the decoded layer has its brightest pixel exactly there.
+    sci0 = layers[0][1]
+    assert np.unravel_index(np.argmax(sci0), sci0.shape) == (5, 53) and sci0[5, 53] > 100.0
+    assert layers[2][2][25, 9] == np.float32(4.0)
     sci_hdu = fd.find(hdus, "SCI_0")
     cols = fd._columns(sci_hdu[0])
     for r in range(50):
