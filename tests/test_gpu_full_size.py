@@ -27,13 +27,18 @@ CONFIGS = {
     "cfg4_shard": ["--frames", "128", "--size", "4096", "--vel-steps", "32", "--ang-steps", "2"],
     # configs[4]: 512 x 2048 x 2048 uint16-encoded, 4096 candidates per pixel (8.8e12 evals)
     "cfg5_deep_u16": ["--frames", "512", "--size", "2048", "--num-bytes", "2", "--vel-steps", "64", "--ang-steps", "64"],
+    # configs[1] with a likelihood threshold: the lists' floor (flag 1024, what StackSearch.search_all passes) at full size --
+    # every kernel compared runs with it, the exact-position window included
+    "cfg2_f32_min_lh_10": ["--min-lh", "10"],
+    # ... and one GPU's share of configs[3] with it (64 candidates: two 64 x 8 tiles per CU)
+    "cfg4_shard_min_lh_10": ["--frames", "128", "--size", "4096", "--vel-steps", "32", "--ang-steps", "2", "--min-lh", "10"],
 }
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_full_size_properties(name):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
-           "--verify"] + CONFIGS[name]
+           "--no-live-traffic", "--no-masked", "--verify"] + CONFIGS[name]
     proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     assert lines, proc.stderr[-2000:]
@@ -43,6 +48,24 @@ def test_full_size_properties(name):
     assert proc.returncode == 0
     assert out["roofline"]["kernel"].startswith("kb::kb_search_lds<") and v["other_kernel"] == "kb_search_direct"
     assert out["value"] > 1e9  # north star floor, evals/s
+
+
+@pytest.mark.parametrize("extra", [[], ["--min-lh", "10"]])
+def test_headline_size_through_the_rccl_branch(extra):
+    """BASELINE configs[1] at full size through bench.py's N > 1 branch on the real RCCL backend (world size 1,
+    KBMOD_FORCE_DIST): 16 stable records per pixel, one gather (dense, finished behind the next search) or the sparse exchange
+    (with a likelihood threshold), the tie-exact merge -- the merged lists equal ONE search over the same candidates."""
+    env = dict(os.environ, KBMOD_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--verify"] + extra
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert lines and proc.returncode == 0, proc.stderr[-2000:]
+    out = json.loads(lines[-1])
+    assert out["verify"]["merged_equals_single_device_ok"] and out["verify"]["backend"] == "nccl"
+    assert out["exchange"]["form"] == ("sparse" if extra else "dense")
+    if extra:
+        assert out["exchange"]["wire_bytes_per_rank"] < out["exchange"]["dense_bytes_per_rank"] // 16 and out["verify_survivors"] > 0
 
 
 def _oracle_view(orc, lib, meta, arr, times):
