@@ -802,6 +802,9 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
     } else {
         lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, false>(a, tc, smem, lists);
     }
+#ifdef KB_EXP_NO_RESULTS  // (timing experiment: what the result stores cost; wrong results)
+    if (a.K == 12345)
+#endif
     if constexpr (!SIGMAG) {
         if constexpr (TileLists<KS, LM>::STORE_POOLED) {
             write_results_pooled(a, tc, lists.state, lists.store, PooledLayout{(uint32_t)(ROWS * WAVE)}, threadIdx.x);
@@ -809,7 +812,9 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
             write_results_stored<TileLists<KS, LM>::RECORDS>(a, tc, lists.state, lists.store, TileLists<KS, LM>::SLOT_BYTES * threadIdx.x,
                                                          ROWS * WAVE * TileLists<KS, LM>::SLOT_BYTES);
         } else if constexpr (TileLists<KS, LM>::PACKED) {
-            write_packed<KS>(a, tc, lists.packed);
+            // (every wave has left the summing loop behind a barrier: the group buffers are free; 32 lanes x (7 K + 1) dwords
+            // per wave -- 7.3 KB for K = 8 -- fit sixteen times into them)
+            write_packed<KS>(a, tc, lists.packed, smem + (size_t)tc.wv * (32 * (7 * KS + 1) * 4));
         } else {
             write_results<KS>(a, tc, lists.top);
         }
