@@ -224,6 +224,44 @@ __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int chu
         pending &= pending - 1u;
     }
 }
+// The K result records of every lane of a wave -- 64 consecutive start pixels of one row, hence one contiguous run of
+// 64 * K records in the result array -- leave as coalesced stores: each half of the wave lays its records down in the wave's
+// own patch of LDS (the group buffers are dead by the epilogue), then all 64 lanes write the patch out linearly, 256
+// contiguous bytes per store instruction.  The per-lane form stores 7 (or 4) dwords per slot at a lane stride of K records:
+// 3.76 GB of results of a 4096 x 4096 search took 1.5 ms of a 20 ms kernel that way (KB_EXP_NO_RESULTS), against 0.85 ms
+// for a plain fill of as many bytes.  R = dwords per record (7: kb_trajectory, 4: kb_compact_result); rec(s, w) fills
+// record s of the calling lane; `patch`: at least 32 * (R * K + 1) dwords of LDS owned by this wave.
+template <int R, typename MakeRecord>
+__device__ __forceinline__ void store_wave_records(uint32_t* run /* record 0 of the wave's lane 0 */, int K, bool live, char* patch,
+                                                   const MakeRecord& rec) {
+    typedef __attribute__((address_space(3))) uint32_t* LdsWords;
+    const LdsWords lds = (LdsWords)(uint32_t)(uintptr_t)patch;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t rk = (uint32_t)(R * K), stride = rk | 1u;           // (odd pitch: the 32 lanes of a half hit 32 different banks)
+    const uint32_t inv = ((1u << 20) + rk - 1u) / rk;                  // i / rk == (i * inv) >> 20 for i < 32 * rk, rk <= 188
+    const int n_live = __popcll(__ballot(live));                       // (live lanes are a prefix of the wave)
+    for (int h = 0; h < 2; ++h) {
+        if (live && (lane >> 5) == h) {
+            for (int s = 0; s < K; ++s) {
+                uint32_t w[R];
+                rec(s, w);
+#pragma unroll
+                for (int j = 0; j < R; ++j) lds[(uint32_t)(lane & 31) * stride + (uint32_t)(s * R + j)] = w[j];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t total = (uint32_t)max(0, min(32, n_live - 32 * h)) * rk;
+        uint32_t* dst = run + (size_t)(32 * h) * rk;
+        for (uint32_t i = (uint32_t)lane; i < total; i += WAVE) {
+            const uint32_t src = (i * inv) >> 20;
+            dst[i] = lds[src * stride + (i - src * rk)];
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Stable lists of 16 in the list store of kb_search_lds, pooled (LIST_STORE_POOLED): what the tie-exact exchange between
 // devices runs with chunks of WIDE_CHUNK candidates (2 K = 16 records per pixel, flag 512).  A thread's list is
 //   * 16 likelihoods in list order (four 16-byte rows of the lane-interleaved store),
@@ -350,7 +388,65 @@ __device__ __forceinline__ void finish_chunk_pooled(const SearchArgs& a, int chu
     }
 }
 __device__ __forceinline__ void write_results_pooled(const SearchArgs& a, const TileCoords& tc, const ListState& ls,
-                                                     const char* tile_list, const PooledLayout lay, uint32_t tid) {
+                                                     const char* tile_list, const PooledLayout lay, uint32_t tid,
+                                                     char* wave_patch = nullptr) {
+    if (wave_patch != nullptr && a.K * 7 <= 128) {  // (uniform) the coalesced form, see store_wave_records
+        if (!tc.row_active) return;
+        const bool live = tc.x_i < a.sw;
+        const ResultSink sink = a.cold->results;
+        const kb_trajectory* cands = a.cold->cands;
+        const size_t run0 = ((size_t)tc.y_i * a.sw + (size_t)(tc.tx * WAVE)) * a.K;
+        uint64_t cells = 0;
+        if (live && ls.stored) {
+            const uint2 c = *reinterpret_cast<const uint2*>(tile_list + lay.cells(tid));
+            cells = ((uint64_t)c.y << 32) | (uint64_t)c.x;
+        }
+        // (lh, flux, candidate, count) of slot s of this lane's list; candidate < 0: an empty slot
+        auto slot = [&](int s, float* lh, float* flux, int* id, uint32_t* obs) {
+            *lh = -FLT_MAX;
+            *flux = 0.0f;
+            *id = -1;
+            *obs = 0u;
+            if (ls.stored) {
+                const float v = *reinterpret_cast<const float*>(tile_list + lay.lh_row(s >> 2, tid) + 4 * (s & 3));
+                if (v != -FLT_MAX) {
+                    const uint32_t cell = (uint32_t)(cells >> (4 * s)) & 15u;
+                    const uint2 r = *reinterpret_cast<const uint2*>(tile_list + lay.pool(cell, tid));
+                    *lh = v;
+                    *flux = __uint_as_float(r.x);
+                    *id = (int)(r.y & 0xffffu);
+                    *obs = r.y >> 16;
+                }
+            }
+        };
+        if (sink.compact != nullptr) {
+            store_wave_records<4>(reinterpret_cast<uint32_t*>(sink.compact + run0), a.K, live, wave_patch, [&](int s, uint32_t (&w)[4]) {
+                float lh, flux;
+                int id;
+                uint32_t obs;
+                slot(s, &lh, &flux, &id, &obs);
+                w[0] = __float_as_uint(lh);
+                w[1] = __float_as_uint(flux);
+                w[2] = id < 0 ? 0xffffffffu : (uint32_t)(sink.cand_base + id);
+                w[3] = obs;
+            });
+        } else {
+            store_wave_records<7>(reinterpret_cast<uint32_t*>(sink.full + run0), a.K, live, wave_patch, [&](int s, uint32_t (&w)[7]) {
+                float lh, flux;
+                int id;
+                uint32_t obs;
+                slot(s, &lh, &flux, &id, &obs);
+                w[0] = id < 0 ? 0u : __float_as_uint(cands[id].vx);
+                w[1] = id < 0 ? 0u : __float_as_uint(cands[id].vy);
+                w[2] = __float_as_uint(lh);
+                w[3] = __float_as_uint(flux);
+                w[4] = (uint32_t)tc.x;
+                w[5] = (uint32_t)tc.y;
+                w[6] = obs;
+            });
+        }
+        return;
+    }
     if (tc.x_i >= a.sw || !tc.row_active) return;
     const size_t slot0 = ((size_t)tc.y_i * a.sw + tc.x_i) * a.K;
     uint64_t cells = 0;
@@ -375,44 +471,6 @@ __device__ __forceinline__ void write_results_pooled(const SearchArgs& a, const 
             }
         }
         store_result(a.cold->results, slot0 + s, res, id_s);
-    }
-}
-
-// The K result records of every lane of a wave -- 64 consecutive start pixels of one row, hence one contiguous run of
-// 64 * K records in the result array -- leave as coalesced stores: each half of the wave lays its records down in the wave's
-// own patch of LDS (the group buffers are dead by the epilogue), then all 64 lanes write the patch out linearly, 256
-// contiguous bytes per store instruction.  The per-lane form stores 7 (or 4) dwords per slot at a lane stride of K records:
-// 3.76 GB of results of a 4096 x 4096 search took 1.5 ms of a 20 ms kernel that way (KB_EXP_NO_RESULTS), against 0.85 ms
-// for a plain fill of as many bytes.  R = dwords per record (7: kb_trajectory, 4: kb_compact_result); rec(s, w) fills
-// record s of the calling lane; `patch`: at least 32 * (R * K + 1) dwords of LDS owned by this wave.
-template <int R, typename MakeRecord>
-__device__ __forceinline__ void store_wave_records(uint32_t* run /* record 0 of the wave's lane 0 */, int K, bool live, char* patch,
-                                                   const MakeRecord& rec) {
-    typedef __attribute__((address_space(3))) uint32_t* LdsWords;
-    const LdsWords lds = (LdsWords)(uint32_t)(uintptr_t)patch;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const uint32_t rk = (uint32_t)(R * K), stride = rk | 1u;           // (odd pitch: the 32 lanes of a half hit 32 different banks)
-    const uint32_t inv = ((1u << 20) + rk - 1u) / rk;                  // i / rk == (i * inv) >> 20 for i < 32 * rk, rk <= 188
-    const int n_live = __popcll(__ballot(live));                       // (live lanes are a prefix of the wave)
-    for (int h = 0; h < 2; ++h) {
-        if (live && (lane >> 5) == h) {
-            for (int s = 0; s < K; ++s) {
-                uint32_t w[R];
-                rec(s, w);
-#pragma unroll
-                for (int j = 0; j < R; ++j) lds[(uint32_t)(lane & 31) * stride + (uint32_t)(s * R + j)] = w[j];
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t total = (uint32_t)max(0, min(32, n_live - 32 * h)) * rk;
-        uint32_t* dst = run + (size_t)(32 * h) * rk;
-        for (uint32_t i = (uint32_t)lane; i < total; i += WAVE) {
-            const uint32_t src = (i * inv) >> 20;
-            dst[i] = lds[src * stride + (i - src * rk)];
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
     }
 }
 

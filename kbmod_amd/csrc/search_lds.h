@@ -807,7 +807,19 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
 #endif
     if constexpr (!SIGMAG) {
         if constexpr (TileLists<KS, LM>::STORE_POOLED) {
-            write_results_pooled(a, tc, lists.state, lists.store, PooledLayout{(uint32_t)(ROWS * WAVE)}, threadIdx.x);
+            // (16 slots x 7 dwords + 1 per lane, 32 lanes: 14.5 KB per wave -- eleven waves' worth fits 160 KB, so the sixteen
+            // waves of a 64 x 16 tile go in two turns)
+            constexpr int PATCH = 32 * (7 * 16 + 1) * 4;
+            constexpr int TURNS = (ROWS * PATCH + 2 * lds_group_bytes(ROWS) - 1) / (2 * lds_group_bytes(ROWS));
+#pragma unroll
+            for (int turn = 0; turn < TURNS; ++turn) {
+                const int per_turn = (ROWS + TURNS - 1) / TURNS;
+                if (tc.wv / per_turn == turn) {
+                    write_results_pooled(a, tc, lists.state, lists.store, PooledLayout{(uint32_t)(ROWS * WAVE)}, threadIdx.x,
+                                         smem + (size_t)(tc.wv % per_turn) * PATCH);
+                }
+                if (TURNS > 1) __syncthreads();
+            }
         } else if constexpr (TileLists<KS, LM>::STORED) {
             write_results_stored<TileLists<KS, LM>::RECORDS>(a, tc, lists.state, lists.store, TileLists<KS, LM>::SLOT_BYTES * threadIdx.x,
                                                          ROWS * WAVE * TileLists<KS, LM>::SLOT_BYTES);
