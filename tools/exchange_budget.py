@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--min-lh", type=float, default=10.0)
     ap.add_argument("--results-per-pixel", type=int, default=8)
-    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--rank-flags", type=int, default=1024,
                     help="extra kb_device_search_compact flags of the per-rank searches (1024: nothing below min_lh enters a list; 0 to compare)")
     ap.add_argument("--contiguous", action="store_true", help="contiguous angle bands per rank (default: angle rows dealt boustrophedon)")
@@ -80,13 +80,16 @@ def main():
     rank_params.results_per_pixel = L
 
     def timed(fn, reps):
+        """Median wall time of `reps` synchronised calls after one warm-up, in ms (a single hiccup does not set a rank's time)."""
         fn()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        ts = []
         for _ in range(reps):
+            t0 = time.perf_counter()
             fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps * 1e3
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts))
 
     records = torch.empty((S * L, 4), dtype=torch.int32, device=dev)
     packed_buf = torch.empty((max(1024, S * L // 16), 4), dtype=torch.int32, device=dev)
