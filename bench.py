@@ -316,15 +316,20 @@ def main():
                 b = which_set[0]
                 which_set[0] = (b + 1) % n_sets
                 records, gathered = records2[b], gathered2[b]
-                check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), rank_params, cands.data_ptr(),
-                                                        n_local, rank * n_local, records.data_ptr(), S * list_len,
-                                                        flags | (512 if exact_ties else 0), stream, C.byref(st)))
                 if sparse:
+                    # the search writes the count bytes of the sparse header itself where its kernel instance can, and then
+                    # leaves out the record runs of waves that keep nothing (kb_device_search_counted)
+                    counted = C.c_int32(0)
+                    check(lib, lib.kb_device_search_counted(C.byref(meta), arr, times.data_ptr(), rank_params, cands.data_ptr(),
+                                                            n_local, rank * n_local, records.data_ptr(), S * list_len,
+                                                            sp_header.data_ptr(), flags | (512 if exact_ties else 0), stream,
+                                                            C.byref(st), C.byref(counted)))
                     # nothing to hide: the wire carries a count byte per pixel and the few records above the threshold
                     stats = {}
                     try:
                         kdist.gather_and_merge_sparse(records, (ins, W - ins), (ins, H - ins), K, list_len, float(params.min_lh),
-                                                      all_cands, out=results, header=sp_header, packed=sp_packed[0], stats=stats)
+                                                      all_cands, out=results, header=sp_header, packed=sp_packed[0], stats=stats,
+                                                      counted=bool(counted.value))
                     except RuntimeError as err:
                         if "records kept, room for" not in str(err):
                             raise
@@ -332,9 +337,14 @@ def main():
                         need = int(sp_header[(S + 15) // 16 * 16:].view(torch.int64)[0].item())
                         sp_packed[0] = torch.empty((need + need // 4 + 1024, 4), dtype=torch.int32, device=dev)
                         kdist.gather_and_merge_sparse(records, (ins, W - ins), (ins, H - ins), K, list_len, float(params.min_lh),
-                                                      all_cands, out=results, header=sp_header, packed=sp_packed[0], stats=stats)
+                                                      all_cands, out=results, header=sp_header, packed=sp_packed[0], stats=stats,
+                                                      counted=bool(counted.value))
+                    stats["search_wrote_counts"] = bool(counted.value)
                     wire.update(stats)
                 else:
+                    check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), rank_params, cands.data_ptr(),
+                                                            n_local, rank * n_local, records.data_ptr(), S * list_len,
+                                                            flags | (512 if exact_ties else 0), stream, C.byref(st)))
                     nxt = kdist.start_gather_compact(records, (ins, W - ins), (ins, H - ins), K, all_cands, gathered=gathered,
                                                      out=results, list_len=list_len)
                     drain()               # the previous step's gather has had this step's search to travel in; merge it now
@@ -525,7 +535,8 @@ def main():
     if dist_mode:
         out["exchange"] = {"form": "sparse" if sparse else "dense", "list_len": list_len, "backend": backend,
                            "wire_bytes_per_rank": wire.get("wire_bytes"), "dense_bytes_per_rank": S * list_len * 16,
-                           "records_per_rank": wire.get("totals"), "overlapped": bool(not sparse and not args.no_overlap)}
+                           "records_per_rank": wire.get("totals"), "overlapped": bool(not sparse and not args.no_overlap),
+                           "search_wrote_counts": wire.get("search_wrote_counts")}
     if build_kernel_ms is not None:
         in_out = float(T) * H * W * 8 + float(meta.total_array_size)  # sci + var in, the array out
         out["psi_phi_build"] = {"kernel": "separable strip (<= 1e-4)" if args.separable_psf else "2-D strip (bit-identical)",

@@ -328,6 +328,19 @@ uint64_t kb_sparse_header_bytes(uint64_t n_pixels);
 int kb_sparsify_compact(const kb_compact_result* lists_dev, uint64_t n_pixels, int32_t list_len, float min_lh,
                         uint8_t* header_dev, kb_compact_result* packed_dev, uint64_t packed_capacity,
                         uint64_t* total_out_host, void* stream);
+/* The search itself can write the count bytes (new): kb_device_search_counted is kb_device_search_compact that also fills
+ * counts_dev[n_pixels] -- records per start pixel with cand >= 0 and !(lh < params.min_lh), a prefix of the pixel's sorted
+ * list -- and, where it does, does NOT write the record runs of waves (64 consecutive start pixels of a row) that keep nothing:
+ * for a thresholded search nearly all of results_dev stays untouched.  *counts_written_out = 1 when the kernel instance that ran
+ * did so (kb_search_lds with packed or pooled lists), 0 when it wrote every slot and no counts (then use kb_sparsify_compact).
+ * kb_sparsify_counted: the rest of kb_sparsify_compact given such counts in header_dev[0 .. n_pixels) -- block sums, scan,
+ * total, and a scatter that reads only the counted records.  Same header / packed layout; synchronises the stream. */
+int kb_device_search_counted(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
+                             kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
+                             int32_t cand_index_base, kb_compact_result* results_dev, uint64_t n_results, uint8_t* counts_dev,
+                             uint32_t flags, void* stream, kb_search_stats* stats_out, int32_t* counts_written_out);
+int kb_sparsify_counted(const kb_compact_result* lists_dev, uint64_t n_pixels, int32_t list_len, uint8_t* header_dev,
+                        kb_compact_result* packed_dev, uint64_t packed_capacity, uint64_t* total_out_host, void* stream);
 /* kb_merge_compact_exact on sparse lists: headers_dev = n_lists headers header_stride bytes apart (what one gather of
  * the devices' headers leaves on the root), packed_ptrs_host[r] = device pointer to list r's records (may be NULL when
  * its total is 0).  out_dev: [n_pixels][K] trajectories; where a record survives the post-filter the output equals

@@ -112,6 +112,25 @@ __global__ __launch_bounds__(256) void kb_sparsify_kernel(const kb_compact_resul
     }
 }
 
+// The scatter pass when the counts are GIVEN (the search wrote them: ResultSink::counts): a pixel keeps the first counts[p]
+// records of its list -- the survivors of a sorted list are a prefix --, and only those are read: the runs of waves that
+// kept nothing were never written.
+__global__ __launch_bounds__(256) void kb_sparsify_counted_kernel(const kb_compact_result* __restrict__ lists, uint64_t n_pixels,
+                                                                  int L, const uint8_t* __restrict__ counts,
+                                                                  const uint32_t* __restrict__ block_totals,
+                                                                  const uint64_t* __restrict__ block_base,
+                                                                  kb_compact_result* __restrict__ packed) {
+    __shared__ uint32_t wave_sums[4];
+    if (block_totals[blockIdx.x] == 0) return;
+    const uint64_t pix = (uint64_t)blockIdx.x * SPARSE_BLOCK + threadIdx.x;
+    const uint32_t c = pix < n_pixels ? counts[pix] : 0u;
+    uint32_t total = 0;
+    const uint32_t before = block_scan_256(c, wave_sums, &total);
+    const kb_compact_result* src = lists + pix * (uint64_t)L;
+    kb_compact_result* dst = packed + block_base[blockIdx.x] + before;
+    for (uint32_t k = 0; k < c; ++k) *reinterpret_cast<uint4*>(dst + k) = *reinterpret_cast<const uint4*>(src + k);
+}
+
 // Block totals -> exclusive uint64 bases, one workgroup per list (blockIdx.x); grand[list] = the list's total.
 __global__ __launch_bounds__(1024) void kb_sparse_scan_kernel(const uint32_t* __restrict__ totals, uint64_t n_blocks,
                                                               uint64_t* __restrict__ bases, uint64_t* __restrict__ grand) {
@@ -366,6 +385,50 @@ int kb_sparsify_compact(const kb_compact_result* lists_dev, uint64_t n_pixels, i
                        (int)list_len, min_lh, header_dev, totals, bases, packed_dev);
     KB_HIP_TRY(hipGetLastError());
     KB_HIP_TRY(hipStreamSynchronize(stream));  // the scratch is free for the next call when this one returns
+    return 0;
+}
+
+int kb_sparsify_counted(const kb_compact_result* lists_dev, uint64_t n_pixels, int32_t list_len, uint8_t* header_dev,
+                        kb_compact_result* packed_dev, uint64_t packed_capacity, uint64_t* total_out_host, void* stream_v) {
+    using namespace kb;
+    if (total_out_host == nullptr) return fail("sparsify_counted: null count pointer");
+    *total_out_host = 0;
+    if (lists_dev == nullptr || header_dev == nullptr) return fail("sparsify_counted: null pointer");
+    if (list_len <= 0 || list_len > MERGE_EXACT_MAX_K2) return fail("sparsify_counted: lists of 1 to 32 records per pixel");
+    if (n_pixels == 0) return fail("sparsify_counted: no pixels");
+    if (((uintptr_t)lists_dev | (uintptr_t)packed_dev | (uintptr_t)header_dev) & 15u) {
+        return fail("sparsify_counted: buffers must be aligned to 16 bytes");
+    }
+    KB_REQUIRE_DEVICE("the sparse exchange.");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    const uint64_t n_blocks = (n_pixels + SPARSE_BLOCK - 1) / SPARSE_BLOCK;
+    if (n_blocks > 0x7fffffffull) return fail("sparsify_counted: too many pixels for one launch");
+    const int slot = exchange_device_slot();
+    std::lock_guard<std::mutex> lock(g_exchange_mutex[slot]);
+    void* scratch = nullptr;
+    if (exchange_scratch(slot, n_blocks * 12 + 64, &scratch)) return 1;
+    uint64_t* bases = reinterpret_cast<uint64_t*>(scratch);
+    uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + n_blocks * 8);
+    uint64_t* total_dev = reinterpret_cast<uint64_t*>(header_dev + (n_pixels + 15) / 16 * 16);
+    KB_HIP_TRY(hipMemsetAsync(header_dev + n_pixels, 0, kb_sparse_header_bytes(n_pixels) - n_pixels, stream));
+    hipLaunchKernelGGL(kb_sparse_blocksum_kernel, dim3((unsigned)n_blocks, 1), dim3(256), 0, stream, header_dev, (uint64_t)0, n_pixels,
+                       n_blocks, totals);
+    KB_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(kb_sparse_scan_kernel, dim3(1), dim3(1024), 0, stream, totals, n_blocks, bases, total_dev);
+    KB_HIP_TRY(hipGetLastError());
+    uint64_t total = 0;
+    KB_HIP_TRY(hipMemcpyAsync(&total, total_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    KB_HIP_TRY(hipStreamSynchronize(stream));
+    *total_out_host = total;
+    if (total == 0) return 0;
+    if (packed_dev == nullptr || total > packed_capacity) {
+        return fail("sparsify_counted: " + std::to_string(total) + " records kept, room for " +
+                    std::to_string(packed_dev == nullptr ? 0 : packed_capacity));
+    }
+    hipLaunchKernelGGL(kb_sparsify_counted_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, lists_dev, n_pixels, (int)list_len,
+                       header_dev, totals, bases, packed_dev);
+    KB_HIP_TRY(hipGetLastError());
+    KB_HIP_TRY(hipStreamSynchronize(stream));
     return 0;
 }
 

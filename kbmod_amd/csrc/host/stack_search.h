@@ -620,27 +620,41 @@ protected:
                 }
                 detail::DeviceBlock slice((hi - lo) * sizeof(Trajectory)), records(part_results * sizeof(kb_compact_result));
                 if (hi > lo) check_status(kb_copy_block_to_gpu(cands.data() + lo, slice.ptr, (hi - lo) * sizeof(Trajectory)));
-                check_status(kb_device_search_compact(&psi_phi_array.get_meta_data(), array, times, part_params,
-                                                      slice.as<const kb_trajectory>(), hi - lo, (int32_t)lo,
-                                                      records.as<kb_compact_result>(), part_results, part_flags, nullptr,
-                                                      &part_stats[part]));
+                // Tie-exact parts: the search writes the count bytes of the sparse header itself where its kernel instance can
+                // (and then leaves out the record runs of waves that keep nothing); kb_sparsify_compact counts otherwise.
+                detail::DeviceBlock header(exact ? header_bytes : 1);
+                int32_t counted = 0;
+                if (exact) {
+                    check_status(kb_device_search_counted(&psi_phi_array.get_meta_data(), array, times, part_params,
+                                                          slice.as<const kb_trajectory>(), hi - lo, (int32_t)lo,
+                                                          records.as<kb_compact_result>(), part_results, header.as<uint8_t>(),
+                                                          part_flags, nullptr, &part_stats[part], &counted));
+                } else {
+                    check_status(kb_device_search_compact(&psi_phi_array.get_meta_data(), array, times, part_params,
+                                                          slice.as<const kb_trajectory>(), hi - lo, (int32_t)lo,
+                                                          records.as<kb_compact_result>(), part_results, part_flags, nullptr,
+                                                          &part_stats[part]));
+                }
                 // (the stats path returns without a final stream synchronisation: a fault inside the kernels must
                 // surface here, on the device it happened on, not in a later call)
                 check_status(kb_device_synchronize());
                 if (exact) {
-                    detail::DeviceBlock header(header_bytes);
                     uint64_t kept = 0, room = std::max<uint64_t>(1024, part_results / 16);
                     detail::DeviceBlock packed(room * sizeof(kb_compact_result));
-                    int rc = kb_sparsify_compact(records.as<const kb_compact_result>(), n_pixels,
-                                                 (int32_t)part_params.results_per_pixel, params.min_lh, header.as<uint8_t>(),
-                                                 packed.as<kb_compact_result>(), room, &kept, nullptr);
+                    auto sparsify = [&]() {
+                        return counted ? kb_sparsify_counted(records.as<const kb_compact_result>(), n_pixels,
+                                                             (int32_t)part_params.results_per_pixel, header.as<uint8_t>(),
+                                                             packed.as<kb_compact_result>(), room, &kept, nullptr)
+                                       : kb_sparsify_compact(records.as<const kb_compact_result>(), n_pixels,
+                                                             (int32_t)part_params.results_per_pixel, params.min_lh, header.as<uint8_t>(),
+                                                             packed.as<kb_compact_result>(), room, &kept, nullptr);
+                    };
+                    int rc = sparsify();
                     if (rc != 0 && kept > room) {  // more survivors than guessed: the count is known now
                         detail::DeviceBlock larger(kept * sizeof(kb_compact_result));
                         std::swap(packed.ptr, larger.ptr);
                         room = kept;
-                        rc = kb_sparsify_compact(records.as<const kb_compact_result>(), n_pixels,
-                                                 (int32_t)part_params.results_per_pixel, params.min_lh, header.as<uint8_t>(),
-                                                 packed.as<kb_compact_result>(), room, &kept, nullptr);
+                        rc = sparsify();
                     }
                     check_status(rc);
                     check_status(kb_copy_block_between_gpus(headers.as<uint8_t>() + (uint64_t)part * header_bytes, home, header.ptr,

@@ -125,6 +125,12 @@ struct ResultSink {
     kb_trajectory* full;
     kb_compact_result* compact;
     int cand_base;  // added to the candidate index of a compact record
+    // Optional (kb_device_search_counted; the epilogues of kb_search_lds with packed or pooled lists honour it): one byte per
+    // start pixel = the number of its records that survive the likelihood post-filter (cand >= 0 and not lh < keep_min_lh, a
+    // prefix of the sorted list) -- the header of the sparse exchange form, written by the search itself --, and a wave whose 64
+    // pixels keep nothing does NOT write its run of records at all.
+    uint8_t* counts;
+    float keep_min_lh;
 };
 // cand < 0: the placeholder of an empty slot (kernels.cu:293-301).
 __device__ __forceinline__ void store_result(const ResultSink& sink, size_t slot, const kb_trajectory& res, int cand) {

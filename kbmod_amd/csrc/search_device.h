@@ -233,10 +233,14 @@ __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int chu
 // record s of the calling lane; `patch`: at least 32 * (R * K + 1) dwords of LDS owned by this wave.
 template <int R, typename MakeRecord>
 __device__ __forceinline__ void store_wave_records(uint32_t* run /* record 0 of the wave's lane 0 */, int K, bool live, char* patch,
-                                                   const MakeRecord& rec) {
+                                                   const MakeRecord& rec, uint8_t* counts_run = nullptr, int kept = 0) {
     typedef __attribute__((address_space(3))) uint32_t* LdsWords;
     const LdsWords lds = (LdsWords)(uint32_t)(uintptr_t)patch;
     const int lane = threadIdx.x & (WAVE - 1);
+    if (counts_run != nullptr) {  // (uniform) ResultSink::counts: the count byte of every pixel; nothing else for a wave that keeps nothing
+        if (live) counts_run[lane] = (uint8_t)kept;
+        if (__ballot(live && kept != 0) == 0ull) return;
+    }
     const uint32_t rk = (uint32_t)(R * K), stride = rk | 1u;           // (odd pitch: the 32 lanes of a half hit 32 different banks)
     const uint32_t inv = ((1u << 20) + rk - 1u) / rk;                  // i / rk == (i * inv) >> 20 for i < 32 * rk, rk <= 188
     const int n_live = __popcll(__ballot(live));                       // (live lanes are a prefix of the wave)
@@ -402,6 +406,15 @@ __device__ __forceinline__ void write_results_pooled(const SearchArgs& a, const 
             cells = ((uint64_t)c.y << 32) | (uint64_t)c.x;
         }
         // (lh, flux, candidate, count) of slot s of this lane's list; candidate < 0: an empty slot
+        uint8_t* counts_run = sink.counts != nullptr ? sink.counts + ((size_t)tc.y_i * a.sw + (size_t)(tc.tx * WAVE)) : nullptr;
+        int kept = 0;
+        if (counts_run != nullptr && live && ls.stored) {
+            for (int r = 0; r < 4; ++r) {  // (the list's likelihoods, in list order: -FLT_MAX marks an empty slot)
+                const uint4 v = *reinterpret_cast<const uint4*>(tile_list + lay.lh_row(r, tid));
+                const float l4[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+                for (int j = 0; j < 4; ++j) kept += (4 * r + j < a.K && l4[j] != -FLT_MAX && !(l4[j] < sink.keep_min_lh)) ? 1 : 0;
+            }
+        }
         auto slot = [&](int s, float* lh, float* flux, int* id, uint32_t* obs) {
             *lh = -FLT_MAX;
             *flux = 0.0f;
@@ -429,7 +442,7 @@ __device__ __forceinline__ void write_results_pooled(const SearchArgs& a, const 
                 w[1] = __float_as_uint(flux);
                 w[2] = id < 0 ? 0xffffffffu : (uint32_t)(sink.cand_base + id);
                 w[3] = obs;
-            });
+            }, counts_run, kept);
         } else {
             store_wave_records<7>(reinterpret_cast<uint32_t*>(sink.full + run0), a.K, live, wave_patch, [&](int s, uint32_t (&w)[7]) {
                 float lh, flux;
@@ -443,7 +456,7 @@ __device__ __forceinline__ void write_results_pooled(const SearchArgs& a, const 
                 w[4] = (uint32_t)tc.x;
                 w[5] = (uint32_t)tc.y;
                 w[6] = obs;
-            });
+            }, counts_run, kept);
         }
         return;
     }
@@ -483,6 +496,12 @@ __device__ __forceinline__ void write_packed(const SearchArgs& a, const TileCoor
         const ResultSink sink = a.cold->results;
         const kb_trajectory* cands = a.cold->cands;
         const size_t run0 = ((size_t)tc.y_i * a.sw + (size_t)(tc.tx * WAVE)) * a.K;   // the slot of lane 0's first record
+        uint8_t* counts_run = sink.counts != nullptr ? sink.counts + ((size_t)tc.y_i * a.sw + (size_t)(tc.tx * WAVE)) : nullptr;
+        int kept = 0;
+        if (counts_run != nullptr) {
+#pragma unroll
+            for (int k = 0; k < KS; ++k) kept += (k < a.K && top.io[k] != TopKPacked<KS>::EMPTY && !(top.lh[k] < sink.keep_min_lh)) ? 1 : 0;
+        }
         if (sink.compact != nullptr) {
             store_wave_records<4>(reinterpret_cast<uint32_t*>(sink.compact + run0), a.K, live, wave_patch, [&](int s, uint32_t (&w)[4]) {
                 uint32_t io = TopKPacked<KS>::EMPTY;
@@ -500,7 +519,7 @@ __device__ __forceinline__ void write_packed(const SearchArgs& a, const TileCoor
                 w[1] = __float_as_uint(empty ? 0.0f : flux);
                 w[2] = empty ? 0xffffffffu : (uint32_t)(sink.cand_base + (int)(io & 0xffffu));
                 w[3] = empty ? 0u : (io >> 16);
-            });
+            }, counts_run, kept);
         } else {
             store_wave_records<7>(reinterpret_cast<uint32_t*>(sink.full + run0), a.K, live, wave_patch, [&](int s, uint32_t (&w)[7]) {
                 uint32_t io = TopKPacked<KS>::EMPTY;
@@ -522,7 +541,7 @@ __device__ __forceinline__ void write_packed(const SearchArgs& a, const TileCoor
                 w[4] = (uint32_t)tc.x;
                 w[5] = (uint32_t)tc.y;
                 w[6] = empty ? 0u : (io >> 16);
-            });
+            }, counts_run, kept);
         }
         return;
     }

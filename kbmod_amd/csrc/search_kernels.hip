@@ -745,7 +745,8 @@ namespace kb {
 static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
                               kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
                               const ResultSink sink, uint64_t n_results, uint32_t flags, void* stream_v,
-                              kb_search_stats* stats_out) {
+                              kb_search_stats* stats_out, int* counts_written = nullptr) {
+    if (counts_written != nullptr) *counts_written = 0;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (meta == nullptr) return fail("deviceSearchFilter: null meta data");
     // kernels.cu:337-340
@@ -1164,8 +1165,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     // the cold block of the kernel arguments (search_common.h) lives in device memory
     void* cold_dev = nullptr;
     if (ensure_workspace(5, sizeof(SearchCold), &cold_dev)) return 1;
-    a.cold = reinterpret_cast<const SearchCold*>(cold_dev);
-    KB_HIP_TRY(hipMemcpyAsync(cold_dev, &cold, sizeof(SearchCold), hipMemcpyHostToDevice, stream));
+    a.cold = reinterpret_cast<const SearchCold*>(cold_dev);  // (uploaded below, once the list form -- and with it the sink -- is settled)
 
     // Where kb_search_lds keeps its per-pixel lists (ListMode, search_lds.h): lists of up to 8 as packed result
     // records in registers (3); longer ones, or candidate indices beyond 16 bits, as whole records in the HBM store
@@ -1206,6 +1206,13 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
             }
         }
     }
+
+    // ResultSink::counts is honoured by the epilogues of kb_search_lds with packed or pooled lists only: any other instance
+    // writes every slot and leaves the counts to the caller (kb_device_search_counted then counts them from the records).
+    const bool counts_ok = sink.counts != nullptr && which == 2 && !sigmag && a.K <= 32 && (list_mode == 3 || list_mode == 4);
+    if (!counts_ok) cold.results.counts = nullptr;
+    if (counts_written != nullptr) *counts_written = counts_ok ? 1 : 0;
+    KB_HIP_TRY(hipMemcpyAsync(cold_dev, &cold, sizeof(SearchCold), hipMemcpyHostToDevice, stream));
 
     g_kernel_instance[0] = 0;
     search_timer.begin();
@@ -1316,6 +1323,19 @@ int kb_device_search_compact(const kb_psi_phi_meta* meta, const void* psi_phi_de
     const kb::ResultSink sink = {nullptr, results_dev, cand_index_base};
     return kb::search_filter_impl(meta, psi_phi_dev, times_dev, params, cands_dev, n_cands, sink, n_results, flags, stream,
                                   stats_out);
+}
+
+int kb_device_search_counted(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
+                             kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
+                             int32_t cand_index_base, kb_compact_result* results_dev, uint64_t n_results, uint8_t* counts_dev,
+                             uint32_t flags, void* stream, kb_search_stats* stats_out, int32_t* counts_written_out) {
+    if (counts_dev == nullptr || counts_written_out == nullptr) return kb::fail("device_search_counted: null pointer");
+    const kb::ResultSink sink = {nullptr, results_dev, cand_index_base, counts_dev, params.min_lh};
+    int written = 0;
+    const int rc = kb::search_filter_impl(meta, psi_phi_dev, times_dev, params, cands_dev, n_cands, sink, n_results, flags, stream,
+                                          stats_out, &written);
+    *counts_written_out = written;
+    return rc;
 }
 
 int kb_release_workspaces(void) {

@@ -196,6 +196,41 @@ def sparsify_compact(records, n_pixels, list_len, min_lh, header=None, packed=No
     return torch.from_numpy(h), torch.from_numpy(p.view(np.int32).reshape(-1, COMPACT_WORDS)), int(p.size // 16)
 
 
+def sparsify_counted(records, n_pixels, list_len, header, packed=None):
+    """The rest of :func:`sparsify_compact` when the SEARCH wrote the count bytes (kb_device_search_counted with
+    ``counts_dev = header``): block sums, scan, total, and a scatter that reads only the counted records of ``records`` -- the
+    runs the search skipped are never touched.  Device tensors only; ``packed`` as in :func:`sparsify_compact`.
+    -> ``(header, packed, total)``."""
+    import ctypes as C
+
+    import torch
+
+    if not (records.is_cuda and records.dtype == torch.int32 and records.dim() == 2 and records.shape[1] == COMPACT_WORDS
+            and records.is_contiguous() and records.shape[0] == int(n_pixels) * int(list_len)):
+        raise ValueError("records: expected a contiguous int32 device tensor [n_pixels * list_len, 4] of kb_compact_result records")
+    lib = device_lib()
+    hb = int(lib.kb_sparse_header_bytes(int(n_pixels)))
+    if not (header.dtype == torch.uint8 and header.numel() == hb and header.is_contiguous() and header.device == records.device):
+        raise ValueError(f"header: expected a contiguous uint8 tensor of {hb} bytes on the records' device")
+    if packed is not None and not (packed.dtype == torch.int32 and packed.dim() == 2 and packed.shape[1] == COMPACT_WORDS
+                                   and packed.is_contiguous() and packed.device == records.device):
+        raise ValueError("packed: expected a contiguous int32 tensor [capacity, 4] on the records' device")
+    total = C.c_uint64(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = lib.kb_sparsify_counted(records.data_ptr(), int(n_pixels), int(list_len), header.data_ptr(),
+                                 0 if packed is None else packed.data_ptr(), 0 if packed is None else int(packed.shape[0]),
+                                 C.byref(total), stream)
+    if rc != 0 and packed is None and total.value > 0:
+        packed = torch.empty((int(total.value), COMPACT_WORDS), dtype=torch.int32, device=records.device)
+        rc = lib.kb_sparsify_counted(records.data_ptr(), int(n_pixels), int(list_len), header.data_ptr(), packed.data_ptr(),
+                                     int(total.value), C.byref(total), stream)
+    if rc != 0:
+        raise RuntimeError(lib.kb_last_error().decode())
+    if packed is None:
+        packed = torch.empty((0, COMPACT_WORDS), dtype=torch.int32, device=records.device)
+    return header, packed, int(total.value)
+
+
 def sparse_totals(headers, n_pixels):
     """The record totals the headers [n_lists, header_bytes] announce (int64 on the host)."""
     at = (int(n_pixels) + 15) // 16 * 16
@@ -247,19 +282,23 @@ def merge_sparse_exact(headers, packed_list, x_bounds, y_bounds, K, list_len, al
 
 
 def gather_and_merge_sparse(local_records, x_bounds, y_bounds, K, list_len, min_lh, all_cands, group=None, out=None, dst=0,
-                            header=None, packed=None, stats=None):
+                            header=None, packed=None, stats=None, counted=False):
     """The exchange step in its sparse form: sparsify on every rank, ONE gather of the headers to global rank ``dst``, one
     point-to-point message per rank with exactly the records its header announced (all of them in flight together: seven
     transfers into the root, each on its own xGMI link), and the tie-exact merge there.  Returns the merged [S*K, 7]
     trajectories on rank ``dst`` and **None on every other rank**.  ``stats``: a dict that receives ``wire_bytes`` (what this
-    rank sent: header + records) and, on the root, ``totals``."""
+    rank sent: header + records) and, on the root, ``totals``.  ``counted``: this rank's search wrote the count bytes into
+    ``header`` itself (kb_device_search_counted said so) -- :func:`sparsify_counted` finishes the header and packs."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     me = dist.get_rank()
     n_pixels = (int(x_bounds[1]) - int(x_bounds[0])) * (int(y_bounds[1]) - int(y_bounds[0]))
-    header, packed, total = sparsify_compact(local_records.contiguous(), n_pixels, list_len, min_lh, header, packed)
+    if counted:
+        header, packed, total = sparsify_counted(local_records, n_pixels, list_len, header, packed)
+    else:
+        header, packed, total = sparsify_compact(local_records.contiguous(), n_pixels, list_len, min_lh, header, packed)
     via_host = header.is_cuda and dist.get_backend(group) != "nccl"
     h_send = header.cpu() if via_host else header
     p_send = packed[:total].cpu() if via_host else packed[:total]

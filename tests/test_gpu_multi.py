@@ -383,6 +383,46 @@ def test_list_floor_flag_keeps_every_survivor(ds, ds_dyadic, grid, grid_dense, w
         assert below.sum() <= max(4, n_a // 50)
 
 
+@pytest.mark.parametrize("flags", [2, 4, 4 | 64, 4 | 128, 4 | 512, 4 | 512 | 1024, 4 | 1024])
+@pytest.mark.parametrize("cfg", [dict(K=8, min_lh=5.0), dict(K=16, min_lh=3.0), dict(K=4, min_obs=10, min_lh=6.0),
+                                 dict(K=32, min_lh=4.0), dict(K=8, min_lh=-2.0), dict(K=8, min_lh=1e9)])
+@pytest.mark.parametrize("which", ["chunks_of_8", "wide_chunks"])
+def test_counted_search_writes_the_sparse_header(ds, ds_dyadic, grid, grid_dense, which, cfg, flags):
+    """kb_device_search_counted: the count bytes the search writes are the ones kb_sparsify_compact counts from the full
+    record lists, every record a count covers is the record of kb_device_search_compact, records of waves that keep nothing
+    are NOT written (the buffer keeps its fill), and kb_sparsify_counted packs the same bytes.  Where the kernel instance
+    cannot write counts, it says so and the records are all there."""
+    from kbmod_amd import distributed as kdist
+
+    d, (vx, vy) = (ds, grid) if which == "chunks_of_8" else (ds_dyadic, grid_dense)
+    torch = d.torch
+    cands = d.candidates(vx, vy)
+    p = d.params(**cfg)
+    K, S = cfg["K"], d.H * d.W
+    want, st0 = d.search_compact(p, cands, 7, flags)
+    h_want, pk_want, total = kdist.sparsify_compact(want, S, K, cfg["min_lh"])
+    POISON = 0x5a5a5a5a
+    got, header, written, st1 = d.search_counted(p, cands, 7, flags, poison=POISON)
+    assert st0.kernel_name == st1.kernel_name
+    if not written:
+        assert torch.equal(got, want)
+        return
+    assert torch.equal(header[:S], h_want[:S])  # (the padding and the total behind the counts are kb_sparsify_counted's)
+    counts = header[:S].to(torch.int64)
+    slot = torch.arange(K, device=got.device).repeat(S)
+    covered = slot < counts.repeat_interleave(K)
+    assert torch.equal(got[covered], want[covered])
+    # a pixel's uncovered records are either the search's own (its wave kept something) or untouched
+    untouched = (got == POISON).all(dim=1)
+    assert bool(((got == want).all(dim=1) | untouched).all())
+    assert not bool((untouched & covered).any())
+    if total == 0:
+        assert bool(untouched.all())
+    packed = torch.empty((max(1, total), 4), dtype=torch.int32, device=got.device)
+    _, _, n = kdist.sparsify_counted(got, S, K, header, packed)
+    assert n == total and torch.equal(packed[:total], pk_want[:total]) and torch.equal(header, h_want)
+
+
 def test_exchange_budget_tool_at_reduced_size():
     """tools/exchange_budget.py (the 8-rank exchange measured piece by piece on one GPU; DESIGN.md section 5's table) on a stack
     small enough for the suite: every rank's sparse lists merged == one search over the job-wide list after the post-filter,

@@ -155,6 +155,26 @@ class DeviceStack:
         self.torch.cuda.synchronize()
         return out, st
 
+    def search_counted(self, params, cands, cand_base, flags=0, poison=None):
+        """kb_device_search_counted -> (records, counts header, counts_written, stats); ``poison``: the int32 value the record
+        buffer is filled with first (records the search skipped keep it)."""
+        import ctypes as C
+
+        from kbmod_amd import capi
+
+        S = (params.x_start_max - params.x_start_min) * (params.y_start_max - params.y_start_min)
+        n = S * params.results_per_pixel
+        out = self.torch.empty((n, 4), dtype=self.torch.int32, device="cuda")
+        if poison is not None:
+            out.fill_(poison)
+        header = self.torch.full((int(self.lib.kb_sparse_header_bytes(S)),), 0xEE, dtype=self.torch.uint8, device="cuda")
+        st, written = capi.Stats(), C.c_int32(-1)
+        capi.check(self.lib.kb_device_search_counted(C.byref(self.meta), self.arr, self.times.data_ptr(), params,
+                                                     cands.data_ptr(), cands.shape[0], cand_base, out.data_ptr(), n,
+                                                     header.data_ptr(), flags, self.stream, C.byref(st), C.byref(written)))
+        self.torch.cuda.synchronize()
+        return out, header, int(written.value), st
+
     def close(self):
         if self.arr:
             self.lib.kb_free_gpu_block(self.arr)

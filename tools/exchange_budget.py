@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--single-flags", type=int, default=0,
                     help="flags of the single-GPU step the aggregate is quoted against (1024: with the list floor, what "
                          "StackSearch.search_all and bench.py pass for a thresholded search)")
+    ap.add_argument("--counted", action="store_true",
+                    help="per-rank searches through kb_device_search_counted (the search writes the count bytes and skips the "
+                         "record runs of waves that keep nothing) + kb_sparsify_counted")
     ap.add_argument("--dense", action="store_true", help="also gather and merge the dense lists (world x S x 2K x 16 bytes on this device)")
     args = ap.parse_args()
 
@@ -100,16 +103,26 @@ def main():
         cands = all_cands[r * n_local:(r + 1) * n_local]
         st = Stats()
 
+        counted = C.c_int32(0)
+
         def search():
-            bench.check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), rank_params, cands.data_ptr(),
-                                                          n_local, r * n_local, records.data_ptr(), S * L, 512 | args.rank_flags, stream, C.byref(st)))
+            if args.counted:
+                bench.check(lib, lib.kb_device_search_counted(C.byref(meta), arr, times.data_ptr(), rank_params, cands.data_ptr(),
+                                                              n_local, r * n_local, records.data_ptr(), S * L, header_buf.data_ptr(),
+                                                              512 | args.rank_flags, stream, C.byref(st), C.byref(counted)))
+            else:
+                bench.check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), rank_params, cands.data_ptr(),
+                                                              n_local, r * n_local, records.data_ptr(), S * L, 512 | args.rank_flags, stream, C.byref(st)))
 
         search_ms.append(timed(search, args.reps))
         kernel_ms.append(float(st.search_kernel_ms))
         out = {}
 
         def sparsify():
-            out["h"], out["p"], out["n"] = kdist.sparsify_compact(records, S, L, args.min_lh, header_buf, packed_buf)
+            if args.counted and counted.value:
+                out["h"], out["p"], out["n"] = kdist.sparsify_counted(records, S, L, header_buf, packed_buf)
+            else:
+                out["h"], out["p"], out["n"] = kdist.sparsify_compact(records, S, L, args.min_lh, header_buf, packed_buf)
 
         sparsify_ms.append(timed(sparsify, args.reps))
         headers.append(out["h"].clone())
@@ -173,6 +186,7 @@ def main():
     step_sparse = rank_ms + wire_ms_sparse + merge_sparse_ms
     out = {
         "workload": f"{T}x{H}x{W} f32, {n_local} candidates per rank x {world} ranks, K={K}, lists of {L} stable records, min_lh={args.min_lh:g}",
+        "counted_search": bool(args.counted),
         "per_rank": {"search_call_ms": search_ms, "search_kernel_ms": kernel_ms, "sparsify_ms": sparsify_ms, "wire_bytes": wire,
                      "dense_wire_bytes": dense_bytes},
         "root": {"merge_sparse_ms": merge_sparse_ms, "merge_dense_ms": merge_dense_ms,

@@ -1,7 +1,8 @@
 """One-off sweep of the sparse multi-GPU exchange on one GPU: python tools/fuzz_exchange.py FIRST LAST
 Random stacks, candidate lists, K, world sizes, thresholds and partitions: per-rank searches with 2 K stable records and the
 list floor -> kb_sparsify_compact -> kb_merge_sparse_exact must equal ONE search over the whole list after the post-filter
-(and the dense tie-exact merge must equal that search as it is)."""
+(and the dense tie-exact merge must equal that search as it is); and where the search can write the counts itself
+(kb_device_search_counted), header and packed records through kb_sparsify_counted must be the same bytes."""
 import sys
 
 sys.path.insert(0, ".")
@@ -13,6 +14,7 @@ from tests import util
 
 EMPTY = np.float32(-3.4028234663852886e38)
 bad = []
+n_counted = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rng = np.random.default_rng(seed)
     T = int(rng.integers(3, 40))
@@ -46,6 +48,14 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             rec, _ = d.search_compact(p2, all_cands[int(lo):int(hi)], int(lo), flags | 512 | 1024)
             h, pk, total = kdist.sparsify_compact(rec, H * W, 2 * K, min_lh)
             headers.append(h), packed.append(pk)
+            # the same through the counted search: header and packed records must be the same bytes
+            recc, hc, written, _ = d.search_counted(p2, all_cands[int(lo):int(hi)], int(lo), flags | 512 | 1024, poison=0x5a5a5a5a)
+            if written:
+                n_counted += 1
+                pkc = tt.empty((max(1, total), 4), dtype=tt.int32, device="cuda")
+                _, _, totc = kdist.sparsify_counted(recc, H * W, 2 * K, hc, pkc)
+                if not (totc == total and tt.equal(hc, h) and tt.equal(pkc[:total], pk[:total])):
+                    bad.append(("counted", seed))
             rec0, _ = d.search_compact(p2, all_cands[int(lo):int(hi)], int(lo), flags | 512)
             dense.append(rec0)
         merged = kdist.merge_sparse_exact(tt.stack(headers), packed, (0, W), (0, H), K, 2 * K, all_cands)
@@ -62,4 +72,4 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             bad.append(seed)
     finally:
         d.close()
-print("seeds", sys.argv[1], sys.argv[2], "mismatches", bad)
+print("seeds", sys.argv[1], sys.argv[2], "mismatches", bad, "counted searches", n_counted)
