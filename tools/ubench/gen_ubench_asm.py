@@ -52,8 +52,35 @@ def macro(name, n_cand, rows, batches, shared_addr=False):
             f"// {name}: {len(ins)} instructions per iteration, {n_cand * rows} evaluations\n")
 
 
+def class_macro(name, jumps=True):
+    """Prefix-sharing model: per iteration only n = 1 + (iteration & 15) of the 16 (address add, read, add) units run (mean 8.5),
+    entered by two computed jumps (s_setpc_b64) into code laid out for unit 15 down to 0; `jumps` False: the same unit counts
+    cannot be had without jumps, so the variant runs all 16 (control: the jump overhead alone shows against KB_UB_TODAY)."""
+    lines = ["s_mov_b32 s60, %2"] + [f"v_mov_b32 v{32 + i}, 0" for i in range(32)]
+    # the two entry tables' addresses, once (s[66:67] reads, s[68:69] adds)
+    lines += ["s_getpc_b64 s[66:67]", "kb_ub_here_%=:", "s_add_u32 s66, s66, kb_ub_rd_%=-kb_ub_here_%=", "s_addc_u32 s67, s67, 0",
+              "s_getpc_b64 s[68:69]", "kb_ub_here2_%=:", "s_add_u32 s68, s68, kb_ub_ad_%=-kb_ub_here2_%=", "s_addc_u32 s69, s69, 0", "1:"]
+    lines += ["s_and_b32 s62, s60, 15" if jumps else "s_mov_b32 s62, 15", "s_sub_u32 s62, 15, s62", "s_mul_i32 s63, s62, 12",
+              "s_add_u32 s64, s66, s63", "s_addc_u32 s65, s67, 0", "s_setpc_b64 s[64:65]", "kb_ub_rd_%=:"]
+    for j in range(15, -1, -1):
+        lines += [f"v_add_u32_e32 v124, %{3 + j}, %0", f"ds_read_b64 v[{96 + 2 * j}:{97 + 2 * j}], v124"]
+    lines += ["s_waitcnt lgkmcnt(0)", "s_lshl_b32 s63, s62, 3", "s_add_u32 s64, s68, s63", "s_addc_u32 s65, s69, 0", "s_setpc_b64 s[64:65]", "kb_ub_ad_%=:"]
+    for j in range(15, -1, -1):
+        lines.append(f"v_pk_add_f32 v[{32 + 2 * j}:{33 + 2 * j}], v[{32 + 2 * j}:{33 + 2 * j}], v[{96 + 2 * j}:{97 + 2 * j}]")
+    lines += ["s_sub_u32 s60, s60, 1", "s_cmp_lg_u32 s60, 0", "s_cbranch_scc1 1b"]
+    for i in range(1, 32):
+        lines.append(f"v_add_f32 v32, v32, v{32 + i}")
+    lines.append("v_mov_b32 %1, v32")
+    text = " \\\n    ".join('"' + l + '\\n\\t"' for l in lines)
+    clob = ", ".join(f'"v{i}"' for i in list(range(32, 64)) + list(range(96, 128)))
+    return (f"#define {name}(base, iters, o, result) \\\n  asm volatile( \\\n    {text} \\\n    : \"+v\"(base), \"=&v\"(result) : \"s\"(iters), "
+            + ", ".join(f'"s"(o[{c}])' for c in range(16)) + f" : {clob}, \"s60\", \"s62\", \"s63\", \"s64\", \"s65\", \"s66\", \"s67\", \"s68\", \"s69\", \"scc\", \"memory\");\n")
+
+
 print("// generated by gen_ubench_asm.py -- do not edit")
 print(macro("KB_UB_TODAY", 16, 1, 1))
 print(macro("KB_UB_ROWS2", 8, 2, 1))
 print(macro("KB_UB_ROWS2W", 16, 2, 2))
 print(macro("KB_UB_ROWS4", 8, 2, 2, shared_addr=True))
+print(class_macro("KB_UB_CLASS"))
+print(class_macro("KB_UB_CLASS16", jumps=False))
