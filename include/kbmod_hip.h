@@ -339,6 +339,17 @@ int kb_device_search_counted(const kb_psi_phi_meta* meta, const void* psi_phi_de
                              kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
                              int32_t cand_index_base, kb_compact_result* results_dev, uint64_t n_results, uint8_t* counts_dev,
                              uint32_t flags, void* stream, kb_search_stats* stats_out, int32_t* counts_written_out);
+/* The same for a single device's whole search (stack_search.cpp:221-284 with a likelihood threshold): the 28-byte trajectories
+ * of kb_device_search_filter + the count bytes, and the filter / sort that reads through them -- only the counted records are
+ * read, the working storage is sized by what survives, min_lh must be the search's own and above -FLT_MAX (the counts leave
+ * out the placeholders of empty slots).  Otherwise kb_filter_sort_results_checked. */
+int kb_device_search_filter_counted(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
+                                    kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
+                                    kb_trajectory* results_dev, uint64_t n_results, uint8_t* counts_dev, uint32_t flags, void* stream,
+                                    kb_search_stats* stats_out, int32_t* counts_written_out);
+int kb_filter_sort_results_counted(const kb_trajectory* results_dev, uint64_t n_pixels, int32_t list_len, const uint8_t* counts_dev,
+                                   float min_lh, int32_t min_obs, kb_trajectory* out_dev, uint64_t* n_out_host,
+                                   int64_t* first_invalid_host, void* stream);
 int kb_sparsify_counted(const kb_compact_result* lists_dev, uint64_t n_pixels, int32_t list_len, uint8_t* header_dev,
                         kb_compact_result* packed_dev, uint64_t packed_capacity, uint64_t* total_out_host, void* stream);
 /* kb_merge_compact_exact on sparse lists: headers_dev = n_lists headers header_stride bytes apart (what one gather of

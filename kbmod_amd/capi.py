@@ -74,6 +74,11 @@ def load_lib():
     lib.kb_device_search_counted.argtypes = [C.POINTER(Meta), C.c_void_p, C.c_void_p, Params, C.c_void_p, C.c_uint64, C.c_int32,
                                              C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Stats),
                                              C.POINTER(C.c_int32)]
+    lib.kb_device_search_filter_counted.argtypes = [C.POINTER(Meta), C.c_void_p, C.c_void_p, Params, C.c_void_p, C.c_uint64,
+                                                    C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Stats),
+                                                    C.POINTER(C.c_int32)]
+    lib.kb_filter_sort_results_counted.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_float, C.c_int32, C.c_void_p,
+                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.c_void_p]
     lib.kb_sparsify_counted.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64,
                                         C.POINTER(C.c_uint64), C.c_void_p]
     lib.kb_merge_sparse_exact.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, Params,

@@ -131,6 +131,31 @@ __global__ __launch_bounds__(256) void kb_sparsify_counted_kernel(const kb_compa
     for (uint32_t k = 0; k < c; ++k) *reinterpret_cast<uint4*>(dst + k) = *reinterpret_cast<const uint4*>(src + k);
 }
 
+// The same for whole trajectories (28-byte records: kb_filter_sort_results_counted).  A wave walks its pixels that keep
+// something one after the other and copies each one's c x 7 dwords with all lanes: contiguous reads, contiguous writes.
+__global__ __launch_bounds__(256) void kb_compact_counted_full_kernel(const kb_trajectory* __restrict__ lists, uint64_t n_pixels,
+                                                                      int L, const uint8_t* __restrict__ counts,
+                                                                      const uint32_t* __restrict__ block_totals,
+                                                                      const uint64_t* __restrict__ block_base,
+                                                                      kb_trajectory* __restrict__ packed) {
+    __shared__ uint32_t wave_sums[4];
+    if (block_totals[blockIdx.x] == 0) return;
+    const uint64_t pix = (uint64_t)blockIdx.x * SPARSE_BLOCK + threadIdx.x;
+    const uint32_t c = pix < n_pixels ? counts[pix] : 0u;
+    uint32_t total = 0;
+    const uint32_t before = block_scan_256(c, wave_sums, &total);
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave_pix0 = (uint64_t)blockIdx.x * SPARSE_BLOCK + (uint64_t)(threadIdx.x & ~63);
+    const uint32_t* src0 = reinterpret_cast<const uint32_t*>(lists + wave_pix0 * (uint64_t)L);
+    uint32_t* dst0 = reinterpret_cast<uint32_t*>(packed + block_base[blockIdx.x]);
+    for (unsigned long long todo = __ballot(c != 0); todo != 0ull; todo &= todo - 1ull) {
+        const int p = __builtin_ctzll(todo);
+        const uint32_t n_dw = 7u * (uint32_t)__shfl((int)c, p), to = 7u * (uint32_t)__shfl((int)before, p);
+        const uint32_t from = 7u * (uint32_t)L * (uint32_t)p;
+        for (uint32_t i = (uint32_t)lane; i < n_dw; i += 64u) dst0[to + i] = src0[from + i];
+    }
+}
+
 // Block totals -> exclusive uint64 bases, one workgroup per list (blockIdx.x); grand[list] = the list's total.
 __global__ __launch_bounds__(1024) void kb_sparse_scan_kernel(const uint32_t* __restrict__ totals, uint64_t n_blocks,
                                                               uint64_t* __restrict__ bases, uint64_t* __restrict__ grand) {
@@ -431,6 +456,45 @@ int kb_sparsify_counted(const kb_compact_result* lists_dev, uint64_t n_pixels, i
     KB_HIP_TRY(hipStreamSynchronize(stream));
     return 0;
 }
+
+}  // extern "C"
+
+namespace kb {
+// counts[n_pixels] (records kept per start pixel, a prefix of its list of L trajectories: kb_device_search_filter_counted) ->
+// the kept trajectories pixel after pixel in out_dev.  *total_host is valid whenever the call returns 0 or fails for want of
+// room (capacity = 0 asks for the count alone); synchronises the stream.
+int compact_counted_full(const kb_trajectory* lists_dev, uint64_t n_pixels, int L, const uint8_t* counts_dev, kb_trajectory* out_dev,
+                         uint64_t capacity, uint64_t* total_host, hipStream_t stream) {
+    *total_host = 0;
+    const uint64_t n_blocks = (n_pixels + SPARSE_BLOCK - 1) / SPARSE_BLOCK;
+    if (n_blocks > 0x7fffffffull) return fail("filter_sort_results_counted: too many pixels for one launch");
+    const int slot = exchange_device_slot();
+    std::lock_guard<std::mutex> lock(g_exchange_mutex[slot]);
+    void* scratch = nullptr;
+    if (exchange_scratch(slot, n_blocks * 12 + 64, &scratch)) return 1;
+    uint64_t* bases = reinterpret_cast<uint64_t*>(scratch);
+    uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + n_blocks * 8);
+    uint64_t* total_dev = reinterpret_cast<uint64_t*>(static_cast<char*>(scratch) + (n_blocks * 12 + 15) / 16 * 16);
+    hipLaunchKernelGGL(kb_sparse_blocksum_kernel, dim3((unsigned)n_blocks, 1), dim3(256), 0, stream, counts_dev, (uint64_t)0, n_pixels,
+                       n_blocks, totals);
+    KB_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(kb_sparse_scan_kernel, dim3(1), dim3(1024), 0, stream, totals, n_blocks, bases, total_dev);
+    KB_HIP_TRY(hipGetLastError());
+    uint64_t total = 0;
+    KB_HIP_TRY(hipMemcpyAsync(&total, total_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    KB_HIP_TRY(hipStreamSynchronize(stream));
+    *total_host = total;
+    if (total == 0 || capacity == 0) return 0;
+    if (total > capacity) return fail("filter_sort_results_counted: " + std::to_string(total) + " records counted, room for " + std::to_string(capacity));
+    hipLaunchKernelGGL(kb_compact_counted_full_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, lists_dev, n_pixels, L, counts_dev,
+                       totals, bases, out_dev);
+    KB_HIP_TRY(hipGetLastError());
+    KB_HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+}  // namespace kb
+
+extern "C" {
 
 int kb_merge_sparse_exact(const uint8_t* headers_dev, uint64_t header_stride, const kb_compact_result* const* packed_ptrs_host,
                           int32_t n_lists, int32_t list_len, kb_search_params params, const kb_trajectory* all_cands_dev,

@@ -19,6 +19,7 @@
 #define KBH_STACK_SEARCH_H_
 
 #include <algorithm>
+#include <cfloat>
 #include <cstring>
 #include <sstream>
 #include <chrono>
@@ -384,6 +385,7 @@ public:
             ResultBlocks& blocks = result_blocks;
             blocks.reserve(max_results * sizeof(Trajectory));
             detail::DeviceBlock &raw = blocks.raw, &kept = blocks.kept;
+            int32_t counted = 0;  // the search wrote the per-pixel counts of its survivors (single device, likelihood threshold)
             bool fan_out = search_devices.size() > 1 && !search_list.empty();
             if (fan_out && params.results_per_pixel > 32) {
                 // (the 16-byte exchange records and the merge kernels cover lists of up to 32 per pixel)
@@ -402,11 +404,24 @@ public:
                 // flag 1024: everything below min_lh is removed a few lines down (stack_search.cpp:266-270), so the kernels
                 // need not insert it in the first place -- same survivors, no list work on pixels nothing reaches
                 const uint32_t below_min_lh_dropped = 1024u;
-                check_status(kb_device_search_filter(
-                        &psi_phi_array.get_meta_data(), psi_phi_array.get_gpu_array_ptr(),
-                        psi_phi_array.get_gpu_time_array_ptr(), params,
-                        reinterpret_cast<const kb_trajectory*>(candidate_list.get_gpu_list_ptr()), candidate_list.get_size(),
-                        raw.as<kb_trajectory>(), max_results, search_flags | unchanged | below_min_lh_dropped, nullptr, &last_stats));
+                // With a likelihood threshold the search also writes, per start pixel, how many of its records pass it -- and
+                // then leaves out the record runs of waves that keep nothing --, and the filter below reads through those
+                // counts instead of walking S * K records (kb_device_search_filter_counted; include/kbmod_hip.h).
+                if (params.min_lh > -FLT_MAX && params.results_per_pixel <= 32) {
+                    blocks.reserve_counts(max_results / params.results_per_pixel);
+                    check_status(kb_device_search_filter_counted(
+                            &psi_phi_array.get_meta_data(), psi_phi_array.get_gpu_array_ptr(),
+                            psi_phi_array.get_gpu_time_array_ptr(), params,
+                            reinterpret_cast<const kb_trajectory*>(candidate_list.get_gpu_list_ptr()), candidate_list.get_size(),
+                            raw.as<kb_trajectory>(), max_results, blocks.counts.as<uint8_t>(),
+                            search_flags | unchanged | below_min_lh_dropped, nullptr, &last_stats, &counted));
+                } else {
+                    check_status(kb_device_search_filter(
+                            &psi_phi_array.get_meta_data(), psi_phi_array.get_gpu_array_ptr(),
+                            psi_phi_array.get_gpu_time_array_ptr(), params,
+                            reinterpret_cast<const kb_trajectory*>(candidate_list.get_gpu_list_ptr()), candidate_list.get_size(),
+                            raw.as<kb_trajectory>(), max_results, search_flags | unchanged | below_min_lh_dropped, nullptr, &last_stats));
+                }
                 resident_searched = psi_phi_preloaded;
                 candidate_list.move_to_cpu();
             }
@@ -418,9 +433,16 @@ public:
             DebugTimer filter_timer = DebugTimer("Filtering results by LH and min_obs", rs_logger);
             uint64_t n_kept = 0;
             int64_t first_invalid = -1;  // (the validity scan of stack_search.cpp:280 rides on the gather of the survivors)
-            check_status(kb_filter_sort_results_checked(raw.as<kb_trajectory>(), max_results, params.min_lh,
-                                                        params.min_observations, kept.as<kb_trajectory>(), &n_kept, &first_invalid,
-                                                        nullptr));
+            if (counted != 0) {
+                check_status(kb_filter_sort_results_counted(raw.as<kb_trajectory>(), max_results / params.results_per_pixel,
+                                                            (int32_t)params.results_per_pixel, blocks.counts.as<uint8_t>(),
+                                                            params.min_lh, params.min_observations, kept.as<kb_trajectory>(), &n_kept,
+                                                            &first_invalid, nullptr));
+            } else {
+                check_status(kb_filter_sort_results_checked(raw.as<kb_trajectory>(), max_results, params.min_lh,
+                                                            params.min_observations, kept.as<kb_trajectory>(), &n_kept, &first_invalid,
+                                                            nullptr));
+            }
             report_filtering(max_results, n_kept);
             filter_timer.stop();
             host_ms.filter_sort = since(t_filter);
@@ -717,8 +739,8 @@ protected:
     std::vector<int> search_devices;
     // result buffers of search_all on the home device (raw per-pixel lists, filtered + sorted survivors)
     struct ResultBlocks {
-        detail::DeviceBlock raw, kept;
-        uint64_t bytes = 0;
+        detail::DeviceBlock raw, kept, counts;
+        uint64_t bytes = 0, count_bytes = 0;
         int device = -1;  // the device the blocks live on: a later search from a thread whose current device differs gets its own
         // Blocks beyond this are returned once a search's results have reached the host (a 4096 x 4096 search keeps
         // 2 x 3.8 GB otherwise, which get_gpu_free_memory / validate_gpu would report as taken between searches).
@@ -732,12 +754,21 @@ protected:
             bytes = need;
             device = now;
         }
+        // (one byte per start pixel, on the device of the other two: call after reserve)
+        void reserve_counts(uint64_t need) {
+            if (need <= count_bytes && counts.ptr != nullptr) return;
+            if (counts.ptr != nullptr) (void)kb_free_gpu_block(counts.release());
+            check_status(kb_allocate_gpu_block(std::max<uint64_t>(need, 1), &counts.ptr));
+            count_bytes = need;
+        }
         void release() {
             const int now = kb_get_device();
             const bool elsewhere = device >= 0 && now >= 0 && device != now;
             if (elsewhere) (void)kb_set_device(device);  // a block is freed on the device it was allocated on
             if (raw.ptr != nullptr) (void)kb_free_gpu_block(raw.release());
             if (kept.ptr != nullptr) (void)kb_free_gpu_block(kept.release());
+            if (counts.ptr != nullptr) (void)kb_free_gpu_block(counts.release());
+            count_bytes = 0;
             if (elsewhere) (void)kb_set_device(now);
             bytes = 0;
             device = -1;

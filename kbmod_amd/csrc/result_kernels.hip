@@ -8,6 +8,7 @@
 // reference's unstable sort may produce); the kernels around them are ours.
 #include <algorithm>
 #include <mutex>
+#include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -390,6 +391,62 @@ void release_result_arenas() {
 namespace kb {
 static int filter_sort_impl(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs, kb_trajectory* out_dev,
                             uint64_t* n_out_host, int64_t* first_invalid_host, void* stream_v);
+static int sort_and_gather(const kb_trajectory* compact, size_t kept, uint64_t n, char* base, size_t rec_bytes, size_t tmp_all,
+                           size_t key_bytes, kb_trajectory* out_dev, int64_t* first_invalid_host, hipStream_t stream);
+// exchange_kernels.hip
+int compact_counted_full(const kb_trajectory* lists_dev, uint64_t n_pixels, int L, const uint8_t* counts_dev, kb_trajectory* out_dev,
+                         uint64_t capacity, uint64_t* total_host, hipStream_t stream);
+}
+// kb_filter_sort_results_checked for results whose search wrote the per-pixel counts (kb_device_search_filter_counted): only the
+// counted records are read -- the runs the search skipped are never touched --, and the working storage is sized by what survives.
+extern "C" int kb_filter_sort_results_counted(const kb_trajectory* results_dev, uint64_t n_pixels, int32_t list_len,
+                                              const uint8_t* counts_dev, float min_lh, int32_t min_obs, kb_trajectory* out_dev,
+                                              uint64_t* n_out_host, int64_t* first_invalid_host, void* stream_v) {
+    using namespace kb;
+    KB_REQUIRE_DEVICE("the result filter.");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (n_out_host == nullptr) return fail("filter_sort_results_counted: null count pointer");
+    *n_out_host = 0;
+    if (first_invalid_host != nullptr) *first_invalid_host = -1;
+    if (n_pixels == 0) return 0;
+    if (results_dev == nullptr || out_dev == nullptr || counts_dev == nullptr) return fail("filter_sort_results_counted: null pointer");
+    if (list_len <= 0 || list_len > 32) return fail("filter_sort_results_counted: lists of 1 to 32 records per pixel");
+    // (the counts leave out the placeholders of empty slots, which filter_by_likelihood keeps when min_lh <= -FLT_MAX)
+    if (!(min_lh > -FLT_MAX)) return fail("filter_sort_results_counted: needs a likelihood threshold above -FLT_MAX");
+    if (n_pixels * (uint64_t)list_len > 0xffffffffull) return fail("filter_sort_results_counted: more than 2^32 results");
+    uint64_t total = 0;
+    if (compact_counted_full(results_dev, n_pixels, list_len, counts_dev, nullptr, 0, &total, stream)) return 1;
+    if (total == 0) return 0;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t rec_bytes = up(total * sizeof(kb_trajectory)), key_bytes = up(total * sizeof(float));
+    const KeepPredicate pred{min_lh, min_obs};
+    size_t tmp_bytes = 0, tmp2_bytes = 0;
+    KB_HIP_TRY(rocprim::select(nullptr, tmp_bytes, results_dev, static_cast<kb_trajectory*>(nullptr), static_cast<size_t*>(nullptr),
+                               (size_t)total, pred, stream));
+    KB_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, tmp2_bytes, static_cast<float*>(nullptr), static_cast<float*>(nullptr),
+                                              static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), (size_t)total, 0, 32,
+                                              stream));
+    const size_t tmp_all = up(std::max<size_t>(std::max(tmp_bytes, tmp2_bytes), 16));
+    ArenaLock arena;
+    char* base = nullptr;
+    // [records kept | count + first-invalid words | temporary storage | 2 x keys | 2 x indices | the counted records]
+    if (arena.reserve(rec_bytes + 256 + tmp_all + 4 * key_bytes + rec_bytes, &base)) return 1;
+    kb_trajectory* compact = reinterpret_cast<kb_trajectory*>(base);
+    kb_trajectory* counted = reinterpret_cast<kb_trajectory*>(base + rec_bytes + 256 + tmp_all + 4 * key_bytes);
+    size_t kept = (size_t)total;
+    if (min_obs > 0) {
+        // (a counted record passes the likelihood test by construction; the observation count is tested here)
+        if (compact_counted_full(results_dev, n_pixels, list_len, counts_dev, counted, total, &total, stream)) return 1;
+        size_t* count = reinterpret_cast<size_t*>(base + rec_bytes);
+        KB_HIP_TRY(rocprim::select(base + rec_bytes + 256, tmp_bytes, counted, compact, count, (size_t)total, pred, stream));
+        KB_HIP_TRY(hipMemcpyAsync(&kept, count, sizeof(size_t), hipMemcpyDeviceToHost, stream));
+        KB_HIP_TRY(hipStreamSynchronize(stream));
+    } else {
+        if (compact_counted_full(results_dev, n_pixels, list_len, counts_dev, compact, total, &total, stream)) return 1;
+    }
+    *n_out_host = kept;
+    if (kept == 0) return 0;
+    return sort_and_gather(compact, kept, total, base, rec_bytes, tmp_all, key_bytes, out_dev, first_invalid_host, stream);
 }
 extern "C" int kb_filter_sort_results(const kb_trajectory* results_dev, uint64_t n, float min_lh, int32_t min_obs,
                                       kb_trajectory* out_dev, uint64_t* n_out_host, void* stream_v) {
@@ -432,10 +489,6 @@ static int kb::filter_sort_impl(const kb_trajectory* results_dev, uint64_t n, fl
     kb_trajectory* compact = reinterpret_cast<kb_trajectory*>(base);
     size_t* count = reinterpret_cast<size_t*>(base + rec_bytes);
     void* tmp = base + rec_bytes + 256;
-    float* keys_in = reinterpret_cast<float*>(base + rec_bytes + 256 + tmp_all);
-    float* keys_out = reinterpret_cast<float*>(base + rec_bytes + 256 + tmp_all + key_bytes);
-    uint32_t* idx_in = reinterpret_cast<uint32_t*>(base + rec_bytes + 256 + tmp_all + 2 * key_bytes);
-    uint32_t* idx_out = reinterpret_cast<uint32_t*>(base + rec_bytes + 256 + tmp_all + 3 * key_bytes);
 
     // ---- 1. stable compaction into a temporary ----
     KB_HIP_TRY(rocprim::select(tmp, tmp_bytes, results_dev, compact, count, (size_t)n, pred, stream));
@@ -445,6 +498,18 @@ static int kb::filter_sort_impl(const kb_trajectory* results_dev, uint64_t n, fl
     *n_out_host = kept;
     if (kept == 0) return 0;
 
+    return sort_and_gather(compact, kept, n, base, rec_bytes, tmp_all, key_bytes, out_dev, first_invalid_host, stream);
+}
+
+// Steps 2 and 3 of the filter: `kept` surviving records at `compact` (the head of the arena at `base`, laid out as in
+// filter_sort_impl for up to n records) -> sorted by likelihood, descending and stable, in out_dev.
+static int kb::sort_and_gather(const kb_trajectory* compact, size_t kept, uint64_t n, char* base, size_t rec_bytes, size_t tmp_all,
+                               size_t key_bytes, kb_trajectory* out_dev, int64_t* first_invalid_host, hipStream_t stream) {
+    void* tmp = base + rec_bytes + 256;
+    float* keys_in = reinterpret_cast<float*>(base + rec_bytes + 256 + tmp_all);
+    float* keys_out = reinterpret_cast<float*>(base + rec_bytes + 256 + tmp_all + key_bytes);
+    uint32_t* idx_in = reinterpret_cast<uint32_t*>(base + rec_bytes + 256 + tmp_all + 2 * key_bytes);
+    uint32_t* idx_out = reinterpret_cast<uint32_t*>(base + rec_bytes + 256 + tmp_all + 3 * key_bytes);
     // ---- 2. stable descending radix sort of (lh, index) ----
     const unsigned blocks = (unsigned)((kept + 255) / 256);
     hipLaunchKernelGGL(kb_extract_keys_kernel, dim3(blocks), dim3(256), 0, stream, compact, (uint64_t)kept, keys_in, idx_in);

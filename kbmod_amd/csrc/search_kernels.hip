@@ -1338,6 +1338,19 @@ int kb_device_search_counted(const kb_psi_phi_meta* meta, const void* psi_phi_de
     return rc;
 }
 
+int kb_device_search_filter_counted(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
+                                    kb_search_params params, const kb_trajectory* cands_dev, uint64_t n_cands,
+                                    kb_trajectory* results_dev, uint64_t n_results, uint8_t* counts_dev, uint32_t flags, void* stream,
+                                    kb_search_stats* stats_out, int32_t* counts_written_out) {
+    if (counts_dev == nullptr || counts_written_out == nullptr) return kb::fail("device_search_filter_counted: null pointer");
+    const kb::ResultSink sink = {results_dev, nullptr, 0, counts_dev, params.min_lh};
+    int written = 0;
+    const int rc = kb::search_filter_impl(meta, psi_phi_dev, times_dev, params, cands_dev, n_cands, sink, n_results, flags, stream,
+                                          stats_out, &written);
+    *counts_written_out = written;
+    return rc;
+}
+
 int kb_release_workspaces(void) {
     using namespace kb;
     release_result_arenas();

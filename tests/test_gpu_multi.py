@@ -423,6 +423,58 @@ def test_counted_search_writes_the_sparse_header(ds, ds_dyadic, grid, grid_dense
     assert n == total and torch.equal(packed[:total], pk_want[:total]) and torch.equal(header, h_want)
 
 
+@pytest.mark.parametrize("flags", [2, 4, 4 | 64, 4 | 128, 4 | 1024, 4 | 512 | 1024])
+@pytest.mark.parametrize("cfg", [dict(K=8, min_lh=5.0), dict(K=8, min_lh=5.0, min_obs=30), dict(K=16, min_lh=3.0),
+                                 dict(K=4, min_obs=10, min_lh=6.0), dict(K=8, min_lh=-2.0), dict(K=8, min_lh=1e9),
+                                 dict(K=1, min_lh=0.5), dict(K=32, min_lh=4.0)])
+@pytest.mark.parametrize("which", ["chunks_of_8", "wide_chunks"])
+def test_counted_filter_sort_equals_the_filter_over_every_record(ds, ds_dyadic, grid, grid_dense, which, cfg, flags):
+    """kb_device_search_filter_counted + kb_filter_sort_results_counted (what StackSearch.search_all runs for a search with a
+    likelihood threshold): the filtered, sorted trajectories are bit for bit those of kb_device_search_filter +
+    kb_filter_sort_results_checked, although the record runs of waves that keep nothing were never written (the buffer is
+    filled with NaN patterns first: a record read by mistake would surface as an invalid trajectory or a mismatch)."""
+    import ctypes as C
+
+    from kbmod_amd import capi
+
+    d, (vx, vy) = (ds, grid) if which == "chunks_of_8" else (ds_dyadic, grid_dense)
+    torch, lib = d.torch, d.lib
+    cands = d.candidates(vx, vy)
+    p = d.params(**cfg)
+    K, S = cfg["K"], d.H * d.W
+    n = S * K
+    want_raw, st0 = d.search(p, cands, flags)
+    out0 = torch.empty((n, 7), dtype=torch.float32, device="cuda")
+    cnt0, bad0 = C.c_uint64(0), C.c_int64(-2)
+    lib.kb_filter_sort_results_checked.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_uint64),
+                                                   C.POINTER(C.c_int64), C.c_void_p]
+    capi.check(lib.kb_filter_sort_results_checked(want_raw.data_ptr(), n, p.min_lh, p.min_observations, out0.data_ptr(),
+                                                  C.byref(cnt0), C.byref(bad0), None))
+    got_raw = torch.full((n, 7), float("nan"), dtype=torch.float32, device="cuda")
+    counts = torch.full((S,), 0xEE, dtype=torch.uint8, device="cuda")
+    st1, written = capi.Stats(), C.c_int32(-1)
+    capi.check(lib.kb_device_search_filter_counted(C.byref(d.meta), d.arr, d.times.data_ptr(), p, cands.data_ptr(), cands.shape[0],
+                                                   got_raw.data_ptr(), n, counts.data_ptr(), flags, d.stream, C.byref(st1),
+                                                   C.byref(written)))
+    torch.cuda.synchronize()
+    assert st0.kernel_name == st1.kernel_name
+    if not written.value:
+        assert torch.equal(got_raw.view(torch.int32), want_raw.view(torch.int32))
+        return
+    out1 = torch.full((n, 7), float("nan"), dtype=torch.float32, device="cuda")
+    cnt1, bad1 = C.c_uint64(0), C.c_int64(-2)
+    capi.check(lib.kb_filter_sort_results_counted(got_raw.data_ptr(), S, K, counts.data_ptr(), p.min_lh, p.min_observations,
+                                                  out1.data_ptr(), C.byref(cnt1), C.byref(bad1), None))
+    assert cnt1.value == cnt0.value and bad1.value == bad0.value == -1
+    k = int(cnt0.value)
+    assert torch.equal(out1[:k].view(torch.int32), out0[:k].view(torch.int32))
+    if cfg["min_lh"] >= 1e9:
+        assert k == 0 and bool(torch.isnan(got_raw).all())
+    with pytest.raises(RuntimeError, match="above -FLT_MAX"):
+        capi.check(lib.kb_filter_sort_results_counted(got_raw.data_ptr(), S, K, counts.data_ptr(), float("-inf"), 0, out1.data_ptr(),
+                                                      C.byref(cnt1), C.byref(bad1), None))
+
+
 def test_exchange_budget_tool_at_reduced_size():
     """tools/exchange_budget.py (the 8-rank exchange measured piece by piece on one GPU; DESIGN.md section 5's table) on a stack
     small enough for the suite: every rank's sparse lists merged == one search over the job-wide list after the post-filter,

@@ -1,5 +1,5 @@
 """End-to-end time of StackSearch.search_all(on_gpu=True) at cfg2 (what a caller of the pybind surface sees: search,
-filter + sort in HBM, download of the survivors into the host list)."""
+filter + sort in HBM, download of the survivors into the host list).  Other sizes: search_all_timing.py T H W VEL_STEPS ANG_STEPS."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,13 +8,14 @@ import kbmod_amd.search as kb
 from kbmod_amd import fake_data as fd
 
 rng = np.random.default_rng(1)
-T, H, W = 64, 512, 512
+T, H, W = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (64, 512, 512)
+VS, AS = (int(v) for v in sys.argv[4:6]) if len(sys.argv) > 5 else (32, 32)
 sci = (rng.standard_normal((T, H, W)) * 2).astype(np.float32)
 var = np.full((T, H, W), 4.0, dtype=np.float32)
 psf = fd.make_gaussian_kernel(1.0)
 s = kb.StackSearch.from_image_stacks(sci, var, [psf] * T, list(np.arange(T) / T))
 s.preload_psi_phi_array()
-vx, vy = fd.kbmod_v1_candidates(32, 5.0, 40.0, 32, 0.0, 1.5)
+vx, vy = fd.kbmod_v1_candidates(VS, 5.0, 40.0, AS, 0.0, 1.5)
 cands = [kb.Trajectory(0, 0, float(a), float(b)) for a, b in zip(vx, vy)]
 for min_lh in (0.0, 10.0):
     s.set_min_lh(min_lh)
