@@ -360,6 +360,12 @@ int kb_sparsify_counted(const kb_compact_result* lists_dev, uint64_t n_pixels, i
 int kb_merge_sparse_exact(const uint8_t* headers_dev, uint64_t header_stride, const kb_compact_result* const* packed_ptrs_host,
                           int32_t n_lists, int32_t list_len, kb_search_params params, const kb_trajectory* all_cands_dev,
                           uint64_t n_all_cands, kb_trajectory* out_dev, void* stream);
+/* ... with the number of merged records per start pixel to counts_out_dev[n_pixels] (they are a prefix of the pixel's K slots),
+ * and NO slot written for a wave (64 consecutive start pixels) that nothing reaches: what kb_filter_sort_results_counted reads
+ * through.  counts_out_dev = NULL: kb_merge_sparse_exact. */
+int kb_merge_sparse_exact_counted(const uint8_t* headers_dev, uint64_t header_stride, const kb_compact_result* const* packed_ptrs_host,
+                                  int32_t n_lists, int32_t list_len, kb_search_params params, const kb_trajectory* all_cands_dev,
+                                  uint64_t n_all_cands, kb_trajectory* out_dev, uint8_t* counts_out_dev, void* stream);
 
 /* ---- host instantiations of the device functions ------------------------- */
 /* kernels.cu:154-242 evaluateTrajectory called with host pointers

@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void kb_merge_sparse_exact_kernel(const uint8_
                                                                     uint64_t n_blocks, int n_lists, uint64_t n_pixels, int K2,
                                                                     int K, int sw, int x_min, int y_min,
                                                                     const kb_trajectory* __restrict__ all_cands,
-                                                                    uint64_t n_all_cands, kb_trajectory* __restrict__ out) {
+                                                                    uint64_t n_all_cands, kb_trajectory* __restrict__ out,
+                                                                    uint8_t* __restrict__ counts_out) {
     __shared__ uint32_t wave_sums[4];
     const uint64_t pix = (uint64_t)blockIdx.x * SPARSE_BLOCK + threadIdx.x;
     const bool live = pix < n_pixels;
@@ -230,6 +231,12 @@ __global__ __launch_bounds__(256) void kb_merge_sparse_exact_kernel(const uint8_
     // A wave none of whose 64 pixels is reached by any list -- nearly every wave of a thresholded search -- writes its
     // 64 x K placeholders as ONE contiguous run of 16-byte stores (the per-thread form below stores 7 dwords per slot at a
     // lane stride of K x 28 bytes: 1.7 TB/s for the 3.76 GB of a 4096 x 4096 search, where a plain fill reaches 4.5).
+    // counts_out (kb_merge_sparse_exact_counted): the number of merged records per pixel instead of the placeholders -- a wave
+    // nothing reaches writes its 64 zero bytes and no slot at all.
+    if (counts_out != nullptr && __ballot(any != 0) == 0ull) {
+        if (live) counts_out[pix] = 0;
+        return;
+    }
     if (__ballot(any != 0) == 0ull && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
         const int lane = threadIdx.x & 63;
         const uint32_t n_live = (uint32_t)__popcll(__ballot(live));          // (live lanes are a prefix of the wave)
@@ -278,6 +285,7 @@ __global__ __launch_bounds__(256) void kb_merge_sparse_exact_kernel(const uint8_
     kb_trajectory* dst = out + pix * (uint64_t)K;
     if (any == 0) {  // an empty pixel in a wave that holds a reached one
         for (int s = 0; s < K; ++s) dst[s] = empty;
+        if (counts_out != nullptr) counts_out[pix] = 0;
         return;
     }
     auto read = [&](int r, int pos) {
@@ -299,6 +307,7 @@ __global__ __launch_bounds__(256) void kb_merge_sparse_exact_kernel(const uint8_
     int heads[SPARSE_MAX_LISTS];
     int slots[MERGE_EXACT_MAX_K2];
     const int n_out = merge_exact_pixel(read, n_lists, K2, K, merged, heads, slots);
+    int n_valid = 0;  // (the merged list is filled from the top: the valid slots are a prefix)
     for (int s = 0; s < K; ++s) {
         kb_trajectory res = empty;
         if (s < n_out && slots[s] >= 0) {
@@ -310,10 +319,12 @@ __global__ __launch_bounds__(256) void kb_merge_sparse_exact_kernel(const uint8_
                 res.lh = rec.lh;
                 res.flux = rec.flux;
                 res.obs_count = rec.obs_count;
+                n_valid = (n_valid == s) ? s + 1 : n_valid;
             }
         }
         dst[s] = res;
     }
+    if (counts_out != nullptr) counts_out[pix] = (uint8_t)n_valid;
 }
 
 // ---- scratch (block totals and bases), one arena per device, kept between calls ----
@@ -499,6 +510,13 @@ extern "C" {
 int kb_merge_sparse_exact(const uint8_t* headers_dev, uint64_t header_stride, const kb_compact_result* const* packed_ptrs_host,
                           int32_t n_lists, int32_t list_len, kb_search_params params, const kb_trajectory* all_cands_dev,
                           uint64_t n_all_cands, kb_trajectory* out_dev, void* stream_v) {
+    return kb_merge_sparse_exact_counted(headers_dev, header_stride, packed_ptrs_host, n_lists, list_len, params, all_cands_dev,
+                                         n_all_cands, out_dev, nullptr, stream_v);
+}
+
+int kb_merge_sparse_exact_counted(const uint8_t* headers_dev, uint64_t header_stride, const kb_compact_result* const* packed_ptrs_host,
+                                  int32_t n_lists, int32_t list_len, kb_search_params params, const kb_trajectory* all_cands_dev,
+                                  uint64_t n_all_cands, kb_trajectory* out_dev, uint8_t* counts_out_dev, void* stream_v) {
     using namespace kb;
     if (headers_dev == nullptr || packed_ptrs_host == nullptr || out_dev == nullptr || all_cands_dev == nullptr) {
         return fail("merge_sparse_exact: null pointer");
@@ -538,11 +556,11 @@ int kb_merge_sparse_exact(const uint8_t* headers_dev, uint64_t header_stride, co
     if (n_lists <= 8) {
         hipLaunchKernelGGL(kb_merge_sparse_exact_kernel<8>, dim3((unsigned)n_blocks), dim3(256), 0, stream, headers_dev,
                            header_stride, lists, bases, n_blocks, (int)n_lists, n_pixels, (int)list_len, K, (int)sw,
-                           params.x_start_min, params.y_start_min, all_cands_dev, n_all_cands, out_dev);
+                           params.x_start_min, params.y_start_min, all_cands_dev, n_all_cands, out_dev, counts_out_dev);
     } else {
         hipLaunchKernelGGL(kb_merge_sparse_exact_kernel<SPARSE_MAX_LISTS>, dim3((unsigned)n_blocks), dim3(256), 0, stream,
                            headers_dev, header_stride, lists, bases, n_blocks, (int)n_lists, n_pixels, (int)list_len, K, (int)sw,
-                           params.x_start_min, params.y_start_min, all_cands_dev, n_all_cands, out_dev);
+                           params.x_start_min, params.y_start_min, all_cands_dev, n_all_cands, out_dev, counts_out_dev);
     }
     KB_HIP_TRY(hipGetLastError());
     KB_HIP_TRY(hipStreamSynchronize(stream));  // the scratch is free for the next call when this one returns

@@ -395,7 +395,12 @@ public:
                 fan_out = false;
             }
             if (fan_out) {
-                search_on_devices(candidate_list, raw.as<kb_trajectory>(), max_results);
+                // (what the parts send home has passed min_lh already -- the sparse exchange --, so the merged lists hold nothing
+                // else and their lengths are the counts the filter below reads through)
+                const bool want_counts = params.min_lh > -FLT_MAX && params.results_per_pixel <= 16;
+                if (want_counts) blocks.reserve_counts(max_results / params.results_per_pixel);
+                search_on_devices(candidate_list, raw.as<kb_trajectory>(), max_results,
+                                  want_counts ? blocks.counts.as<uint8_t>() : nullptr, &counted);
             } else {
                 candidate_list.move_to_gpu();
                 // flag 256: this object owns the array and has not touched it since its last search on the device
@@ -592,7 +597,11 @@ protected:
     // insertion (flag 512) and kb_merge_compact_exact replays the reference's insertion -- the result equals the
     // single-device search, ties included.  Longer lists (17 .. 32) take the plain merge (ties to the lower
     // candidate index: same likelihoods per slot, possibly another member of a tie), which is logged.
-    void search_on_devices(TrajectoryList& candidates, kb_trajectory* merged, uint64_t max_results) {
+    // merged_counts (may be null): where the tie-exact merge leaves the number of merged records per start pixel -- it then
+    // writes no slot for a wave nothing reaches (kb_merge_sparse_exact_counted); *counted says whether it did.
+    void search_on_devices(TrajectoryList& candidates, kb_trajectory* merged, uint64_t max_results, uint8_t* merged_counts = nullptr,
+                           int32_t* counted = nullptr) {
+        if (counted != nullptr) *counted = 0;
         const int home = kb_get_device();
         const int n_parts = (int)search_devices.size();
         const std::vector<Trajectory>& cands = candidates.get_list();
@@ -704,9 +713,10 @@ protected:
         check_status(kb_set_device(home));
         for (const std::string& e : errors) detail::require(e.empty(), e);
         if (exact) {
-            check_status(kb_merge_sparse_exact(headers.as<const uint8_t>(), header_bytes, packed_ptrs.data(), n_parts,
-                                               (int32_t)part_params.results_per_pixel, params,
-                                               all_cands.as<const kb_trajectory>(), n, merged, nullptr));
+            check_status(kb_merge_sparse_exact_counted(headers.as<const uint8_t>(), header_bytes, packed_ptrs.data(), n_parts,
+                                                       (int32_t)part_params.results_per_pixel, params,
+                                                       all_cands.as<const kb_trajectory>(), n, merged, merged_counts, nullptr));
+            if (counted != nullptr && merged_counts != nullptr) *counted = 1;
         } else {
             check_status(kb_merge_compact(gathered.as<const kb_compact_result>(), n_parts, params,
                                           all_cands.as<const kb_trajectory>(), n, merged, nullptr));

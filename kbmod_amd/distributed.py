@@ -237,11 +237,14 @@ def sparse_totals(headers, n_pixels):
     return headers[:, at:at + 8].contiguous().cpu().view(headers.shape[0], 8).numpy().view(np.int64).reshape(-1)
 
 
-def merge_sparse_exact(headers, packed_list, x_bounds, y_bounds, K, list_len, all_cands, out=None):
+def merge_sparse_exact(headers, packed_list, x_bounds, y_bounds, K, list_len, all_cands, out=None, counts_out=None):
     """Tie-exact merge over sparse lists: ``headers`` uint8 [n_lists, header_bytes] (one gather of the ranks' headers),
     ``packed_list[r]`` int32 [total_r, 4] -> [S*K, 7] trajectories: wherever a record survives the likelihood filter they
     equal ``merge_compact_exact`` on the dense lists (hence the single-device search), every other slot is the empty-slot
-    placeholder.  Device tensors: kb_merge_sparse_exact; CPU tensors: its host twin."""
+    placeholder.  Device tensors: kb_merge_sparse_exact; CPU tensors: its host twin.  ``counts_out`` (device only): a uint8
+    tensor [n_pixels] that receives the number of merged records per start pixel -- a prefix of its K slots --, and then NO
+    slot is written for a wave of 64 start pixels nothing reaches (kb_merge_sparse_exact_counted: what
+    kb_filter_sort_results_counted reads through)."""
     import torch
 
     n_lists = int(headers.shape[0])
@@ -264,14 +267,20 @@ def merge_sparse_exact(headers, packed_list, x_bounds, y_bounds, K, list_len, al
 
         lib = device_lib()
         ptrs = (C.c_void_p * n_lists)(*[(p.data_ptr() if p.shape[0] else None) for p in packed_list])
-        rc = lib.kb_merge_sparse_exact(headers.data_ptr(), int(headers.shape[1]), ptrs, n_lists, int(list_len),
-                                       _bounds(x_bounds, y_bounds, K), all_cands.data_ptr(), all_cands.shape[0], out.data_ptr(),
-                                       torch.cuda.current_stream().cuda_stream)
+        if counts_out is not None and not (counts_out.dtype == torch.uint8 and counts_out.numel() == n_pixels
+                                           and counts_out.is_contiguous() and counts_out.device == headers.device):
+            raise ValueError(f"counts_out: expected a contiguous uint8 tensor of {n_pixels} bytes on the headers' device")
+        rc = lib.kb_merge_sparse_exact_counted(headers.data_ptr(), int(headers.shape[1]), ptrs, n_lists, int(list_len),
+                                               _bounds(x_bounds, y_bounds, K), all_cands.data_ptr(), all_cands.shape[0],
+                                               out.data_ptr(), None if counts_out is None else counts_out.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError(lib.kb_last_error().decode())
     else:
         import kbmod_amd.search as kb
 
+        if counts_out is not None:
+            raise ValueError("counts_out: the host twin of the merge writes every slot")
         cands = [kb.Trajectory(vx=float(v[0]), vy=float(v[1])) for v in all_cands.numpy()]
         res = kb.merge_sparse_exact_host(np.ascontiguousarray(headers.numpy()).reshape(-1), int(headers.shape[1]),
                                          [np.ascontiguousarray(p.numpy()).view(np.uint8).reshape(-1) for p in packed_list],
@@ -282,13 +291,14 @@ def merge_sparse_exact(headers, packed_list, x_bounds, y_bounds, K, list_len, al
 
 
 def gather_and_merge_sparse(local_records, x_bounds, y_bounds, K, list_len, min_lh, all_cands, group=None, out=None, dst=0,
-                            header=None, packed=None, stats=None, counted=False):
+                            header=None, packed=None, stats=None, counted=False, counts_out=None):
     """The exchange step in its sparse form: sparsify on every rank, ONE gather of the headers to global rank ``dst``, one
     point-to-point message per rank with exactly the records its header announced (all of them in flight together: seven
     transfers into the root, each on its own xGMI link), and the tie-exact merge there.  Returns the merged [S*K, 7]
     trajectories on rank ``dst`` and **None on every other rank**.  ``stats``: a dict that receives ``wire_bytes`` (what this
     rank sent: header + records) and, on the root, ``totals``.  ``counted``: this rank's search wrote the count bytes into
-    ``header`` itself (kb_device_search_counted said so) -- :func:`sparsify_counted` finishes the header and packs."""
+    ``header`` itself (kb_device_search_counted said so) -- :func:`sparsify_counted` finishes the header and packs.
+    ``counts_out``: see :func:`merge_sparse_exact` (the root's merge then skips the slots of waves nothing reaches)."""
     import torch
     import torch.distributed as dist
 
@@ -328,7 +338,7 @@ def gather_and_merge_sparse(local_records, x_bounds, y_bounds, K, list_len, min_
     if via_host:
         headers = headers.to(local_records.device)
         bufs = [b.to(local_records.device) for b in bufs]
-    return merge_sparse_exact(headers, bufs, x_bounds, y_bounds, K, list_len, all_cands, out)
+    return merge_sparse_exact(headers, bufs, x_bounds, y_bounds, K, list_len, all_cands, out, counts_out=counts_out)
 
 
 def _check_out(out, n_pixels, K, device):

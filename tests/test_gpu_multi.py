@@ -322,6 +322,35 @@ def test_sparse_exchange_kernels(kb, ds, grid, world, cfg):
         else:
             assert int((want[:, 2] != float(EMPTY)).sum()) == 0  # nothing survives: every count is zero, every slot a placeholder
     assert torch.equal(merged.view(torch.int32), want.view(torch.int32))
+    # the counted form: the merged lists' lengths next to them, no slot written for a wave nothing reaches -- and the filter
+    # that reads through the counts returns what the filter over every slot returns
+    import ctypes as C
+
+    from kbmod_amd import capi
+
+    counts = torch.full((S,), 0xEE, dtype=torch.uint8, device="cuda")
+    out_c = torch.full((S * K, 7), float("nan"), dtype=torch.float32, device="cuda")
+    kdist.merge_sparse_exact(headers, packed, (0, ds.W), (0, ds.H), K, 2 * K, all_cands, out=out_c, counts_out=counts)
+    n_valid = (want[:, 2] != float(EMPTY)).view(S, K).sum(dim=1)
+    assert torch.equal(counts.to(torch.int64), n_valid)
+    covered = torch.arange(K, device="cuda").repeat(S) < n_valid.repeat_interleave(K)
+    same_row = (out_c.view(torch.int32) == want.view(torch.int32)).all(dim=1)
+    assert bool(same_row[covered].all()) and bool((same_row | torch.isnan(out_c).all(dim=1)).all())
+    with pytest.raises(ValueError, match="host twin"):
+        kdist.merge_sparse_exact(headers.cpu(), [q.cpu() for q in packed], (0, ds.W), (0, ds.H), K, 2 * K, all_cands.cpu(),
+                                 counts_out=counts.cpu())
+    if min_lh is not None and min_lh > -1e30:
+        lib = ds.lib
+        res = [torch.empty((S * K, 7), dtype=torch.float32, device="cuda") for _ in range(2)]
+        cnt, bad = [C.c_uint64(0), C.c_uint64(0)], [C.c_int64(-2), C.c_int64(-2)]
+        lib.kb_filter_sort_results_checked.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_uint64),
+                                                       C.POINTER(C.c_int64), C.c_void_p]
+        capi.check(lib.kb_filter_sort_results_checked(want.data_ptr(), S * K, min_lh, p.min_observations, res[0].data_ptr(),
+                                                      C.byref(cnt[0]), C.byref(bad[0]), None))
+        capi.check(lib.kb_filter_sort_results_counted(out_c.data_ptr(), S, K, counts.data_ptr(), min_lh, p.min_observations,
+                                                      res[1].data_ptr(), C.byref(cnt[1]), C.byref(bad[1]), None))
+        assert cnt[0].value == cnt[1].value and bad[0].value == bad[1].value == -1
+        assert torch.equal(res[0][:cnt[0].value].view(torch.int32), res[1][:cnt[1].value].view(torch.int32))
 
 
 @pytest.mark.parametrize("world", [2, 5])

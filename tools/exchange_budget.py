@@ -136,6 +136,13 @@ def main():
     merge_sparse_ms = timed(lambda: kdist.merge_sparse_exact(headers, packed, (0, W), (0, H), K, L, all_cands, out=results),
                             args.reps)
     merged = results.clone()
+    # ... and with the merged lists' lengths written next to them: no slot is written for a wave nothing reaches
+    # (kb_merge_sparse_exact_counted: what StackSearch.search_all's filter reads through behind a multi-device search)
+    merged_counts = torch.empty(S, dtype=torch.uint8, device=dev)
+    results.fill_(float("nan"))
+    merge_counted_ms = timed(lambda: kdist.merge_sparse_exact(headers, packed, (0, W), (0, H), K, L, all_cands, out=results,
+                                                              counts_out=merged_counts), args.reps)
+    merged_c = results.clone()
     merge_dense_ms = None
     if args.dense:
         gathered = torch.stack(dense_lists)
@@ -159,7 +166,15 @@ def main():
     single[gone, 3] = 0.0
     single.view(torch.int32)[gone, 6] = 0
     ok = bool(torch.equal(merged.view(torch.int32), single.view(torch.int32)))
-    del single
+    # the counted merge: the counts are the survivors per pixel, every counted slot is the single search's, the rest is either
+    # the placeholder or untouched
+    want_counts = (~gone).view(S, K).sum(dim=1).to(torch.uint8)
+    covered = (torch.arange(K, device=dev).repeat(S) < merged_counts.to(torch.int64).repeat_interleave(K))
+    untouched = torch.isnan(merged_c).all(dim=1)
+    same_row = (merged_c.view(torch.int32) == single.view(torch.int32)).all(dim=1)
+    ok_counted = bool(torch.equal(merged_counts, want_counts)) and bool(same_row[covered].all()) and bool((same_row | untouched).all())
+    ok = ok and ok_counted
+    del single, covered, untouched, same_row
 
     # the single-GPU step of the weak-scaling series: n_local candidates, K records per pixel, the reference's insertion
     st0 = Stats()
@@ -189,16 +204,17 @@ def main():
         "counted_search": bool(args.counted),
         "per_rank": {"search_call_ms": search_ms, "search_kernel_ms": kernel_ms, "sparsify_ms": sparsify_ms, "wire_bytes": wire,
                      "dense_wire_bytes": dense_bytes},
-        "root": {"merge_sparse_ms": merge_sparse_ms, "merge_dense_ms": merge_dense_ms,
+        "root": {"merge_sparse_ms": merge_sparse_ms, "merge_sparse_counted_ms": merge_counted_ms, "merge_dense_ms": merge_dense_ms,
                  "merge_sparse_reads_bytes": int(sum(wire)), "merge_dense_reads_bytes": dense_bytes * world,
                  "merge_writes_bytes": S * K * 28},
-        "verify": {"merged_equals_single_device_after_post_filter_ok": ok, "survivors": survivors},
+        "verify": {"merged_equals_single_device_after_post_filter_ok": ok, "counted_merge_ok": ok_counted, "survivors": survivors},
         "single_gpu": {"step_ms": single_gpu_ms, "kernel_ms": float(st0.search_kernel_ms), "kernel": st0.kernel_name.decode(),
                        "step_ms_with_list_floor": single_gpu_floor_ms, "job_wide_list_on_one_gpu_ms": one_all_ms},
         "predicted_no_overlap": {
             "xgmi_link_GBps": XGMI_LINK_GBPS,
             "wire_ms_sparse": wire_ms_sparse, "wire_ms_dense": wire_ms_dense,
             "step_ms_sparse": step_sparse,
+            "step_ms_sparse_counted_merge": rank_ms + wire_ms_sparse + merge_counted_ms,
             "step_ms_dense": None if merge_dense_ms is None else max(search_ms) + wire_ms_dense + merge_dense_ms,
             "aggregate_vs_one_gpu_sparse": world * single_gpu_ms / step_sparse,
             "aggregate_vs_one_gpu_with_list_floor_sparse": world * single_gpu_floor_ms / step_sparse,
