@@ -1208,9 +1208,11 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     }
 
     // ResultSink::counts is honoured by the epilogues of kb_search_lds with packed or pooled lists only: any other instance
-    // writes every slot and leaves the counts to the caller (kb_device_search_counted then counts them from the records).
-    const bool counts_ok = sink.counts != nullptr && which == 2 && !sigmag && a.K <= 32 && (list_mode == 3 || list_mode == 4);
-    if (!counts_ok) cold.results.counts = nullptr;
+    // writes every slot and leaves the counts to the caller (kb_sparsify_compact then counts them from the records).
+    // With the in-search sigma-G filter the lists are written by kb_sigmag_select_kernel, which honours it for its last batch.
+    const bool counts_ok = sink.counts != nullptr && a.K <= 32 &&
+                           (sigmag || (which == 2 && (list_mode == 3 || list_mode == 4)));
+    if (!counts_ok || sigmag) cold.results.counts = nullptr;
     if (counts_written != nullptr) *counts_written = counts_ok ? 1 : 0;
     KB_HIP_TRY(hipMemcpyAsync(cold_dev, &cold, sizeof(SearchCold), hipMemcpyHostToDevice, stream));
 
@@ -1245,7 +1247,10 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
             if (a.chunk_lo < a.chunk_hi) launch_search(a, fmt, true, which, lds_rows, 0, stream);  // the emitting instances keep no list
             KB_HIP_TRY(hipGetLastError());
             const ResultSink* next = &bufs[(n_batches - 1 - b) % 2];
-            if (launch_sigmag_resolve(a, cold, prev, *next, resolve_waves, stream)) return 1;
+            // (the lists of a batch that another one follows are read back slot by slot: only the last may leave runs unwritten)
+            ResultSink next_sink = *next;
+            next_sink.counts = (counts_ok && b == n_batches - 1) ? sink.counts : nullptr;
+            if (launch_sigmag_resolve(a, cold, prev, next_sink, resolve_waves, stream)) return 1;
             prev = next;
         }
         variant = a.K <= 8 ? 8 : (a.K <= 16 ? 16 : 32);

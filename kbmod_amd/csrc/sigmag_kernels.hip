@@ -460,6 +460,13 @@ __global__ __launch_bounds__(256) void kb_sigmag_select_kernel(const ResolveArgs
         }
     }
 
+    if (a.next.counts != nullptr) {  // (uniform) ResultSink::counts: every entry of a list has passed min_lh -- its length is the count
+        int filled = 0;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) filled += (k < a.K && top.id[k] != -1) ? 1 : 0;
+        if (live) a.next.counts[pixel] = (uint8_t)filled;
+        if (__ballot(live && filled != 0) == 0ull) return;  // ... and a row of 64 empty lists writes no slot
+    }
     if (!live) return;
     const int x = x_i + a.params.x_start_min, y = ty + a.params.y_start_min;
     for (int s = 0; s < a.K; ++s) {

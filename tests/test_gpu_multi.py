@@ -414,7 +414,8 @@ def test_list_floor_flag_keeps_every_survivor(ds, ds_dyadic, grid, grid_dense, w
 
 @pytest.mark.parametrize("flags", [2, 4, 4 | 64, 4 | 128, 4 | 512, 4 | 512 | 1024, 4 | 1024])
 @pytest.mark.parametrize("cfg", [dict(K=8, min_lh=5.0), dict(K=16, min_lh=3.0), dict(K=4, min_obs=10, min_lh=6.0),
-                                 dict(K=32, min_lh=4.0), dict(K=8, min_lh=-2.0), dict(K=8, min_lh=1e9)])
+                                 dict(K=32, min_lh=4.0), dict(K=8, min_lh=-2.0), dict(K=8, min_lh=1e9),
+                                 dict(K=4, min_obs=8, sigmag=(0.25, 0.75, 0.7413, 3.0)), dict(K=8, sigmag=(0.25, 0.75, 0.7413, 6.0))])
 @pytest.mark.parametrize("which", ["chunks_of_8", "wide_chunks"])
 def test_counted_search_writes_the_sparse_header(ds, ds_dyadic, grid, grid_dense, which, cfg, flags):
     """kb_device_search_counted: the count bytes the search writes are the ones kb_sparsify_compact counts from the full
@@ -429,7 +430,7 @@ def test_counted_search_writes_the_sparse_header(ds, ds_dyadic, grid, grid_dense
     p = d.params(**cfg)
     K, S = cfg["K"], d.H * d.W
     want, st0 = d.search_compact(p, cands, 7, flags)
-    h_want, pk_want, total = kdist.sparsify_compact(want, S, K, cfg["min_lh"])
+    h_want, pk_want, total = kdist.sparsify_compact(want, S, K, float(p.min_lh))
     POISON = 0x5a5a5a5a
     got, header, written, st1 = d.search_counted(p, cands, 7, flags, poison=POISON)
     assert st0.kernel_name == st1.kernel_name
@@ -455,7 +456,8 @@ def test_counted_search_writes_the_sparse_header(ds, ds_dyadic, grid, grid_dense
 @pytest.mark.parametrize("flags", [2, 4, 4 | 64, 4 | 128, 4 | 1024, 4 | 512 | 1024])
 @pytest.mark.parametrize("cfg", [dict(K=8, min_lh=5.0), dict(K=8, min_lh=5.0, min_obs=30), dict(K=16, min_lh=3.0),
                                  dict(K=4, min_obs=10, min_lh=6.0), dict(K=8, min_lh=-2.0), dict(K=8, min_lh=1e9),
-                                 dict(K=1, min_lh=0.5), dict(K=32, min_lh=4.0)])
+                                 dict(K=1, min_lh=0.5), dict(K=32, min_lh=4.0),
+                                 dict(K=4, min_obs=8, sigmag=(0.25, 0.75, 0.7413, 3.0)), dict(K=8, sigmag=(0.25, 0.75, 0.7413, 6.0))])
 @pytest.mark.parametrize("which", ["chunks_of_8", "wide_chunks"])
 def test_counted_filter_sort_equals_the_filter_over_every_record(ds, ds_dyadic, grid, grid_dense, which, cfg, flags):
     """kb_device_search_filter_counted + kb_filter_sort_results_counted (what StackSearch.search_all runs for a search with a
@@ -497,7 +499,7 @@ def test_counted_filter_sort_equals_the_filter_over_every_record(ds, ds_dyadic, 
     assert cnt1.value == cnt0.value and bad1.value == bad0.value == -1
     k = int(cnt0.value)
     assert torch.equal(out1[:k].view(torch.int32), out0[:k].view(torch.int32))
-    if cfg["min_lh"] >= 1e9:
+    if cfg.get("min_lh", 0) >= 1e9:
         assert k == 0 and bool(torch.isnan(got_raw).all())
     with pytest.raises(RuntimeError, match="above -FLT_MAX"):
         capi.check(lib.kb_filter_sort_results_counted(got_raw.data_ptr(), S, K, counts.data_ptr(), float("-inf"), 0, out1.data_ptr(),

@@ -17,8 +17,11 @@ s = kb.StackSearch.from_image_stacks(sci, var, [psf] * T, list(np.arange(T) / T)
 s.preload_psi_phi_array()
 vx, vy = fd.kbmod_v1_candidates(VS, 5.0, 40.0, AS, 0.0, 1.5)
 cands = [kb.Trajectory(0, 0, float(a), float(b)) for a, b in zip(vx, vy)]
-for min_lh in (0.0, 10.0):
-    s.set_min_lh(min_lh)
+for min_lh in (0.0, 10.0, "sigmag 10"):
+    if isinstance(min_lh, str):
+        s.enable_gpu_sigmag_filter([0.25, 0.75], 0.7413, 10.0)  # the in-search sigma-G filter (BASELINE configs[2])
+    else:
+        s.set_min_lh(min_lh)
     for rep in range(4):
         t0 = time.perf_counter()
         s.search_all(cands, True)
