@@ -453,6 +453,36 @@ def test_counted_search_writes_the_sparse_header(ds, ds_dyadic, grid, grid_dense
     assert n == total and torch.equal(packed[:total], pk_want[:total]) and torch.equal(header, h_want)
 
 
+def test_counted_sigmag_search_in_batches(ds_dyadic, grid_dense, monkeypatch):
+    """The in-search sigma-G filter with its work-item store capped so that the candidates go in several batches: only the
+    LAST batch's select kernel may leave rows unwritten (the lists of the others are read back slot by slot), and the counts
+    are those of the finished lists."""
+    from kbmod_amd import distributed as kdist
+
+    d, (vx, vy) = ds_dyadic, grid_dense
+    torch = d.torch
+    monkeypatch.setenv("KBMOD_SIGMAG_CAP", "4000")
+    cands = d.candidates(vx, vy)
+    p = d.params(K=8, sigmag=(0.25, 0.75, 0.7413, 6.0))
+    S = d.H * d.W
+    want, st0 = d.search_compact(p, cands, 0, 4)
+    assert st0.num_search_launches > 3  # (three launches per batch)
+    h_want, pk_want, total = kdist.sparsify_compact(want, S, 8, float(p.min_lh))
+    got, header, written, st1 = d.search_counted(p, cands, 0, 4, poison=0x5a5a5a5a)
+    assert written == 1 and st1.num_search_launches == st0.num_search_launches and 0 < total < S * 8
+    assert torch.equal(header[:S], h_want[:S])
+    packed = torch.empty((total, 4), dtype=torch.int32, device=got.device)
+    _, _, n = kdist.sparsify_counted(got, S, 8, header, packed)
+    assert n == total and torch.equal(packed, pk_want[:total]) and torch.equal(header, h_want)
+    # a row of 64 start pixels that keeps nothing was not written at all
+    W = d.W
+    for y in range(d.H):
+        for x0 in range(0, W, 64):
+            px = slice(y * W + x0, y * W + min(W, x0 + 64))
+            if int(header[px].sum()) == 0:
+                assert bool((got.view(S, 8 * 4)[px] == 0x5a5a5a5a).all())
+
+
 @pytest.mark.parametrize("flags", [2, 4, 4 | 64, 4 | 128, 4 | 1024, 4 | 512 | 1024])
 @pytest.mark.parametrize("cfg", [dict(K=8, min_lh=5.0), dict(K=8, min_lh=5.0, min_obs=30), dict(K=16, min_lh=3.0),
                                  dict(K=4, min_obs=10, min_lh=6.0), dict(K=8, min_lh=-2.0), dict(K=8, min_lh=1e9),
