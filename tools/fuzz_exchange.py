@@ -68,8 +68,19 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         want[gone, 3] = 0.0
         want.view(tt.int32)[gone, 6] = 0
         ok = ok and tt.equal(merged.view(tt.int32), want.view(tt.int32))
+        # the counted merge: list lengths per pixel, every counted slot the single search's, the rest placeholder or untouched
+        S = H * W
+        counts = tt.full((S,), 0xEE, dtype=tt.uint8, device="cuda")
+        out_c = tt.full((S * K, 7), float("nan"), dtype=tt.float32, device="cuda")
+        kdist.merge_sparse_exact(tt.stack(headers), packed, (0, W), (0, H), K, 2 * K, all_cands, out=out_c, counts_out=counts)
+        n_valid = (want[:, 2] != float(EMPTY)).view(S, K).sum(dim=1)
+        covered = tt.arange(K, device="cuda").repeat(S) < n_valid.repeat_interleave(K)
+        same_row = (out_c.view(tt.int32) == want.view(tt.int32)).all(dim=1)
+        ok_c = tt.equal(counts.to(tt.int64), n_valid) and bool(same_row[covered].all()) and bool((same_row | tt.isnan(out_c).all(dim=1)).all())
         if not ok:
             bad.append(seed)
+        if not ok_c:
+            bad.append(("counted merge", seed))
     finally:
         d.close()
 print("seeds", sys.argv[1], sys.argv[2], "mismatches", bad, "counted searches", n_counted)
