@@ -71,14 +71,27 @@ struct Samples {
 // run of equal ratios mixes different (psi, phi) pairs: the exchange sort's own order then matters
 // and the caller runs the literal code for that lane.
 // *lh_out / *flux_out receive the two clipped SUMS (psi, phi); the caller divides (once per work item).
+// keep (may be null): instead of chaining the sums across the lanes, hand the sorted samples (lane i: the i-th smallest ratio's
+// pair) and the range [keep->lo, keep->hi] of sorted positions to add back to the caller, which sums a batch of trajectories
+// with one lane each (kb_sigmag_clip_kernel).
+struct KeepRange {
+    float spsi, sphi;  // per lane
+    int lo, hi;        // uniform; lo > hi: nothing to add (the sums are 0)
+};
 __device__ __forceinline__ bool clip_wave(const ResolveArgs& a, int lane, const Samples s, float* lh_out, float* flux_out,
-                                          int* obs_out) {
+                                          int* obs_out, KeepRange* keep = nullptr) {
     const bool valid = __builtin_isfinite(s.psi) && __builtin_isfinite(s.phi);
     const int n = __popcll(__ballot(valid));
     *obs_out = n;
     if (n == 0) {  // kernels.cu:201: nothing to clip, the unclipped values stand
         *lh_out = 0.0f;  // sums (0, 0): lh_from_sums / flux_from_sums give the -1 of kernels.cu:201
         *flux_out = 0.0f;
+        if (keep != nullptr) {
+            keep->spsi = 0.0f;
+            keep->sphi = 0.0f;
+            keep->lo = 1;
+            keep->hi = 0;
+        }
         return true;
     }
     const float lc = valid ? ((s.phi != 0.0f) ? (s.psi / s.phi) : 0.0f) : 0.0f;
@@ -120,6 +133,15 @@ __device__ __forceinline__ bool clip_wave(const ResolveArgs& a, int lane, const 
     const int upto = __popcll(__ballot((lane < n) && (sv <= max_value)));
     const int min_keep = min(below, median_ind);
     const int max_keep = max(median_ind + 1, upto) - 1;
+    if (keep != nullptr) {
+        keep->spsi = spsi;
+        keep->sphi = sphi;
+        keep->lo = min_keep;
+        keep->hi = max_keep;
+        *lh_out = 0.0f;
+        *flux_out = 0.0f;
+        return true;
+    }
     // ((0 + v[min_keep]) + v[min_keep + 1]) + ... + v[max_keep], chained across the lanes
     // One v_add_f32_dpp per sum and step (written out: from chain_add the compiler makes two DPP moves and a packed add,
     // 16 cycles of the vector unit per step instead of 8, and a scalar loop of three more instructions around them -- the
@@ -262,6 +284,7 @@ __device__ __forceinline__ bool clip_wave_multi(const ResolveArgs& a, int lane, 
 }
 
 constexpr int CLIP_BLOCK = 256;
+constexpr int CLIP_BATCH = 16;  // trajectories whose kept samples are added up side by side (8.3 KB of LDS per wave)
 
 // E: epochs per lane of the cooperative clip (1: up to 64 epochs, 2: up to 128, 4: up to 256); beyond 64 * E epochs
 // every trajectory takes the literal per-lane code.
@@ -277,6 +300,43 @@ __global__ __launch_bounds__(CLIP_BLOCK) void kb_sigmag_clip_kernel(const Resolv
     for (int s = 0; s < E; ++s) tm[s] = (s * WAVE + lane < a.T) ? a.times[s * WAVE + lane] : 0.0;
     const SigmaGScratch<WAVE> scratch = make_scratch(a.sg_scratch, a.T, (size_t)wave, lane);
 
+    // T <= 64: the sums of the kept samples -- ((0 + v[lo]) + v[lo + 1]) + ... in sorted order, one add after the other like the
+    // reference's loop -- are not chained across the lanes trajectory by trajectory (every step of that chain is a wave-wide
+    // instruction of which one lane's result counts: a third of this kernel's instructions) but in batches: a trajectory's sorted
+    // pairs go to a row of LDS, and when CLIP_BATCH rows are filled, lane r adds up row r, sixteen chains side by side.
+    // Adding +0 for a position outside [lo, hi] changes nothing: a sum that starts at +0 is never -0.
+    __shared__ float2 batch_rows[CLIP_BLOCK / WAVE][E == 1 ? CLIP_BATCH : 1][WAVE + 1];  // (+1: sixteen lanes, sixteen pairs of banks)
+    float2(*rows)[WAVE + 1] = batch_rows[threadIdx.x >> 6];
+    int b_lo = 1, b_hi = 0, b_obs = 0;  // of the trajectory in row `lane`
+    size_t b_dest = 0;                  // where its results go
+    int n_batched = 0;                  // (uniform) rows filled
+    auto flush_batch = [&]() {
+        if (n_batched == 0) return;
+        __builtin_amdgcn_wave_barrier();  // (the rows were written by this wave's own lanes)
+        const bool mine = lane < n_batched;
+        const int lo = mine ? b_lo : 1, hi = mine ? b_hi : 0;
+        const int from = wave_min_i32(mine ? lo : WAVE), to = wave_max_i32(mine ? hi : -1);  // (uniform) the positions anybody adds
+        float acc_psi = 0.0f, acc_phi = 0.0f;
+        const float2* row = rows[mine ? lane : 0];
+        for (int i = from; i <= to; i += 4) {
+            float2 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = row[min(i + j, WAVE - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = (unsigned)(i + j - lo) <= (unsigned)(hi - lo) && hi >= lo;
+                acc_psi += in ? v[j].x : 0.0f;
+                acc_phi += in ? v[j].y : 0.0f;
+            }
+        }
+        if (mine) {
+            a.sg.lh[b_dest] = lh_from_sums(acc_psi, acc_phi);
+            a.sg.flux[b_dest] = flux_from_sums(acc_psi, acc_phi);
+            a.sg.obs[b_dest] = b_obs;
+        }
+        n_batched = 0;
+    };
+
     unsigned long long n_clipped = 0, n_literal = 0;
     for (int e = wave; e < n_entries; e += n_waves) {
         const SgEntry ent = a.sg.entries[e];
@@ -288,6 +348,7 @@ __global__ __launch_bounds__(CLIP_BLOCK) void kb_sigmag_clip_kernel(const Resolv
         float lh = 0.0f, flux = 0.0f;
         int obs = 0;
         uint64_t literal = mask;
+        uint64_t batched = 0;  // trajectories whose results the batch writes
         if (cooperative) {
             literal = 0;
             int cy[E];
@@ -332,7 +393,19 @@ __global__ __launch_bounds__(CLIP_BLOCK) void kb_sigmag_clip_kernel(const Resolv
                     Samples one;
                     one.psi = cur_psi[0];
                     one.phi = cur_phi[0];
-                    done = clip_wave(a, lane, one, &r_lh, &r_flux, &r_obs);
+                    KeepRange keep;
+                    done = clip_wave(a, lane, one, &r_lh, &r_flux, &r_obs, &keep);
+                    if (done) {  // (uniform) into the batch: the row, and its range + destination to the lane that will add it up
+                        rows[n_batched][lane] = make_float2(keep.spsi, keep.sphi);
+                        if (lane == n_batched) {
+                            b_lo = keep.lo;
+                            b_hi = keep.hi;
+                            b_obs = r_obs;
+                            b_dest = (size_t)e * WAVE + (size_t)L;
+                        }
+                        batched |= 1ull << L;
+                        if (++n_batched == CLIP_BATCH) flush_batch();
+                    }
                 } else {
                     done = clip_wave_multi<E>(a, lane, cur_psi, cur_phi, &r_lh, &r_flux, &r_obs);
                 }
@@ -372,13 +445,14 @@ __global__ __launch_bounds__(CLIP_BLOCK) void kb_sigmag_clip_kernel(const Resolv
             flux = trj.flux;
             obs = trj.obs_count;
         }
-        if ((mask >> lane) & 1) {
+        if (((mask & ~batched) >> lane) & 1) {
             const size_t o = (size_t)e * WAVE + lane;
             a.sg.lh[o] = lh;
             a.sg.flux[o] = flux;
             a.sg.obs[o] = obs;
         }
     }
+    flush_batch();
     if (lane == 0) {
         if (wave == 0) atomicAdd(&a.sg.totals[0], (unsigned long long)n_entries);
         if (n_clipped != 0) atomicAdd(&a.sg.totals[1], n_clipped);

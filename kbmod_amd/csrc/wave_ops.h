@@ -174,6 +174,18 @@ __device__ __forceinline__ float chain_add(float acc, float y) {
     return prev + y;
 }
 // The same step with a carry entering at lane 0 (the running sum of the 64 positions before this slot).
+// minimum / maximum of one int per lane over the wave, in a scalar register
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 __device__ __forceinline__ float chain_add_carry(float acc, float y, float carry) {
     const float prev = __int_as_float(
             __builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(acc), DPP_WAVE_SHR1, 0xf, 0xf, false));
