@@ -28,7 +28,7 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "search_common.h"
+#include "search_device.h"
 #include "wave_ops.h"
 
 #pragma clang fp contract(off)
@@ -534,16 +534,13 @@ __global__ __launch_bounds__(256) void kb_sigmag_select_kernel(const ResolveArgs
         }
     }
 
-    if (a.next.counts != nullptr) {  // (uniform) ResultSink::counts: every entry of a list has passed min_lh -- its length is the count
-        int filled = 0;
+    // every entry of a list has passed min_lh: the list's length is the count ResultSink::counts asks for
+    int filled = 0;
 #pragma unroll
-        for (int k = 0; k < KS; ++k) filled += (k < a.K && top.id[k] != -1) ? 1 : 0;
-        if (live) a.next.counts[pixel] = (uint8_t)filled;
-        if (__ballot(live && filled != 0) == 0ull) return;  // ... and a row of 64 empty lists writes no slot
-    }
-    if (!live) return;
+    for (int k = 0; k < KS; ++k) filled += (k < a.K && top.id[k] != -1) ? 1 : 0;
     const int x = x_i + a.params.x_start_min, y = ty + a.params.y_start_min;
-    for (int s = 0; s < a.K; ++s) {
+    // slot s of this lane's list as a full record and the candidate behind it (-1: the placeholder of an empty slot)
+    auto record = [&](int s, kb_trajectory* res, int* cand) {
         int ref = -1;
         float lh_s = -FLT_MAX;
 #pragma unroll
@@ -553,27 +550,83 @@ __global__ __launch_bounds__(256) void kb_sigmag_select_kernel(const ResolveArgs
                 lh_s = top.lh[k];
             }
         }
-        const size_t slot = pixel * a.K + s;
+        *res = placeholder_result(x, y);  // kernels.cu:293-301
+        *cand = -1;
         if (ref <= -2) {  // carried over from an earlier batch
             const size_t from = pixel * a.K + (size_t)(-(ref + 2));
-            if (a.next.compact != nullptr) {
-                a.next.compact[slot] = a.prev.compact[from];
+            if (a.prev.compact != nullptr) {
+                const kb_compact_result old = a.prev.compact[from];
+                res->lh = old.lh;
+                res->flux = old.flux;
+                res->obs_count = old.obs_count;
+                *cand = old.cand;  // (already offset by cand_base)
             } else {
-                a.next.full[slot] = a.prev.full[from];
+                *res = a.prev.full[from];
+                *cand = 0;
             }
-            continue;
+        } else if (ref >= 0) {
+            *cand = (int)a.sg.entries[ref].cand;
+            res->vx = a.cands[*cand].vx;
+            res->vy = a.cands[*cand].vy;
+            res->lh = lh_s;
+            res->flux = a.sg.flux[(size_t)ref * WAVE + lane];
+            res->obs_count = a.sg.obs[(size_t)ref * WAVE + lane];
+            *cand += a.next.cand_base;
         }
-        kb_trajectory res = placeholder_result(x, y);  // kernels.cu:293-301
-        int cand = -1;
-        if (ref >= 0) {
-            cand = (int)a.sg.entries[ref].cand;
-            res.vx = a.cands[cand].vx;
-            res.vy = a.cands[cand].vy;
-            res.lh = lh_s;
-            res.flux = a.sg.flux[(size_t)ref * WAVE + lane];
-            res.obs_count = a.sg.obs[(size_t)ref * WAVE + lane];
+    };
+    if constexpr (KS <= 16) {
+        // the wave's 64 x K records are one contiguous run of the result array: coalesced stores through a patch of LDS
+        // (store_wave_records, search_device.h; it also writes the count bytes and leaves out a row of 64 empty lists)
+        __shared__ uint32_t patches[4][32 * (7 * KS + 1)];
+        char* patch = reinterpret_cast<char*>(patches[threadIdx.x >> 6]);
+        const size_t run0 = ((size_t)ty * a.sw + (size_t)(tx * WAVE)) * a.K;
+        uint8_t* counts_run = a.next.counts != nullptr ? a.next.counts + ((size_t)ty * a.sw + (size_t)(tx * WAVE)) : nullptr;
+        if (a.next.compact != nullptr) {
+            store_wave_records<4>(reinterpret_cast<uint32_t*>(a.next.compact + run0), a.K, live, patch, [&](int s, uint32_t (&w)[4]) {
+                kb_trajectory res;
+                int cand;
+                record(s, &res, &cand);
+                w[0] = __float_as_uint(res.lh);
+                w[1] = __float_as_uint(res.flux);
+                w[2] = (uint32_t)cand;
+                w[3] = (uint32_t)res.obs_count;
+            }, counts_run, filled);
+        } else {
+            store_wave_records<7>(reinterpret_cast<uint32_t*>(a.next.full + run0), a.K, live, patch, [&](int s, uint32_t (&w)[7]) {
+                kb_trajectory res;
+                int cand;
+                record(s, &res, &cand);
+                w[0] = __float_as_uint(res.vx);
+                w[1] = __float_as_uint(res.vy);
+                w[2] = __float_as_uint(res.lh);
+                w[3] = __float_as_uint(res.flux);
+                w[4] = (uint32_t)res.x;
+                w[5] = (uint32_t)res.y;
+                w[6] = (uint32_t)res.obs_count;
+            }, counts_run, filled);
         }
-        store_result(a.next, slot, res, cand);
+        return;
+    }
+    if (a.next.counts != nullptr) {  // (uniform)
+        if (live) a.next.counts[pixel] = (uint8_t)filled;
+        if (__ballot(live && filled != 0) == 0ull) return;  // ... and a row of 64 empty lists writes no slot
+    }
+    if (!live) return;
+    for (int s = 0; s < a.K; ++s) {
+        kb_trajectory res;
+        int cand;
+        record(s, &res, &cand);
+        const size_t slot = pixel * a.K + s;
+        if (a.next.compact != nullptr) {
+            kb_compact_result out;
+            out.lh = res.lh;
+            out.flux = res.flux;
+            out.cand = cand;
+            out.obs_count = res.obs_count;
+            a.next.compact[slot] = out;
+        } else {
+            a.next.full[slot] = res;
+        }
     }
 }
 
