@@ -21,6 +21,8 @@ done
 # round 4 additions: the multi-GPU exchange budget measured on this one GPU (cfg4 and cfg2 with a likelihood threshold), the
 # RCCL path at world size 1, the issue model, the post-search kernels, StackSearch.search_all end to end, other configurations
 python tools/exchange_budget.py --dense > gpurun_out/${R}_exchange_budget_cfg4.json 2>/dev/null
+python tools/exchange_budget.py --counted > gpurun_out/${R}_exchange_budget_cfg4_counted.json 2>/dev/null
+python tools/exchange_budget.py --frames 64 --size 512 --vel-steps 32 --ang-steps 32 --counted > gpurun_out/${R}_exchange_budget_cfg2_lh10_counted.json 2>/dev/null
 python tools/exchange_budget.py --rank-flags 0 > gpurun_out/${R}_exchange_budget_cfg4_nofloor.json 2>/dev/null
 python tools/exchange_budget.py --frames 64 --size 512 --vel-steps 32 --ang-steps 32 --dense > gpurun_out/${R}_exchange_budget_cfg2_lh10.json 2>/dev/null
 KBMOD_FORCE_DIST=1 python bench.py --gpus 1 --frames 128 --size 4096 --vel-steps 32 --ang-steps 2 --min-lh 10 --steps 5 --verify --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${R}_cfg4_rccl_world1_bench_line.json

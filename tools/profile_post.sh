@@ -13,4 +13,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
   DB=$(find /tmp/pmc_post -name "*_results.db" | head -1)
   python tools/rocprof_summary.py $DB $DB | grep -E "kb::|rocprim|counter \||---\|---\|---\|---\|---\|---" > gpurun_out/${TAG}_post_pmc_$C.md
 done
-python tools/search_all_timing.py > gpurun_out/${TAG}_search_all_timing.log 2>/dev/null
+{ python tools/search_all_timing.py; echo "# 64 x 2048 x 2048, 64 candidates"; python tools/search_all_timing.py 64 2048 2048 32 2;
+  echo "# 128 x 4096 x 4096, 64 candidates"; python tools/search_all_timing.py 128 4096 4096 32 2; } 2>/dev/null | grep -E "^#|min_lh" > gpurun_out/${TAG}_search_all_timing.log
