@@ -752,9 +752,14 @@ protected:
         detail::DeviceBlock raw, kept, counts;
         uint64_t bytes = 0, count_bytes = 0;
         int device = -1;  // the device the blocks live on: a later search from a thread whose current device differs gets its own
-        // Blocks beyond this are returned once a search's results have reached the host (a 4096 x 4096 search keeps
-        // 2 x 3.8 GB otherwise, which get_gpu_free_memory / validate_gpu would report as taken between searches).
-        static constexpr uint64_t kKeepBytes = 1ull << 30;
+        // Blocks beyond this are returned once a search's results have reached the host (get_gpu_free_memory / validate_gpu
+        // report them as taken between searches otherwise): 1 GiB or a sixteenth of the device's memory, whichever is larger
+        // -- 18 GB on an MI355X; re-allocating 2 x 3.8 GB for every search of a 4096 x 4096 stack showed as an occasional
+        // stall of seconds in hipMalloc.
+        static uint64_t keep_bytes() {
+            static const uint64_t k = std::max<uint64_t>(1ull << 30, (uint64_t)kb_gpu_total_memory() / 16);
+            return k;
+        }
         void reserve(uint64_t need) {
             const int now = kb_get_device();
             if (need <= bytes && raw.ptr != nullptr && kept.ptr != nullptr && device == now) return;
@@ -784,7 +789,7 @@ protected:
             device = -1;
         }
         void trim() {
-            if (bytes > kKeepBytes) release();
+            if (bytes > keep_bytes()) release();
         }
     } result_blocks;
     std::vector<Replica> replicas;
