@@ -171,3 +171,22 @@ def test_sparse_argument_checks(kb):
         kb.merge_sparse_exact_host(h, len(h), [np.zeros(16 * 2, np.uint8)], 4, 2, 0, 1, 0, 1, cands)  # counts say 3, 2 records
     with pytest.raises(RuntimeError):
         kb.merge_sparse_exact_host(h, len(h) - 16, [np.zeros(16 * 3, np.uint8)], 4, 2, 0, 1, 0, 1, cands)  # stride too short
+
+
+def test_counted_forms_are_device_only():
+    """The counted forms of the exchange (the search wrote the counts; the merge leaves list lengths) exist on the device only:
+    CPU tensors are refused with a message instead of being handed to the C ABI."""
+    import torch
+
+    from kbmod_amd import distributed as kdist
+
+    S, L, K = 4, 4, 2
+    records = torch.zeros((S * L, 4), dtype=torch.int32)
+    header = torch.zeros(32, dtype=torch.uint8)
+    with pytest.raises(ValueError, match="device tensor"):
+        kdist.sparsify_counted(records, S, L, header, torch.zeros((8, 4), dtype=torch.int32))
+    headers = torch.zeros((1, 32), dtype=torch.uint8)
+    cands = torch.zeros((3, 7), dtype=torch.float32)
+    with pytest.raises(ValueError, match="host twin"):
+        kdist.merge_sparse_exact(headers, [torch.zeros((0, 4), dtype=torch.int32)], (0, 2), (0, 2), K, L, cands,
+                                 counts_out=torch.zeros(S, dtype=torch.uint8))
