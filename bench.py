@@ -142,12 +142,6 @@ def main():
     ap.add_argument("--separable-psf", action="store_true",
                     help="build psi/phi with the separable PSF kernel (KB_BUILD_SEPARABLE: <= 1e-4 relative to the reference's "
                          "tap loop instead of bit-identical)")
-    ap.add_argument("--exchange-records", choices=["auto", "k", "2k"], default="auto",
-                    help="N > 1, dense tie-exact exchange: records per pixel and rank.  k = K stable records with hidden ties marked "
-                         "(flags 512 | 4096) -- exact unless the merge calls a pixel ambiguous, in which case the run is repeated "
-                         "with 2 K; 2k = always 2 K; auto = 2k (measured: at the image's border whole families of candidates "
-                         "leave the frame over the same samples and tie exactly -- about 2 000 ambiguous pixels per step at the "
-                         "headline size, so k always ends up repeating the run)")
     ap.add_argument("--exchange", choices=["auto", "dense", "sparse"], default="auto",
                     help="multi-GPU: what travels to rank 0.  dense = every slot of every per-rank list (one gather, hidden under "
                          "the next search); sparse = one count byte per pixel + the records that pass min_lh (kb_sparsify_compact: "
@@ -279,13 +273,6 @@ def main():
     if args.exchange == "sparse" and dist_mode and not exact_ties:
         raise RuntimeError("--exchange sparse goes through the tie-exact merge (K <= 16, not --plain-ties)")
     wire = {}
-    # the dense tie-exact exchange with K records per pixel instead of 2 K: every rank marks hidden ties on its lists' last
-    # records (flag 4096), the merge says whether any pixel needed more (include/kbmod_hip.h: kb_merge_compact_exact_checked)
-    marked = (dist_mode and exact_ties and not sparse and K <= 8 and
-              args.exchange_records == "k")
-    if marked:
-        list_len = K
-    xstate = {"marked": marked, "ambiguous": 0, "unmarked_ranks": 0}
     if dist_mode:
         rank_params = Params.from_buffer_copy(params)
         rank_params.results_per_pixel = list_len
@@ -316,7 +303,6 @@ def main():
         def drain():
             if in_flight[0] is not None:
                 in_flight[0].finish()
-                xstate["ambiguous"] += in_flight[0].ambiguous_pixels
                 in_flight[0] = None
 
         def step(record):
@@ -358,12 +344,9 @@ def main():
                 else:
                     check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), rank_params, cands.data_ptr(),
                                                             n_local, rank * n_local, records.data_ptr(), S * list_len,
-                                                            flags | (512 if exact_ties else 0) | (4096 if xstate["marked"] else 0),
-                                                            stream, C.byref(st)))
-                    if xstate["marked"] and not st.hidden_ties_marked:
-                        xstate["unmarked_ranks"] = 1   # (this rank's kernel instance keeps no packed register lists)
+                                                            flags | (512 if exact_ties else 0), stream, C.byref(st)))
                     nxt = kdist.start_gather_compact(records, (ins, W - ins), (ins, H - ins), K, all_cands, gathered=gathered,
-                                                     out=results, list_len=list_len, marked=xstate["marked"])
+                                                     out=results, list_len=list_len)
                     drain()               # the previous step's gather has had this step's search to travel in; merge it now
                     in_flight[0] = nxt
                     if args.no_overlap:
@@ -402,21 +385,6 @@ def main():
     if sparse:
         sp_packed[0] = torch.empty((max(1024, S * list_len // 64), 4), dtype=torch.int32, device=dev)
     elapsed, kernel_ms, last = run_timed(meta, arr, args.warmup, args.steps)
-    k_record_fallback = None
-    if marked:
-        # Was every pixel of every step decided by K records?  (root: the merges' counts; every rank: were its lists marked)
-        verdict = torch.tensor([xstate["ambiguous"], xstate["unmarked_ranks"]], dtype=torch.int64,
-                               device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(verdict, op=dist.ReduceOp.SUM)
-        k_record_fallback = {"ambiguous_pixels": int(verdict[0].item()), "ranks_without_marks": int(verdict[1].item())}
-        if int(verdict.sum().item()) != 0:
-            # ... no: the whole measurement again with 2 K stable records per pixel (what the line then reports)
-            xstate["marked"] = False
-            list_len = 2 * K
-            rank_params.results_per_pixel = list_len
-            records2 = [torch.empty((S * list_len, 4), dtype=torch.int32, device=dev) for _ in range(n_sets)]
-            gathered2 = [torch.empty((world, S * list_len, 4), dtype=torch.int32, device=dev) if rank == 0 else None for _ in range(n_sets)]
-            elapsed, kernel_ms, last = run_timed(meta, arr, args.warmup, args.steps)
 
     evals_per_step_rank = int(last.num_evals)
     total_evals = evals_per_step_rank * world * args.steps
@@ -570,9 +538,7 @@ def main():
         out["exchange"] = {"form": "sparse" if sparse else "dense", "list_len": list_len, "backend": backend,
                            "wire_bytes_per_rank": wire.get("wire_bytes"), "dense_bytes_per_rank": S * list_len * 16,
                            "records_per_rank": wire.get("totals"), "overlapped": bool(not sparse and not args.no_overlap),
-                           "search_wrote_counts": wire.get("search_wrote_counts"),
-                           "records_per_pixel_and_rank": list_len,
-                           "k_record_exchange": None if k_record_fallback is None else dict(k_record_fallback, repeated_with_2k=not xstate["marked"])}
+                           "search_wrote_counts": wire.get("search_wrote_counts")}
     if build_kernel_ms is not None:
         in_out = float(T) * H * W * 8 + float(meta.total_array_size)  # sci + var in, the array out
         out["psi_phi_build"] = {"kernel": "separable strip (<= 1e-4)" if args.separable_psf else "2-D strip (bit-identical)",

@@ -76,9 +76,6 @@ typedef struct kb_search_stats {
     int32_t env_overrides;        /* bit i: environment switch i was set while this search chose its kernels (they exist for tests
                                      and comparisons and change the kernel instance, never the result): 0 KBMOD_CHUNK, 1 KBMOD_LIST_MODE,
                                      2 KBMOD_EDGE_COUNTS, 3 KBMOD_UNSTAGED_LIMIT, 4 KBMOD_SIGMAG_CAP, 5 KBMOD_DEBUG */
-    int32_t hidden_ties_marked;   /* flag 4096 was honoured: bit 30 of the obs_count of a list's LAST record says that a candidate
-                                     with the same likelihood is hidden behind it (kb_merge_compact_exact on lists of K records) */
-    int32_t reserved1;
 } kb_search_stats;
 
 const char* kb_last_error(void);
@@ -206,10 +203,6 @@ int kb_generate_psi_phi_host(const float* sci_host, const float* var_host, int w
  *      above min_lh are exactly those of the default -- the reference's insertion never lets a smaller likelihood touch
  *      the part of a list at or above a larger one --; which entries below min_lh a list still shows is unspecified.
  *      (With the sigma-G filter the kernel tests min_lh itself, kernels.cu:318-320; the flag changes nothing there.)
- * 4096 (with 512; kb_device_search_compact) a list's LAST record is marked -- bit 30 of its obs_count -- when a candidate with
- *      the same likelihood is hidden behind it: what lets lists of K records (instead of 2 K) merge tie-exactly
- *      (kb_merge_compact_exact_checked).  Honoured by the packed register lists of kb_search_lds (K <= 8);
- *      kb_search_stats::hidden_ties_marked says whether it was -- if not, no record carries a mark and lists of 2 K are needed.
  * The library keeps its workspaces (shift tables, sigma-G scratch, padded copy) between
  * calls; kb_release_workspaces() returns them. */
 int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev,
@@ -317,15 +310,6 @@ int kb_merge_compact(const kb_compact_result* lists_dev, int32_t n_lists, kb_sea
  * (contiguous slices or interleaved). */
 int kb_merge_compact_exact(const kb_compact_result* lists_dev, int32_t n_lists, int32_t list_len, kb_search_params params,
                            const kb_trajectory* all_cands_dev, uint64_t n_all_cands, kb_trajectory* out_dev, void* stream);
-/* ... that also counts the AMBIGUOUS pixels (new).  Lists of fewer than 2 K - 1 records (down to K) merge exactly as well unless a
- * candidate EQUAL to a full list's last record is hidden behind it and that record sits on the pixel's K-th value: searches with
- * flags 512 | 4096 (kb_search_stats::hidden_ties_marked = 1: the packed register lists of kb_search_lds, K <= 8) mark such a
- * last record in bit 30 of its obs_count, the merges strip the mark and count the pixels where it mattered -- on those, and only
- * on those, the result needs lists of 2 K records (on float data: none).  ambiguous_out_host = NULL: kb_merge_compact_exact.
- * Synchronises the stream when the count is asked for. */
-int kb_merge_compact_exact_checked(const kb_compact_result* lists_dev, int32_t n_lists, int32_t list_len, kb_search_params params,
-                                   const kb_trajectory* all_cands_dev, uint64_t n_all_cands, kb_trajectory* out_dev,
-                                   uint64_t* ambiguous_out_host, void* stream);
 
 /* ---- sparse form of the exchange (new; SURVEY 8(e): "shrink traffic by compacting lh >= min_lh first").
  * The reference removes results below min_lh after its kernel (stack_search.cpp:266-270); its swap-down insertion
@@ -382,12 +366,6 @@ int kb_merge_sparse_exact(const uint8_t* headers_dev, uint64_t header_stride, co
 int kb_merge_sparse_exact_counted(const uint8_t* headers_dev, uint64_t header_stride, const kb_compact_result* const* packed_ptrs_host,
                                   int32_t n_lists, int32_t list_len, kb_search_params params, const kb_trajectory* all_cands_dev,
                                   uint64_t n_all_cands, kb_trajectory* out_dev, uint8_t* counts_out_dev, void* stream);
-/* ... and with the ambiguous pixels counted like kb_merge_compact_exact_checked (lists of K .. 2 K - 2 records from searches with
- * flags 512 | 4096); counts_out_dev and ambiguous_out_host may each be NULL. */
-int kb_merge_sparse_exact_checked(const uint8_t* headers_dev, uint64_t header_stride, const kb_compact_result* const* packed_ptrs_host,
-                                  int32_t n_lists, int32_t list_len, kb_search_params params, const kb_trajectory* all_cands_dev,
-                                  uint64_t n_all_cands, kb_trajectory* out_dev, uint8_t* counts_out_dev, uint64_t* ambiguous_out_host,
-                                  void* stream);
 
 /* ---- host instantiations of the device functions ------------------------- */
 /* kernels.cu:154-242 evaluateTrajectory called with host pointers

@@ -32,8 +32,7 @@ class Stats(C.Structure):
                 ("algorithmic_bytes", C.c_uint64), ("kernel_variant", C.c_int32), ("num_search_launches", C.c_int32),
                 ("sigmag_work_items", C.c_uint64), ("sigmag_trajectories", C.c_uint64), ("lds_read_bytes", C.c_uint64),
                 ("sigmag_literal", C.c_uint64), ("kernel_name", C.c_char * 96), ("padded_copy_reused", C.c_int32),
-                ("special_epochs", C.c_int32), ("edge_count_tables", C.c_int32), ("env_overrides", C.c_int32),
-                ("hidden_ties_marked", C.c_int32), ("reserved1", C.c_int32)]
+                ("special_epochs", C.c_int32), ("edge_count_tables", C.c_int32), ("env_overrides", C.c_int32)]
 
 
 def lib_path():
@@ -84,10 +83,6 @@ def load_lib():
                                         C.POINTER(C.c_uint64), C.c_void_p]
     lib.kb_merge_sparse_exact.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, Params,
                                           C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
-    lib.kb_merge_compact_exact_checked.argtypes = [C.c_void_p, C.c_int32, C.c_int32, Params, C.c_void_p, C.c_uint64, C.c_void_p,
-                                                   C.POINTER(C.c_uint64), C.c_void_p]
-    lib.kb_merge_sparse_exact_checked.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, Params,
-                                                  C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
     lib.kb_merge_sparse_exact_counted.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, Params,
                                                   C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.kb_free_gpu_block.argtypes = [C.c_void_p]

@@ -208,8 +208,7 @@ __global__ __launch_bounds__(256) void kb_merge_sparse_exact_kernel(const uint8_
                                                                     int K, int sw, int x_min, int y_min,
                                                                     const kb_trajectory* __restrict__ all_cands,
                                                                     uint64_t n_all_cands, kb_trajectory* __restrict__ out,
-                                                                    uint8_t* __restrict__ counts_out,
-                                                                    unsigned long long* __restrict__ n_ambiguous) {
+                                                                    uint8_t* __restrict__ counts_out) {
     __shared__ uint32_t wave_sums[4];
     const uint64_t pix = (uint64_t)blockIdx.x * SPARSE_BLOCK + threadIdx.x;
     const bool live = pix < n_pixels;
@@ -307,9 +306,7 @@ __global__ __launch_bounds__(256) void kb_merge_sparse_exact_kernel(const uint8_
     MergedEntry merged[MERGE_EXACT_MAX_K2];
     int heads[SPARSE_MAX_LISTS];
     int slots[MERGE_EXACT_MAX_K2];
-    bool ambiguous = false;  // (lists shorter than 2 K - 1 records with a marked hidden tie at the K-th value: search_math.h)
-    const int n_out = merge_exact_pixel(read, n_lists, K2, K, merged, heads, slots, &ambiguous);
-    if (ambiguous && n_ambiguous != nullptr) atomicAdd(n_ambiguous, 1ull);
+    const int n_out = merge_exact_pixel(read, n_lists, K2, K, merged, heads, slots);
     int n_valid = 0;  // (the merged list is filled from the top: the valid slots are a prefix)
     for (int s = 0; s < K; ++s) {
         kb_trajectory res = empty;
@@ -321,7 +318,7 @@ __global__ __launch_bounds__(256) void kb_merge_sparse_exact_kernel(const uint8_
                 res.vy = all_cands[rec.cand].vy;
                 res.lh = rec.lh;
                 res.flux = rec.flux;
-                res.obs_count = rec.obs_count & ~HIDDEN_TIE_BIT;
+                res.obs_count = rec.obs_count;
                 n_valid = (n_valid == s) ? s + 1 : n_valid;
             }
         }
@@ -520,16 +517,7 @@ int kb_merge_sparse_exact(const uint8_t* headers_dev, uint64_t header_stride, co
 int kb_merge_sparse_exact_counted(const uint8_t* headers_dev, uint64_t header_stride, const kb_compact_result* const* packed_ptrs_host,
                                   int32_t n_lists, int32_t list_len, kb_search_params params, const kb_trajectory* all_cands_dev,
                                   uint64_t n_all_cands, kb_trajectory* out_dev, uint8_t* counts_out_dev, void* stream_v) {
-    return kb_merge_sparse_exact_checked(headers_dev, header_stride, packed_ptrs_host, n_lists, list_len, params, all_cands_dev,
-                                         n_all_cands, out_dev, counts_out_dev, nullptr, stream_v);
-}
-
-int kb_merge_sparse_exact_checked(const uint8_t* headers_dev, uint64_t header_stride, const kb_compact_result* const* packed_ptrs_host,
-                                  int32_t n_lists, int32_t list_len, kb_search_params params, const kb_trajectory* all_cands_dev,
-                                  uint64_t n_all_cands, kb_trajectory* out_dev, uint8_t* counts_out_dev, uint64_t* ambiguous_out_host,
-                                  void* stream_v) {
     using namespace kb;
-    if (ambiguous_out_host != nullptr) *ambiguous_out_host = 0;
     if (headers_dev == nullptr || packed_ptrs_host == nullptr || out_dev == nullptr || all_cands_dev == nullptr) {
         return fail("merge_sparse_exact: null pointer");
     }
@@ -559,10 +547,6 @@ int kb_merge_sparse_exact_checked(const uint8_t* headers_dev, uint64_t header_st
     if (exchange_scratch(slot, (uint64_t)n_lists * n_blocks * 12 + 64, &scratch)) return 1;
     uint64_t* bases = reinterpret_cast<uint64_t*>(scratch);
     uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + (uint64_t)n_lists * n_blocks * 8);
-    // (the count of ambiguous pixels: in the 64 bytes of slack behind the block totals)
-    unsigned long long* counter = ambiguous_out_host == nullptr ? nullptr
-            : reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + ((uint64_t)n_lists * n_blocks * 12 + 15) / 16 * 16);
-    if (counter != nullptr) KB_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(kb_sparse_blocksum_kernel, dim3((unsigned)n_blocks, (unsigned)n_lists), dim3(256), 0, stream, headers_dev,
                        header_stride, n_pixels, n_blocks, totals);
     KB_HIP_TRY(hipGetLastError());
@@ -572,19 +556,13 @@ int kb_merge_sparse_exact_checked(const uint8_t* headers_dev, uint64_t header_st
     if (n_lists <= 8) {
         hipLaunchKernelGGL(kb_merge_sparse_exact_kernel<8>, dim3((unsigned)n_blocks), dim3(256), 0, stream, headers_dev,
                            header_stride, lists, bases, n_blocks, (int)n_lists, n_pixels, (int)list_len, K, (int)sw,
-                           params.x_start_min, params.y_start_min, all_cands_dev, n_all_cands, out_dev, counts_out_dev, counter);
+                           params.x_start_min, params.y_start_min, all_cands_dev, n_all_cands, out_dev, counts_out_dev);
     } else {
         hipLaunchKernelGGL(kb_merge_sparse_exact_kernel<SPARSE_MAX_LISTS>, dim3((unsigned)n_blocks), dim3(256), 0, stream,
                            headers_dev, header_stride, lists, bases, n_blocks, (int)n_lists, n_pixels, (int)list_len, K, (int)sw,
-                           params.x_start_min, params.y_start_min, all_cands_dev, n_all_cands, out_dev, counts_out_dev, counter);
+                           params.x_start_min, params.y_start_min, all_cands_dev, n_all_cands, out_dev, counts_out_dev);
     }
     KB_HIP_TRY(hipGetLastError());
-    if (counter != nullptr) {
-        unsigned long long n = 0;
-        KB_HIP_TRY(hipMemcpyAsync(&n, counter, sizeof(n), hipMemcpyDeviceToHost, stream));
-        KB_HIP_TRY(hipStreamSynchronize(stream));
-        *ambiguous_out_host = n;
-    }
     KB_HIP_TRY(hipStreamSynchronize(stream));  // the scratch is free for the next call when this one returns
     return 0;
 }

@@ -206,8 +206,7 @@ struct SearchArgs {
     float min_lh;
     int all_staged;            // every (chunk, epoch) is staged through LDS
     int force_exact;
-    int stable_lists;          // bit 0: per-pixel lists by stable insertion (flag 512: the tie-exact exchange between devices);
-                               // bit 1: packed register lists mark hidden ties on their last record (flag 4096)
+    int stable_lists;          // per-pixel lists by stable insertion (flag 512: the tie-exact exchange between devices)
     float psi_scale, psi_min_val, phi_scale, phi_min_val;  // decode of encoded samples
 };
 
@@ -474,16 +473,8 @@ struct TopKPacked {
             io[s] = EMPTY;
         }
     }
-    // Hidden ties (flag 4096, with stable lists): bit 30 of the LAST slot's word says that a candidate equal to that slot's
-    // likelihood was refused or has fallen off the end -- what the exchange of K-record lists needs to know (search_math.h:
-    // HIDDEN_TIE_BIT).  The mark belongs to the record: every stable insertion pushes the last slot's record off the list and a
-    // new, unmarked one takes its place, so the bit never has to be cleared.  (Observation counts stay below 2^14.)
-    static constexpr uint32_t TIE_MARK = 1u << 30;
-    __device__ __forceinline__ void note_refused(float cand_lh) {
-        io[KS - 1] |= (io[KS - 1] != EMPTY && cand_lh == lh[KS - 1]) ? TIE_MARK : 0u;
-    }
-    // kernels.cu:323-330: strict '>' swap-down (`stable`: see TopK::insert); `track`: see above
-    __device__ __forceinline__ void insert(float cand_lh, float cand_flux, uint32_t cand_io, bool stable = false, bool track = false) {
+    // kernels.cu:323-330: strict '>' swap-down (`stable`: see TopK::insert)
+    __device__ __forceinline__ void insert(float cand_lh, float cand_flux, uint32_t cand_io, bool stable = false) {
         float cl = cand_lh, cf = cand_flux;
         uint32_t ci = cand_io;
         bool placed = false;
@@ -499,9 +490,6 @@ struct TopKPacked {
             cl = g ? tl : cl;
             cf = g ? tf : cf;
             ci = g ? ti : ci;
-        }
-        if (track) {  // (uniform) what has just left the list -- the old last record, or the candidate itself -- against the new last
-            io[KS - 1] = (io[KS - 1] & ~TIE_MARK) | ((ci != EMPTY && io[KS - 1] != EMPTY && cl == lh[KS - 1]) ? TIE_MARK : 0u);
         }
     }
 };

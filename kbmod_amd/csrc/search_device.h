@@ -218,11 +218,8 @@ __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int chu
         int n;
         select_by_bits<C>(ps, ph, cnt, (uint32_t)c_sel, &p, &f, &n);
         const float lh = lh_from_sums(p, f);
-        const bool track = (a.stable_lists & 2) != 0;  // (uniform) hidden ties marked on the last record (flag 4096)
         if (pending != 0u && lh > top.lh[KS - 1]) {
-            top.insert(lh, flux_from_sums(p, f), (uint32_t)(chunk * C + c_sel) | ((uint32_t)n << 16), a.stable_lists != 0, track);
-        } else if (track && pending != 0u) {
-            top.note_refused(lh);
+            top.insert(lh, flux_from_sums(p, f), (uint32_t)(chunk * C + c_sel) | ((uint32_t)n << 16), a.stable_lists != 0);
         }
         pending &= pending - 1u;
     }
@@ -505,16 +502,6 @@ __device__ __forceinline__ void write_packed(const SearchArgs& a, const TileCoor
 #pragma unroll
             for (int k = 0; k < KS; ++k) kept += (k < a.K && top.io[k] != TopKPacked<KS>::EMPTY && !(top.lh[k] < sink.keep_min_lh)) ? 1 : 0;
         }
-        // flag 4096: is a candidate EQUAL to the last record this list shows hidden behind it?  With all KS slots shown that is
-        // the mark the insertions kept on the last slot; with fewer it is the slot behind the last one shown.
-        bool hidden_tie = false;
-        if ((a.stable_lists & 2) != 0) {
-            hidden_tie = (top.io[KS - 1] != TopKPacked<KS>::EMPTY) && (top.io[KS - 1] & TopKPacked<KS>::TIE_MARK) != 0u;
-#pragma unroll
-            for (int k = 1; k < KS; ++k) {
-                if (k == a.K) hidden_tie = top.io[k] != TopKPacked<KS>::EMPTY && top.lh[k] == top.lh[k - 1];
-            }
-        }
         if (sink.compact != nullptr) {
             store_wave_records<4>(reinterpret_cast<uint32_t*>(sink.compact + run0), a.K, live, wave_patch, [&](int s, uint32_t (&w)[4]) {
                 uint32_t io = TopKPacked<KS>::EMPTY;
@@ -531,7 +518,7 @@ __device__ __forceinline__ void write_packed(const SearchArgs& a, const TileCoor
                 w[0] = __float_as_uint(empty ? -FLT_MAX : lh);
                 w[1] = __float_as_uint(empty ? 0.0f : flux);
                 w[2] = empty ? 0xffffffffu : (uint32_t)(sink.cand_base + (int)(io & 0xffffu));
-                w[3] = empty ? 0u : ((io >> 16) & 0x3fffu) | ((s == a.K - 1 && hidden_tie) ? (uint32_t)HIDDEN_TIE_BIT : 0u);
+                w[3] = empty ? 0u : (io >> 16);
             }, counts_run, kept);
         } else {
             store_wave_records<7>(reinterpret_cast<uint32_t*>(sink.full + run0), a.K, live, wave_patch, [&](int s, uint32_t (&w)[7]) {
@@ -553,7 +540,7 @@ __device__ __forceinline__ void write_packed(const SearchArgs& a, const TileCoor
                 w[3] = __float_as_uint(empty ? 0.0f : flux);
                 w[4] = (uint32_t)tc.x;
                 w[5] = (uint32_t)tc.y;
-                w[6] = empty ? 0u : ((io >> 16) & 0x3fffu);
+                w[6] = empty ? 0u : (io >> 16);
             }, counts_run, kept);
         }
         return;
@@ -571,7 +558,7 @@ __device__ __forceinline__ void write_packed(const SearchArgs& a, const TileCoor
                 res.vy = a.cold->cands[id_s].vy;
                 res.lh = top.lh[s];
                 res.flux = top.flux[s];
-                res.obs_count = (int)((io >> 16) & 0x3fffu);
+                res.obs_count = (int)(io >> 16);
             }
             store_result(a.cold->results, slot0 + s, res, id_s);
         }

@@ -487,8 +487,7 @@ __global__ __launch_bounds__(256) void kb_merge_compact_kernel(const kb_compact_
 __global__ __launch_bounds__(64) void kb_merge_compact_exact_kernel(const kb_compact_result* __restrict__ lists, int n_lists,
                                                                     uint64_t n_pixels, int K2, int K, int sw, int x_min,
                                                                     int y_min, const kb_trajectory* __restrict__ all_cands,
-                                                                    uint64_t n_all_cands, kb_trajectory* __restrict__ out,
-                                                                    unsigned long long* __restrict__ n_ambiguous) {
+                                                                    uint64_t n_all_cands, kb_trajectory* __restrict__ out) {
     const uint64_t pix = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (pix >= n_pixels) return;
     const uint64_t list_stride = n_pixels * (uint64_t)K2;
@@ -497,9 +496,7 @@ __global__ __launch_bounds__(64) void kb_merge_compact_exact_kernel(const kb_com
     MergedEntry merged[MERGE_EXACT_MAX_K2];
     int heads[MERGE_MAX_LISTS];
     int slots[MERGE_EXACT_MAX_K2];
-    bool ambiguous = false;  // (lists shorter than 2 K - 1 records with a marked hidden tie at the K-th value: search_math.h)
-    const int n_out = merge_exact_pixel(read, n_lists, K2, K, merged, heads, slots, &ambiguous);
-    if (ambiguous && n_ambiguous != nullptr) atomicAdd(n_ambiguous, 1ull);
+    const int n_out = merge_exact_pixel(read, n_lists, K2, K, merged, heads, slots);
     const int y_i = (int)(pix / (uint64_t)sw), x_i = (int)(pix - (uint64_t)y_i * (uint64_t)sw);
     for (int s = 0; s < K; ++s) {
         kb_trajectory res = placeholder_result(x_i + x_min, y_i + y_min);
@@ -511,7 +508,7 @@ __global__ __launch_bounds__(64) void kb_merge_compact_exact_kernel(const kb_com
                 res.vy = all_cands[rec.cand].vy;
                 res.lh = rec.lh;
                 res.flux = rec.flux;
-                res.obs_count = rec.obs_count & ~HIDDEN_TIE_BIT;
+                res.obs_count = rec.obs_count;
             }
         }
         out[pix * (uint64_t)K + s] = res;
@@ -845,7 +842,6 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     a.K = (int)params.results_per_pixel;
     a.force_exact = (flags & 1u) ? 1 : 0;
     a.stable_lists = (flags & 512u) ? 1 : 0;  // per-pixel lists as stable top-K (kb_merge_compact_exact)
-    if ((flags & 512u) != 0 && (flags & 4096u) != 0) a.stable_lists |= 2;  // ... with hidden ties marked on the last record
     cold.fast_decode = 0;
     if (meta->num_bytes != 4 && (flags & 8u) == 0) {  // bit 3: force the double-precision decode
         cold.fast_decode = (verify_fast_decode(meta->psi_scale, meta->psi_min_val, meta->num_bytes) &&
@@ -1214,9 +1210,6 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     // ResultSink::counts is honoured by the epilogues of kb_search_lds with packed or pooled lists only: any other instance
     // writes every slot and leaves the counts to the caller (kb_sparsify_compact then counts them from the records).
     // With the in-search sigma-G filter the lists are written by kb_sigmag_select_kernel, which honours it for its last batch.
-    // Flag 4096 is honoured by the packed register lists of kb_search_lds (K <= 8); kb_search_stats::hidden_ties_marked says so.
-    const bool ties_marked = (a.stable_lists & 2) != 0 && which == 2 && list_mode == 3 && !sigmag && a.K <= 8;
-    if (!ties_marked) a.stable_lists &= 1;
     const bool counts_ok = sink.counts != nullptr && a.K <= 32 &&
                            (sigmag || (which == 2 && (list_mode == 3 || list_mode == 4)));
     if (!counts_ok || sigmag) cold.results.counts = nullptr;
@@ -1285,8 +1278,6 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                                        S * (uint64_t)a.K * 28ull + n_cands * 28ull + meta->num_times * 8ull;
         stats_out->kernel_variant = which * 10000 + variant * 100 + meta->num_bytes * 10 + (sigmag ? 1 : 0);
         stats_out->num_search_launches = sigmag && a.K <= 32 ? 3 * n_batches : 1;
-        stats_out->hidden_ties_marked = ties_marked ? 1 : 0;
-        stats_out->reserved1 = 0;
         stats_out->lds_read_bytes = which == 2 ? stats_out->num_evals * 8ull
                                                : (which == 1 ? stats_out->num_evals * 2ull * (uint64_t)meta->block_size : 0ull);
         stats_out->sigmag_work_items = 0;
@@ -1430,14 +1421,7 @@ int kb_merge_compact(const kb_compact_result* lists_dev, int32_t n_lists, kb_sea
 
 int kb_merge_compact_exact(const kb_compact_result* lists_dev, int32_t n_lists, int32_t list_len, kb_search_params params,
                            const kb_trajectory* all_cands_dev, uint64_t n_all_cands, kb_trajectory* out_dev, void* stream_v) {
-    return kb_merge_compact_exact_checked(lists_dev, n_lists, list_len, params, all_cands_dev, n_all_cands, out_dev, nullptr, stream_v);
-}
-
-int kb_merge_compact_exact_checked(const kb_compact_result* lists_dev, int32_t n_lists, int32_t list_len, kb_search_params params,
-                                   const kb_trajectory* all_cands_dev, uint64_t n_all_cands, kb_trajectory* out_dev,
-                                   uint64_t* ambiguous_out_host, void* stream_v) {
     using namespace kb;
-    if (ambiguous_out_host != nullptr) *ambiguous_out_host = 0;
     if (lists_dev == nullptr || out_dev == nullptr || all_cands_dev == nullptr) return fail("merge_compact_exact: null pointer");
     if (n_lists <= 0 || n_lists > MERGE_MAX_LISTS) return fail("merge_compact_exact: unsupported number of lists");
     const int64_t sw = (int64_t)params.x_start_max - params.x_start_min;
@@ -1452,28 +1436,10 @@ int kb_merge_compact_exact_checked(const kb_compact_result* lists_dev, int32_t n
     (void)hipGetLastError();
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     const uint64_t n_pixels = (uint64_t)sw * (uint64_t)sh;
-    unsigned long long* counter = nullptr;
-    if (ambiguous_out_host != nullptr) {  // (a counter per device, made once; the call then ends with a stream synchronisation)
-        static unsigned long long* counters[MAX_DEVICES] = {};
-        static std::mutex counters_mutex;
-        const int slot = current_device_slot();
-        {
-            std::lock_guard<std::mutex> lock(counters_mutex);
-            if (counters[slot] == nullptr) KB_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&counters[slot]), sizeof(unsigned long long)));
-            counter = counters[slot];
-        }
-        KB_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
-    }
     hipLaunchKernelGGL(kb_merge_compact_exact_kernel, dim3((unsigned)((n_pixels + 63) / 64)), dim3(64), 0, stream, lists_dev,
                        n_lists, n_pixels, (int)list_len, K, (int)sw, params.x_start_min, params.y_start_min, all_cands_dev,
-                       n_all_cands, out_dev, counter);
+                       n_all_cands, out_dev);
     KB_HIP_TRY(hipGetLastError());
-    if (ambiguous_out_host != nullptr) {
-        unsigned long long n = 0;
-        KB_HIP_TRY(hipMemcpyAsync(&n, counter, sizeof(n), hipMemcpyDeviceToHost, stream));
-        KB_HIP_TRY(hipStreamSynchronize(stream));
-        *ambiguous_out_host = n;
-    }
     return 0;
 }
 

@@ -118,13 +118,10 @@ def merge_compact(gathered, x_bounds, y_bounds, K, all_cands, out=None):
     return out
 
 
-def merge_compact_exact(gathered, x_bounds, y_bounds, K, list_len, all_cands, out=None, stats=None):
+def merge_compact_exact(gathered, x_bounds, y_bounds, K, list_len, all_cands, out=None):
     """Tie-exact merge: ``gathered`` = [world, S*list_len, 4] per-rank lists built by stable insertion (flag 512,
     ``list_len`` = 2 K records per pixel) -> [S*K, 7] trajectories equal to the single-device search on the whole
-    candidate list.  Device tensors: kb_merge_compact_exact; CPU tensors: its host twin.
-    Lists of K .. 2 K - 2 records from searches with flags 512 | 4096 (a hidden tie marked on a list's last record) merge
-    exactly too wherever the merge does not call a pixel ambiguous: ``stats`` (a dict) receives ``ambiguous_pixels`` -- when it
-    is not 0 the step has to be repeated with lists of 2 K records (include/kbmod_hip.h: kb_merge_compact_exact_checked)."""
+    candidate list.  Device tensors: kb_merge_compact_exact; CPU tensors: its host twin."""
     import torch
 
     _check_exchange_tensors(gathered, all_cands)
@@ -138,16 +135,10 @@ def merge_compact_exact(gathered, x_bounds, y_bounds, K, list_len, all_cands, ou
     if gathered.is_cuda:
         lib = device_lib()
         stream = torch.cuda.current_stream().cuda_stream
-        import ctypes as C
-
-        amb = C.c_uint64(0)
-        rc = lib.kb_merge_compact_exact_checked(gathered.data_ptr(), world, int(list_len), _bounds(x_bounds, y_bounds, K),
-                                                all_cands.data_ptr(), all_cands.shape[0], out.data_ptr(),
-                                                None if stats is None else C.byref(amb), stream)
+        rc = lib.kb_merge_compact_exact(gathered.data_ptr(), world, int(list_len), _bounds(x_bounds, y_bounds, K),
+                                        all_cands.data_ptr(), all_cands.shape[0], out.data_ptr(), stream)
         if rc != 0:
             raise RuntimeError(lib.kb_last_error().decode())
-        if stats is not None:
-            stats["ambiguous_pixels"] = int(amb.value)
     else:
         import kbmod_amd.search as kb
 
@@ -155,8 +146,6 @@ def merge_compact_exact(gathered, x_bounds, y_bounds, K, list_len, all_cands, ou
         raw = np.ascontiguousarray(gathered.numpy()).view(np.uint8).reshape(-1)
         res = kb.merge_compact_exact_host(raw, world, int(list_len), K, int(x_bounds[0]), int(x_bounds[1]),
                                           int(y_bounds[0]), int(y_bounds[1]), cands)
-        if stats is not None:
-            stats["ambiguous_pixels"] = int(kb.last_merge_ambiguous())
         out.copy_(torch.from_numpy(res.view(np.float32).reshape(out.shape)))
     return out
 
@@ -248,7 +237,7 @@ def sparse_totals(headers, n_pixels):
     return headers[:, at:at + 8].contiguous().cpu().view(headers.shape[0], 8).numpy().view(np.int64).reshape(-1)
 
 
-def merge_sparse_exact(headers, packed_list, x_bounds, y_bounds, K, list_len, all_cands, out=None, counts_out=None, stats=None):
+def merge_sparse_exact(headers, packed_list, x_bounds, y_bounds, K, list_len, all_cands, out=None, counts_out=None):
     """Tie-exact merge over sparse lists: ``headers`` uint8 [n_lists, header_bytes] (one gather of the ranks' headers),
     ``packed_list[r]`` int32 [total_r, 4] -> [S*K, 7] trajectories: wherever a record survives the likelihood filter they
     equal ``merge_compact_exact`` on the dense lists (hence the single-device search), every other slot is the empty-slot
@@ -281,15 +270,12 @@ def merge_sparse_exact(headers, packed_list, x_bounds, y_bounds, K, list_len, al
         if counts_out is not None and not (counts_out.dtype == torch.uint8 and counts_out.numel() == n_pixels
                                            and counts_out.is_contiguous() and counts_out.device == headers.device):
             raise ValueError(f"counts_out: expected a contiguous uint8 tensor of {n_pixels} bytes on the headers' device")
-        amb = C.c_uint64(0)
-        rc = lib.kb_merge_sparse_exact_checked(headers.data_ptr(), int(headers.shape[1]), ptrs, n_lists, int(list_len),
+        rc = lib.kb_merge_sparse_exact_counted(headers.data_ptr(), int(headers.shape[1]), ptrs, n_lists, int(list_len),
                                                _bounds(x_bounds, y_bounds, K), all_cands.data_ptr(), all_cands.shape[0],
                                                out.data_ptr(), None if counts_out is None else counts_out.data_ptr(),
-                                               None if stats is None else C.byref(amb), torch.cuda.current_stream().cuda_stream)
+                                               torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError(lib.kb_last_error().decode())
-        if stats is not None:
-            stats["ambiguous_pixels"] = int(amb.value)
     else:
         import kbmod_amd.search as kb
 
@@ -300,8 +286,6 @@ def merge_sparse_exact(headers, packed_list, x_bounds, y_bounds, K, list_len, al
                                          [np.ascontiguousarray(p.numpy()).view(np.uint8).reshape(-1) for p in packed_list],
                                          int(list_len), int(K), int(x_bounds[0]), int(x_bounds[1]), int(y_bounds[0]),
                                          int(y_bounds[1]), cands)
-        if stats is not None:
-            stats["ambiguous_pixels"] = int(kb.last_merge_ambiguous())
         out.copy_(torch.from_numpy(res.view(np.float32).reshape(out.shape)))
     return out
 
@@ -425,11 +409,9 @@ class ExchangeInFlight:
     and the calling stream is not held up), the merge is enqueued behind it when ``finish()`` is called.  The caller must
     leave ``local_records`` (and ``gathered``) alone until then."""
 
-    def __init__(self, work, gathered, staged, merge_args, is_root, send=None, marked=False):
+    def __init__(self, work, gathered, staged, merge_args, is_root, send=None):
         self._work, self._gathered, self._staged, self._merge_args, self._is_root = work, gathered, staged, merge_args, is_root
         self._send = send  # the tensor on the wire (possibly a host copy made here): alive until finish()
-        self._marked = marked
-        self.ambiguous_pixels = 0  # (root, after finish(); lists of K marked records: see merge_compact_exact)
 
     def finish(self):
         if self._work is not None:
@@ -441,24 +423,15 @@ class ExchangeInFlight:
         if self._staged is not None:
             self._gathered.copy_(self._staged)
         x_bounds, y_bounds, K, list_len, all_cands, out = self._merge_args
-        if self._marked:
-            stats = {}
-            merged = merge_compact_exact(self._gathered, x_bounds, y_bounds, K, K if list_len is None else list_len, all_cands, out,
-                                         stats=stats)
-            self.ambiguous_pixels = stats["ambiguous_pixels"]
-            return merged
         if list_len is None or int(list_len) == int(K):
             return merge_compact(self._gathered, x_bounds, y_bounds, K, all_cands, out)
         return merge_compact_exact(self._gathered, x_bounds, y_bounds, K, list_len, all_cands, out)
 
 
 def start_gather_compact(local_records, x_bounds, y_bounds, K, all_cands, group=None, gathered=None, out=None, dst=0,
-                         list_len=None, marked=False):
+                         list_len=None):
     """The exchange of ``gather_and_merge_compact`` in two halves: starts the ONE gather (asynchronously) and returns an
-    ``ExchangeInFlight`` whose ``finish()`` completes it and merges on global rank ``dst`` (None elsewhere).
-    ``marked``: the lists come from searches with flags 512 | 4096 on every rank (K stable records per pixel with hidden ties
-    marked): the tie-exact merge runs on them and ``ExchangeInFlight.ambiguous_pixels`` says on the root whether the step has
-    to be repeated with lists of 2 K records."""
+    ``ExchangeInFlight`` whose ``finish()`` completes it and merges on global rank ``dst`` (None elsewhere)."""
     import torch
     import torch.distributed as dist
 
@@ -469,14 +442,14 @@ def start_gather_compact(local_records, x_bounds, y_bounds, K, all_cands, group=
     merge_args = (x_bounds, y_bounds, K, list_len, all_cands, out)
     if not _is_root(dst, group):
         work = dist.gather(send, None, dst=dst, group=group, async_op=True)
-        return ExchangeInFlight(work, None, None, merge_args, False, send, marked)
+        return ExchangeInFlight(work, None, None, merge_args, False, send)
     if gathered is None:
         gathered = torch.empty((world,) + tuple(local_records.shape), dtype=local_records.dtype,
                                device=local_records.device)
     staged = torch.empty(gathered.shape, dtype=gathered.dtype) if via_host else None
     target = staged if via_host else gathered
     work = dist.gather(send, [target[r] for r in range(world)], dst=dst, group=group, async_op=True)
-    return ExchangeInFlight(work, gathered, staged, merge_args, True, send, marked)
+    return ExchangeInFlight(work, gathered, staged, merge_args, True, send)
 
 
 def merge_topk(gathered, n_pixels, K, out=None):

@@ -142,72 +142,6 @@ def test_tie_exact_sharded_search_equals_unsharded(kb, ds, grid, world, cfg):
     assert ((e[:, :-1] == e[:, 1:]) & (e[:, :-1] != EMPTY)).any()
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
-@pytest.mark.parametrize("cfg", [dict(K=8), dict(K=3, min_obs=5, min_lh=1.0), dict(K=5), dict(K=8, min_lh=4.0)])
-@pytest.mark.parametrize("which", ["chunks_of_8", "wide_chunks"])
-def test_k_record_exchange_with_hidden_tie_marks(kb, ds, ds_dyadic, grid, grid_dense, which, world, cfg):
-    """Every slice searched with K stable records per pixel and flags 512 | 4096 (a hidden tie marked on a list's last record,
-    kb_search_stats::hidden_ties_marked), merged by kb_merge_compact_exact_checked: wherever the merge does not call a pixel
-    ambiguous the result IS the unsharded search, field for field; every pixel that differs is one the host twin calls
-    ambiguous; no mark reaches a result; the sparse form of the same lists agrees."""
-    from kbmod_amd import distributed as kdist
-
-    d, (vx, vy) = (ds, grid) if which == "chunks_of_8" else (ds_dyadic, grid_dense)
-    torch = d.torch
-    all_cands = d.candidates(vx, vy)
-    p = d.params(**cfg)
-    K, S = p.results_per_pixel, d.W * d.H
-    parts, marks = [], 0
-    for r in range(world):
-        lo, hi = kdist.shard_bounds(len(vx), r, world)
-        rec, st = d.search_compact(p, all_cands[lo:hi], lo, 4 | 512 | 4096)
-        if st.hidden_ties_marked != 1:
-            # (a slice this short runs another list form: no record is marked, the caller exchanges 2 K records instead)
-            plain, _ = d.search_compact(p, all_cands[lo:hi], lo, 4 | 512)
-            assert torch.equal(rec, plain)
-            pytest.skip("the kernel instance of this slice keeps no packed register lists")
-        assert "kb_search_lds" in st.kernel_name.decode()
-        plain, _ = d.search_compact(p, all_cands[lo:hi], lo, 4 | 512)
-        marked = (rec[:, 3] & (1 << 30)) != 0
-        marks += int(marked.sum())
-        # the mark sits on last records only and is the only difference to the unmarked search
-        assert not bool(marked.view(S, K)[:, :K - 1].any())
-        assert torch.equal(rec[:, :3], plain[:, :3]) and torch.equal(rec[:, 3] & ~(1 << 30), plain[:, 3])
-        parts.append(rec)
-    gathered = torch.stack(parts)
-    stats = {}
-    merged = kdist.merge_compact_exact(gathered, (0, d.W), (0, d.H), K, K, all_cands, stats=stats)
-    torch.cuda.synchronize()
-    hstats = {}
-    host = kdist.merge_compact_exact(gathered.cpu(), (0, d.W), (0, d.H), K, K, all_cands.cpu(), stats=hstats)
-    assert torch.equal(merged.cpu().view(torch.int32), host.view(torch.int32)) and hstats == stats
-    assert int((merged.view(torch.int32)[:, 6] & (1 << 30)).sum()) == 0
-    full, _ = d.search(p, all_cands, 0)
-    differs = (merged.view(torch.int32) != full.view(torch.int32)).any(dim=1).view(S, K).any(dim=1)
-    n_diff = int(differs.sum())
-    assert n_diff <= stats["ambiguous_pixels"]
-    if stats["ambiguous_pixels"] == 0:
-        assert n_diff == 0
-    g = gathered.cpu().view(world, S, K, 4)
-    for pix in torch.nonzero(differs).flatten().tolist()[:50]:
-        one = {}
-        kdist.merge_compact_exact(g[:, pix].contiguous().view(world, K, 4), (0, 1), (0, 1), K, K, all_cands.cpu(), stats=one)
-        assert one["ambiguous_pixels"] == 1, pix
-    if which == "wide_chunks" and K >= 5 and "min_lh" not in cfg:
-        assert marks > 0  # (the dyadic stack is made of ties: the marking is exercised)
-    # the sparse form of the same lists: same records, same ambiguity
-    if "min_lh" in cfg:
-        hs, ps = [], []
-        for r in range(world):
-            h, pk, _ = kdist.sparsify_compact(parts[r], S, K, float(p.min_lh))
-            hs.append(h), ps.append(pk)
-        sstats = {}
-        sparse = kdist.merge_sparse_exact(torch.stack(hs), ps, (0, d.W), (0, d.H), K, K, all_cands, stats=sstats)
-        keep = ~(merged[:, 2] < float(p.min_lh))
-        assert torch.equal(sparse.view(torch.int32)[keep], merged.view(torch.int32)[keep])
-        assert sstats["ambiguous_pixels"] <= stats["ambiguous_pixels"]
-
-
 def test_stable_lists_are_the_top_by_likelihood_then_candidate(ds, grid):
     """Flag 512 alone: the per-pixel list is the first K of the candidates ordered by (likelihood descending, index
     ascending) -- checked against a list long enough to hold every candidate."""
@@ -324,8 +258,7 @@ def test_two_ranks_on_one_gpu_sparse_exchange_through_gloo():
     assert 0 < line["verify_survivors"] < 128 * 128 * 8 // 4 and sum(ex["records_per_rank"]) >= line["verify_survivors"]
 
 
-@pytest.mark.parametrize("extra", [[], ["--no-overlap"], ["--min-lh", "6"], ["--sigmag", "--num-bytes", "1"],
-                                   ["--exchange-records", "k"], ["--exchange-records", "k", "--num-bytes", "1"]])
+@pytest.mark.parametrize("extra", [[], ["--no-overlap"], ["--min-lh", "6"], ["--sigmag", "--num-bytes", "1"]])
 def test_rccl_backend_at_world_size_one(extra):
     """The N > 1 branch of bench.py on the REAL backend (nccl = RCCL) with the one GPU there is: KBMOD_FORCE_DIST=1 makes a
     world of one rank initialise the process group on the device and run compact search -> dist.gather of device tensors
@@ -337,15 +270,6 @@ def test_rccl_backend_at_world_size_one(extra):
                               "backend": "nccl", "exchange": "sparse" if sparse else "dense", "world": 1}
     assert line["exchange"]["backend"] == "nccl" and line["exchange"]["form"] == ("sparse" if sparse else "dense")
     assert line["exchange"]["overlapped"] == (not sparse and "--no-overlap" not in extra)
-    # the dense exchange carries K records per pixel with hidden ties marked, unless told otherwise or a pixel needed 2 K
-    kx = line["exchange"]["k_record_exchange"]
-    if "--exchange-records" not in extra:
-        assert kx is None and line["exchange"]["records_per_pixel_and_rank"] == 16
-    else:
-        # (border pixels tie exactly -- families of candidates leave the frame over the same samples --, so on a whole image the
-        # run normally ends up repeated with 2 K; either way the merged result equals the single-device search: verify above)
-        again = kx["ambiguous_pixels"] != 0 or kx["ranks_without_marks"] != 0
-        assert kx["repeated_with_2k"] == again and line["exchange"]["records_per_pixel_and_rank"] == (16 if again else 8)
 
 
 @pytest.mark.parametrize("world", [1, 3, 8, 11])  # (11: the merge instance for more than eight lists)

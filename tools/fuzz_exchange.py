@@ -15,7 +15,6 @@ from tests import util
 EMPTY = np.float32(-3.4028234663852886e38)
 bad = []
 n_counted = 0
-n_krec = n_amb = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rng = np.random.default_rng(seed)
     T = int(rng.integers(3, 40))
@@ -78,26 +77,10 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         covered = tt.arange(K, device="cuda").repeat(S) < n_valid.repeat_interleave(K)
         same_row = (out_c.view(tt.int32) == want.view(tt.int32)).all(dim=1)
         ok_c = tt.equal(counts.to(tt.int64), n_valid) and bool(same_row[covered].all()) and bool((same_row | tt.isnan(out_c).all(dim=1)).all())
-        # K records per rank with hidden ties marked (flags 512 | 4096): exact wherever the merge is not ambiguous
-        if K <= 8:
-            krecs, all_marked = [], True
-            for lo, hi in lo_hi:
-                rk, stk = d.search_compact(p, all_cands[int(lo):int(hi)], int(lo), flags | 512 | 4096)
-                all_marked = all_marked and stk.hidden_ties_marked == 1
-                krecs.append(rk)
-            if all_marked:
-                n_krec += 1
-                kst = {}
-                km = kdist.merge_compact_exact(tt.stack(krecs), (0, W), (0, H), K, K, all_cands, stats=kst)
-                single, _ = d.search(p, all_cands, flags)
-                n_diff = int((km.view(tt.int32) != single.view(tt.int32)).any(dim=1).view(S, K).any(dim=1).sum())
-                n_amb += kst["ambiguous_pixels"]
-                if n_diff > kst["ambiguous_pixels"] or (kst["ambiguous_pixels"] == 0 and n_diff != 0):
-                    bad.append(("k records", seed, n_diff, kst))
         if not ok:
             bad.append(seed)
         if not ok_c:
             bad.append(("counted merge", seed))
     finally:
         d.close()
-print("seeds", sys.argv[1], sys.argv[2], "mismatches", bad, "counted searches", n_counted, "K-record merges", n_krec, "ambiguous pixels", n_amb)
+print("seeds", sys.argv[1], sys.argv[2], "mismatches", bad, "counted searches", n_counted)
