@@ -313,10 +313,12 @@ constexpr int MERGE_EXACT_MAX_K2 = 32;
 // Lists of fewer than 2 K - 1 records (down to K) merge exactly too, as long as nothing they hide can matter.  A device's
 // stable list of L records is its top L under (likelihood descending, candidate ascending); what it hides lies below its
 // last record, and the only hidden candidates the replay could need are those EQUAL to the pixel's K-th value v (everything
-// above v is among the first K of the union, and every list supplies its own first K).  A search with flag 4096 marks a
-// list's last record -- bit 30 of obs_count -- when a candidate equal to it was refused or fell off the end; a pixel is
-// AMBIGUOUS when a full list whose last record carries the mark ends on v: then, and only then, lists of 2 K records are
-// needed (*ambiguous; on float data: never).  The mark never reaches an output record.
+// above v is among the first K of the union, and every list supplies its own first K).  A producer of such
+// lists marks a list's last record -- bit 30 of obs_count -- when a candidate equal to it was refused or fell off the end; a
+// pixel is AMBIGUOUS when a full list whose last record carries the mark ends on v: then, and only then, lists of 2 K records
+// are needed (*ambiguous).  The mark never reaches an output record.  (No search of this library sets the mark any more: the
+// marking of the packed register lists was built, measured and reverted -- border pixels tie by the thousand and the marking
+// cost every search 1.5 % --; the lists the exchange uses hold 2 K records and never carry it.)
 constexpr int32_t HIDDEN_TIE_BIT = 1 << 30;
 struct MergedEntry {
     float lh;

@@ -199,7 +199,7 @@ HIDDEN_TIE_BIT = 1 << 30
 @pytest.mark.parametrize("extra", [0, 1, 3])
 def test_short_lists_with_hidden_tie_marks(kb, K, extra):
     """Lists of L = K + extra < 2 K - 1 records whose last record is marked (bit 30 of obs_count) when a candidate EQUAL to it is
-    hidden behind it (search_math.h: HIDDEN_TIE_BIT; what a search with flag 4096 leaves): wherever the merge does not call
+    hidden behind it (search_math.h: HIDDEN_TIE_BIT; DESIGN.md section 8 on what produced such lists): wherever the merge does not call
     the pixel ambiguous the result is the reference's sequential insertion over the whole candidate list, and the marks never
     reach an output record.  Likelihoods from a few levels (ties everywhere, ambiguous pixels included) and from many (none)."""
     rng = np.random.default_rng(500 + 10 * K + extra)
