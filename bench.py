@@ -100,6 +100,106 @@ def self_launch(args_list, n):
     return subprocess.call(cmd, env=env)
 
 
+def roofline_block(*, kernel_ms, algorithmic_bytes, lds_read_bytes, evals_per_step, traffic, traffic_source, traffic_rejected,
+                   compulsory_bytes, padded_copy_bytes_guess, is_lds_kernel, kernel, edge_count_tables, mask_fraction,
+                   padded_copy_reused, env_overrides, copy_gbps, read_gbps, lds_gbps, psi_phi_bytes):
+    """The `roofline` object of the line, from plain measured values (no device, no library: tests/test_bench_contract.py
+    calls this with stubbed numbers).  What bounds the dominant kernel, and every fraction with its yardstick and its clock
+    (every rate divides by kernel_ms: the HIP-event duration of the search launch on its own stream, averaged over the run's
+    un-profiled timed steps):
+      cache-resident arrays (the float copy fits the 256 MiB Infinity Cache: BASELINE configs[1], [2]) -- DRAM sees the array
+        once; the fabric bytes are Infinity-Cache hits; what the kernel is bound by is the rate at which the sums read LDS
+        and instructions issue.  SURVEY 8(d)'s "8 B per evaluation" ARE those LDS reads (one ds_read_b64 per sample):
+        achieved = algorithmic bytes / kernel_ms against the LDS read peak of the guide; frac_algorithmic, the same bytes
+        against the 8 TB/s of HBM, is above 1 for that reason and is not a roofline fraction.
+      arrays beyond the Infinity Cache (configs[3], [4]) -- bound "hbm": achieved = fabric bytes / kernel_ms against 8 TB/s."""
+    k_s = kernel_ms * 1e-3
+    alg_rate = float(algorithmic_bytes) / k_s / 1e9
+    cache_resident = padded_copy_bytes_guess <= INFINITY_CACHE_BYTES
+    lds_rate = float(lds_read_bytes) / k_s / 1e9
+    fabric_rate = None if traffic is None else traffic / k_s / 1e9
+    note = []
+    if cache_resident and is_lds_kernel:
+        bound, achieved, peak = "lds+issue", lds_rate, LDS_PEAK_GBPS
+        note.append(f"the array's float copy ({padded_copy_bytes_guess >> 20} MiB) lives in the 256 MiB Infinity Cache: fabric bytes are cache "
+                    "hits, DRAM traffic is about compulsory_bytes; the kernel is bound by LDS reads and instruction issue.  SURVEY "
+                    "8(d)'s 8 B per evaluation are LDS bytes here (one ds_read_b64 per sample): achieved = those bytes / kernel_ms, "
+                    "peak = the guide's LDS read rate; frac_of_measured_lds uses the ds_read_b64 rate measured in this run")
+    else:
+        bound, peak = "hbm", HBM_PEAK_GBPS
+        if fabric_rate is None:
+            # (the algorithmic rate of SURVEY 8(d) is no HBM rate -- staged pixels are reused out of LDS, it exceeds the peak
+            # several times over; it stays in the line as algorithmic_GBps)
+            achieved = compulsory_bytes / k_s / 1e9
+            note.append("no fabric-byte measurement for this workload and kernel instance: achieved = compulsory_bytes / kernel_ms, "
+                        "a LOWER bound of the HBM rate (what any implementation must move: the array once + the result slots)")
+        else:
+            achieved = fabric_rate
+            note.append("achieved = fabric bytes per launch (traffic) / kernel_ms")
+    note.append("clock of every rate: kernel_ms = HIP events around the search launch, un-profiled timed region of this run; "
+                "traffic = bytes per launch from PMC passes (byte counts do not depend on the profiler's slowdown)")
+    return {
+        "bound": bound,
+        "achieved": achieved,
+        "peak": peak,
+        "unit": "GB/s",
+        "frac": achieved / peak,
+        "traffic": traffic,
+        "traffic_source": traffic_source,
+        "traffic_rejected": traffic_rejected,
+        "compulsory_bytes": compulsory_bytes,
+        "traffic_over_compulsory": None if traffic is None else traffic / compulsory_bytes,
+        "note": "; ".join(note),
+        "kernel": kernel,
+        "kernel_ms": kernel_ms,
+        "obs_counts": ("border tiles from tables of epochs per shift (the stack has no masked pixel), none needed elsewhere"
+                       if edge_count_tables and mask_fraction == 0.0 else "counted per sample where NO_DATA can occur"),
+        "padded_copy": ("kept from the first search of this array (the library built the array and nothing has written into it): "
+                        "the decode-and-pad pass is OUTSIDE the timed steps, see first_search"
+                        if padded_copy_reused else "made by this search (decode-and-pad pass inside the step)"),
+        "env_overrides": env_overrides,   # KBMOD_* switches set in this process (0: none; include/kbmod_hip.h)
+        "kernel_evals_per_s": evals_per_step / k_s,
+        "frac_algorithmic": alg_rate / HBM_PEAK_GBPS,
+        "algorithmic_bytes_per_launch": int(algorithmic_bytes),
+        "algorithmic_GBps": alg_rate,
+        "fabric_GBps": fabric_rate,
+        "fabric_frac_of_hbm_peak": None if fabric_rate is None else fabric_rate / HBM_PEAK_GBPS,
+        "fabric_frac_of_achievable": None if fabric_rate is None else fabric_rate / HBM_ACHIEVABLE_GBPS,
+        "hbm_peak_GBps": HBM_PEAK_GBPS,
+        "hbm_achievable_GBps": HBM_ACHIEVABLE_GBPS,
+        "hbm_measured_copy_GBps": float(copy_gbps) or None,
+        "hbm_measured_read_GBps": float(read_gbps) or None,
+        "lds_read_bytes_per_launch": int(lds_read_bytes),
+        "lds_read_GBps": lds_rate,
+        "lds_guide_peak_GBps": LDS_PEAK_GBPS,
+        "lds_measured_peak_GBps": float(lds_gbps) or None,
+        "frac_of_guide_lds": None if not lds_read_bytes else lds_rate / LDS_PEAK_GBPS,
+        "frac_of_measured_lds": None if not (lds_read_bytes and lds_gbps) else lds_rate / float(lds_gbps),
+        "psi_phi_bytes": int(psi_phi_bytes),
+        "cache_resident": bool(cache_resident),
+    }
+
+
+def headline_line(*, total_evals, elapsed_s, world, steps, warmup, dtype, config, roofline):
+    """The driver's contract fields around `config` and `roofline` (pure: tests/test_bench_contract.py)."""
+    return {
+        "metric": "trajectory-epoch evals/sec",
+        "value": total_evals / elapsed_s,
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed_s / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": dtype,
+        "data": "synthetic",
+        "config": config,
+        "roofline": roofline,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,6 +396,7 @@ def main():
     def run_timed(meta, arr, n_warmup, n_steps):
         """n_warmup untimed + n_steps timed whole searches of the array at `arr`; (elapsed s, kernel ms per step, last stats)."""
         kernel_ms = []
+        call_ms = []   # host wall time of the search call alone (tables + sync + kernel; the call returns when its kernel has)
         searched = [False]
         in_flight = [None]   # the exchange of the previous step (N > 1, dense, overlapped)
         which_set = [0]
@@ -312,6 +413,7 @@ def main():
             # resident array passes), which lets the library keep the padded float copy of the last search.
             flags = base_flags | (256 if (searched[0] and args.reuse_padded_copy) else 0)
             searched[0] = True
+            t_call = time.perf_counter()
             if dist_mode:
                 b = which_set[0]
                 which_set[0] = (b + 1) % n_sets
@@ -324,6 +426,7 @@ def main():
                                                             n_local, rank * n_local, records.data_ptr(), S * list_len,
                                                             sp_header.data_ptr(), flags | (512 if exact_ties else 0), stream,
                                                             C.byref(st), C.byref(counted)))
+                    t_call = time.perf_counter() - t_call
                     # nothing to hide: the wire carries a count byte per pixel and the few records above the threshold
                     stats = {}
                     try:
@@ -345,6 +448,7 @@ def main():
                     check(lib, lib.kb_device_search_compact(C.byref(meta), arr, times.data_ptr(), rank_params, cands.data_ptr(),
                                                             n_local, rank * n_local, records.data_ptr(), S * list_len,
                                                             flags | (512 if exact_ties else 0), stream, C.byref(st)))
+                    t_call = time.perf_counter() - t_call
                     nxt = kdist.start_gather_compact(records, (ins, W - ins), (ins, H - ins), K, all_cands, gathered=gathered,
                                                      out=results, list_len=list_len)
                     drain()               # the previous step's gather has had this step's search to travel in; merge it now
@@ -355,8 +459,10 @@ def main():
             else:
                 check(lib, lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), n_local,
                                                        results.data_ptr(), S * K, flags, stream, C.byref(st)))
+                t_call = time.perf_counter() - t_call
             if record:
                 kernel_ms.append(st.search_kernel_ms)
+                call_ms.append(t_call * 1e3)
             return st
 
         for _ in range(n_warmup):
@@ -380,11 +486,11 @@ def main():
             tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        return elapsed, kernel_ms, last
+        return elapsed, kernel_ms, last, call_ms
 
     if sparse:
         sp_packed[0] = torch.empty((max(1024, S * list_len // 64), 4), dtype=torch.int32, device=dev)
-    elapsed, kernel_ms, last = run_timed(meta, arr, args.warmup, args.steps)
+    elapsed, kernel_ms, last, call_ms = run_timed(meta, arr, args.warmup, args.steps)
 
     evals_per_step_rank = int(last.num_evals)
     total_evals = evals_per_step_rank * world * args.steps
@@ -431,114 +537,49 @@ def main():
         except (OSError, ValueError):
             pass
 
-    # What bounds the dominant kernel, and every fraction with its yardstick and its clock (all times below are
-    # kernel_ms: the HIP-event duration of the search launch on its own stream, averaged over this run's timed steps):
-    #  cache-resident arrays (the float copy fits the 256 MiB Infinity Cache: BASELINE configs[1], [2]) -- DRAM sees the array
-    #    once; the fabric bytes are Infinity-Cache hits; what the kernel is bound by is the rate at which the sums read LDS
-    #    and instructions issue.  SURVEY 8(d)'s "8 B per evaluation" ARE those LDS reads (one ds_read_b64 per sample):
-    #    achieved = algorithmic bytes / kernel_ms against the LDS read peak of the guide; frac_algorithmic, the same bytes
-    #    against the 8 TB/s of HBM, is above 1 for that reason and is not a roofline fraction.
-    #  arrays beyond the Infinity Cache (configs[3], [4]) -- bound "hbm": achieved = fabric bytes / kernel_ms against 8 TB/s.
     padded_guess = int(meta.total_array_size) * (8 // int(meta.block_size * 2) if meta.num_bytes != 4 else 1)
-    cache_resident = padded_guess <= INFINITY_CACHE_BYTES
-    lds_rate = float(last.lds_read_bytes) / (k_ms * 1e-3) / 1e9
-    fabric_rate = None if traffic is None else traffic / (k_ms * 1e-3) / 1e9
     # compulsory = what any implementation must move: the array once, the candidates and times in, the result slots out
     compulsory = int(meta.total_array_size) + n_local * 28 + T * 8 + S * K * 28
-    note = []
-    if cache_resident and is_lds_kernel:
-        bound, achieved, peak = "lds+issue", lds_rate, LDS_PEAK_GBPS
-        note.append(f"the array's float copy ({padded_guess >> 20} MiB) lives in the 256 MiB Infinity Cache: fabric bytes are cache "
-                    "hits, DRAM traffic is about compulsory_bytes; the kernel is bound by LDS reads and instruction issue.  SURVEY "
-                    "8(d)'s 8 B per evaluation are LDS bytes here (one ds_read_b64 per sample): achieved = those bytes / kernel_ms, "
-                    "peak = the guide's LDS read rate; frac_of_measured_lds uses the ds_read_b64 rate measured in this run")
-    else:
-        bound, peak = "hbm", HBM_PEAK_GBPS
-        if fabric_rate is None:
-            # (the algorithmic rate of SURVEY 8(d) is no HBM rate -- staged pixels are reused out of LDS, it exceeds the peak
-            # several times over; it stays in the line as algorithmic_GBps)
-            achieved = compulsory / (k_ms * 1e-3) / 1e9
-            note.append("no fabric-byte measurement for this workload and kernel instance: achieved = compulsory_bytes / kernel_ms, "
-                        "a LOWER bound of the HBM rate (what any implementation must move: the array once + the result slots)")
-        else:
-            achieved = fabric_rate
-            note.append("achieved = fabric bytes per launch (traffic) / kernel_ms")
-    note.append("clock of every rate: kernel_ms = HIP events around the search launch, un-profiled timed region of this run; "
-                "traffic = bytes per launch from PMC passes (byte counts do not depend on the profiler's slowdown)")
-
-    out = {
-        "metric": "trajectory-epoch evals/sec",
-        "value": value,
-        "unit": "evals/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": dtype,
-        "data": "synthetic",
-        "config": {
-            "workload": f"{T}x{H}x{W} psi/phi ({'float32' if args.num_bytes in (-1, 4) else 'uint%d' % (8 * args.num_bytes)}), "
-                        f"full {W}x{H} start grid x {n_local} (v,theta) candidates per GPU, K={K}, "
-                        f"sigma-G {'on, min_obs %d' % (T // 2) if args.sigmag else 'off'}"
-                        + (f", min_lh {float(params.min_lh):g}" if float(params.min_lh) > 0 else "")
-                        + (f", {args.mask_fraction:g} of the science pixels masked" if args.mask_fraction > 0 else ""),
-            "frames": T, "height": H, "width": W, "candidates_per_gpu": n_local, "results_per_pixel": K,
-            "sharding": ("candidates (v,theta) by rank (angle rows dealt boustrophedon); psi/phi replicated; "
-                         + (f"sparse exchange (one count byte per pixel + the records with lh >= {float(params.min_lh):g} of {list_len} "
-                            "per pixel: one RCCL gather of the headers + one message per rank) + per-pixel merge, tie-exact" if sparse
-                            else f"one RCCL gather of 16-byte records to rank 0 ({list_len} per pixel) + per-pixel merge, "
-                            + ("tie-exact" if exact_ties else "ties by candidate index")))
-                        if dist_mode else "none",
-            "psi_phi_build_ms": build_ms,
-        },
-        "roofline": {
-            "bound": bound,
-            "achieved": achieved,
-            "peak": peak,
-            "unit": "GB/s",
-            "frac": achieved / peak,
-            "traffic": traffic,
-            "traffic_source": traffic_source,
-            "traffic_rejected": traffic_rejected,
-            "compulsory_bytes": compulsory,
-            "traffic_over_compulsory": None if traffic is None else traffic / compulsory,
-            "note": "; ".join(note),
-            "kernel": instance,
-            "kernel_ms": k_ms,
-            "obs_counts": ("border tiles from tables of epochs per shift (the stack has no masked pixel), none needed elsewhere"
-                           if int(last.edge_count_tables) and args.mask_fraction == 0.0 else "counted per sample where NO_DATA can occur"),
-            "padded_copy": ("kept from the first search of this array (the library built the array and nothing has written into it)"
-                            if int(last.padded_copy_reused) else "made by this search (decode-and-pad pass inside the step)"),
-            "env_overrides": int(last.env_overrides),   # KBMOD_* switches set in this process (0: none; include/kbmod_hip.h)
-            "kernel_evals_per_s": evals_per_step_rank / (k_ms * 1e-3),
-            "frac_algorithmic": alg_rate / HBM_PEAK_GBPS,
-            "algorithmic_bytes_per_launch": int(last.algorithmic_bytes),
-            "algorithmic_GBps": alg_rate,
-            "fabric_GBps": fabric_rate,
-            "fabric_frac_of_hbm_peak": None if fabric_rate is None else fabric_rate / HBM_PEAK_GBPS,
-            "fabric_frac_of_achievable": None if fabric_rate is None else fabric_rate / HBM_ACHIEVABLE_GBPS,
-            "hbm_peak_GBps": HBM_PEAK_GBPS,
-            "hbm_achievable_GBps": HBM_ACHIEVABLE_GBPS,
-            "hbm_measured_copy_GBps": float(copy_gbps.value) or None,
-            "hbm_measured_read_GBps": float(read_gbps.value) or None,
-            "lds_read_bytes_per_launch": int(last.lds_read_bytes),
-            "lds_read_GBps": lds_rate,
-            "lds_guide_peak_GBps": LDS_PEAK_GBPS,
-            "lds_measured_peak_GBps": float(lds_gbps.value) or None,
-            "frac_of_guide_lds": None if not last.lds_read_bytes else lds_rate / LDS_PEAK_GBPS,
-            "frac_of_measured_lds": None if not (last.lds_read_bytes and lds_gbps.value) else lds_rate / float(lds_gbps.value),
-            "psi_phi_bytes": int(meta.total_array_size),
-            "cache_resident": bool(cache_resident),
-        },
+    roof = roofline_block(kernel_ms=k_ms, algorithmic_bytes=int(last.algorithmic_bytes), lds_read_bytes=int(last.lds_read_bytes),
+                          evals_per_step=evals_per_step_rank, traffic=traffic, traffic_source=traffic_source,
+                          traffic_rejected=traffic_rejected, compulsory_bytes=compulsory, padded_copy_bytes_guess=padded_guess,
+                          is_lds_kernel=is_lds_kernel, kernel=instance, edge_count_tables=int(last.edge_count_tables),
+                          mask_fraction=args.mask_fraction, padded_copy_reused=int(last.padded_copy_reused),
+                          env_overrides=int(last.env_overrides), copy_gbps=copy_gbps.value, read_gbps=read_gbps.value,
+                          lds_gbps=lds_gbps.value, psi_phi_bytes=int(meta.total_array_size))
+    config = {
+        "workload": f"{T}x{H}x{W} psi/phi ({'float32' if args.num_bytes in (-1, 4) else 'uint%d' % (8 * args.num_bytes)}), "
+                    f"full {W}x{H} start grid x {n_local} (v,theta) candidates per GPU, K={K}, "
+                    f"sigma-G {'on, min_obs %d' % (T // 2) if args.sigmag else 'off'}"
+                    + (f", min_lh {float(params.min_lh):g}" if float(params.min_lh) > 0 else "")
+                    + (f", {args.mask_fraction:g} of the science pixels masked" if args.mask_fraction > 0 else "")
+                    + ("; a step = one whole search of the resident array (tables + search kernel); the one-time decode-and-pad "
+                       "pass of the array's first search is outside the steps and reported in first_search"
+                       if int(last.padded_copy_reused) else ""),
+        "frames": T, "height": H, "width": W, "candidates_per_gpu": n_local, "results_per_pixel": K,
+        "sharding": ("candidates (v,theta) by rank (angle rows dealt boustrophedon); psi/phi replicated; "
+                     + (f"sparse exchange (one count byte per pixel + the records with lh >= {float(params.min_lh):g} of {list_len} "
+                        "per pixel: one RCCL gather of the headers + one message per rank) + per-pixel merge, tie-exact" if sparse
+                        else f"one RCCL gather of 16-byte records to rank 0 ({list_len} per pixel) + per-pixel merge, "
+                        + ("tie-exact" if exact_ties else "ties by candidate index")))
+                    if dist_mode else "none",
+        "psi_phi_build_ms": build_ms,
     }
+    out = headline_line(total_evals=total_evals, elapsed_s=elapsed, world=world, steps=args.steps, warmup=args.warmup, dtype=dtype,
+                        config=config, roofline=roof)
     if dist_mode:
-        out["exchange"] = {"form": "sparse" if sparse else "dense", "list_len": list_len, "backend": backend,
+        # what a SCALE record needs to explain itself: every rank's own search time (device, HIP events) gathered to rank 0,
+        # what one rank put on the wire, the root's merge, the form of the exchange and how many ranks the backend ran
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "search_kernel_ms": k_ms, "search_call_ms": float(np.mean(call_ms))})
+        out["exchange"] = {"form": "sparse" if sparse else "dense", "exchange_form": "sparse" if sparse else "dense",
+                           "list_len": list_len, "backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
                            "wire_bytes_per_rank": wire.get("wire_bytes"), "dense_bytes_per_rank": S * list_len * 16,
                            "records_per_rank": wire.get("totals"), "overlapped": bool(not sparse and not args.no_overlap),
-                           "search_wrote_counts": wire.get("search_wrote_counts")}
+                           "search_wrote_counts": wire.get("search_wrote_counts"),
+                           "per_rank_search_ms": [p["search_call_ms"] for p in per_rank],
+                           "per_rank_search_kernel_ms": [p["search_kernel_ms"] for p in per_rank],
+                           "merge_ms": kdist.last_merge_ms() if rank == 0 else None}
     if build_kernel_ms is not None:
         in_out = float(T) * H * W * 8 + float(meta.total_array_size)  # sci + var in, the array out
         out["psi_phi_build"] = {"kernel": "separable strip (<= 1e-4)" if args.separable_psf else "2-D strip (bit-identical)",
@@ -574,6 +615,40 @@ def main():
                          "merged_likelihoods_equal_ok": bool(lh_same), "tie_exact": bool(exact_ties), "backend": backend,
                          "exchange": "sparse" if sparse else "dense", "world": world}
 
+    # What a pipeline that builds ONE StackSearch and calls search_all once pays (the reference's, run_search.py:363-378): the
+    # builder + the first search of a FRESH array, whose padded canonical copy does not exist yet -- the timed steps above search
+    # an array whose copy the warm-up search made.  Wall clock, every piece synchronised; the second search of the same fresh
+    # array is the steady step again, the difference is the decode-and-pad pass.
+    if rank == 0 and world == 1 and not dist_mode and not args.child:
+        sci_f, var_f, _, _ = synthetic_stack(torch, dev, T, H, W, args.mask_fraction)
+        meta_f, arr_f = Meta(), C.c_void_p()
+        res_f = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        check(lib, lib.kb_build_psi_phi_from_device_ex(sci_f.data_ptr(), var_f.data_ptr(), psf_all.ctypes.data, psf_dims.ctypes.data,
+                                                       T, H, W, args.num_bytes, build_flags, C.byref(meta_f), C.byref(arr_f), stream))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        st_f = [Stats(), Stats()]
+        t_s = [t1]
+        for i in range(2):
+            check(lib, lib.kb_device_search_filter(C.byref(meta_f), arr_f, times.data_ptr(), params, cands.data_ptr(), n_local,
+                                                   res_f.data_ptr(), S * K, base_flags, stream, C.byref(st_f[i])))
+            torch.cuda.synchronize()
+            t_s.append(time.perf_counter())
+        out["first_search"] = {
+            "first_search_ms": (t_s[1] - t0) * 1e3,                 # builder + (tables + decode-and-pad + search kernel)
+            "build_ms": (t1 - t0) * 1e3,
+            "first_search_call_ms": (t_s[1] - t1) * 1e3,
+            "second_search_call_ms": (t_s[2] - t_s[1]) * 1e3,
+            "pad_pass_ms": ((t_s[1] - t1) - (t_s[2] - t_s[1])) * 1e3 if int(st_f[1].padded_copy_reused) else None,
+            "padded_copy_made_by_first": not bool(st_f[0].padded_copy_reused),
+            "padded_copy_reused_by_second": bool(st_f[1].padded_copy_reused),
+            "results_equal_the_timed_steps": bool(torch.equal(res_f.view(torch.int32), results.view(torch.int32))),
+        }
+        lib.kb_free_gpu_block(arr_f)
+        del sci_f, var_f, res_f
+
     # The same workload on a stack with 1 % of its science pixels masked -- what every real survey stack looks like: then
     # every tile of kb_search_lds counts observations per sample instead of taking them from tables.
     if rank == 0 and world == 1 and not dist_mode and not args.no_masked and args.mask_fraction == 0.0 and T * H * W * 16 < (8 << 30):
@@ -583,7 +658,7 @@ def main():
                                                        T, H, W, args.num_bytes, build_flags, C.byref(meta_m), C.byref(arr_m), stream))
         torch.cuda.synchronize()
         del sci_m, var_m
-        el_m, k_m, last_m = run_timed(meta_m, arr_m, args.warmup, args.steps)
+        el_m, k_m, last_m, _ = run_timed(meta_m, arr_m, args.warmup, args.steps)
         out["masked"] = {"mask_fraction": 0.01, "ms_per_step": el_m / args.steps * 1e3, "kernel_ms": float(np.mean(k_m)),
                          "value": int(last_m.num_evals) * args.steps / el_m, "unit": "evals/s",
                          "kernel": last_m.kernel_name.decode(), "steps": args.steps,

@@ -194,9 +194,12 @@ int kb_generate_psi_phi_host(const float* sci_host, const float* var_host, int w
  * 512  (changes the result under ties) per-pixel lists by stable insertion -- the top K by (likelihood descending,
  *      candidate ascending) instead of the reference's swap-down order: the per-device half of the tie-exact
  *      multi-GPU exchange (kb_merge_compact_exact), not a search result of its own.
- *      An array the library built itself (kb_build_psi_phi_*: it allocated it and is its only writer) needs no vouching:
- *      its copy stands until a library call writes into the array (kb_copy_block_to_gpu, kb_copy_block_between_gpus) or
- *      frees it -- the canonical frame is made once per array, by its first search, not once per search.
+ *      An array the library built itself (kb_build_psi_phi_*: it allocated it) needs no vouching: its copy stands until
+ *      something writes into the array or it is freed -- the canonical frame is made once per array, by its first search,
+ *      not once per search.  The library's own writers (kb_copy_block_to_gpu, kb_copy_block_between_gpus) say so
+ *      themselves; a caller that stores into such an array by ANY other means (its own kernel, hipMemcpy, a tensor view)
+ *      must call kb_note_array_written(psi_phi_dev) afterwards, and must release the array with kb_free_gpu_block and
+ *      nothing else -- the library knows the array by its address.
  * 2048 never reuse a padded copy (every search re-makes it: measurements of the pad pass, tests).
  * 1024 the caller drops every result below params.min_lh afterwards (the reference does, stack_search.cpp:266-270; the
  *      sparse exchange kb_sparsify_compact does): the kernels then need not insert such candidates.  The slots at or
@@ -211,6 +214,10 @@ int kb_device_search_filter(const kb_psi_phi_meta* meta, const void* psi_phi_dev
                             kb_search_stats* stats_out);
 
 int kb_release_workspaces(void);
+/* new: the caller wrote into a device block by means the library cannot see.  If ptr_dev lies inside an array built by
+ * kb_build_psi_phi_*, every padded copy made of that array (on any device) is stale from now on and the next search
+ * re-makes it; any other pointer is ignored.  Returns 0. */
+int kb_note_array_written(const void* ptr_dev);
 
 /* ---- the same search with 16-byte result records (new; multi-GPU exchange format).  x / y follow from the
  * slot, vx / vy from the candidate: a record carries (lh, flux, candidate index, obs_count), 16 instead of

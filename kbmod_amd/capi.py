@@ -86,6 +86,7 @@ def load_lib():
     lib.kb_merge_sparse_exact_counted.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, Params,
                                                   C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.kb_free_gpu_block.argtypes = [C.c_void_p]
+    lib.kb_note_array_written.argtypes = [C.c_void_p]
     lib.kb_copy_block_to_cpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.kb_copy_block_to_gpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.kb_measure_copy_bandwidth.argtypes = [C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]

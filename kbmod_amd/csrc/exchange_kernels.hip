@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void kb_sparsify_counted_kernel(const kb_compa
     __shared__ uint32_t wave_sums[4];
     if (block_totals[blockIdx.x] == 0) return;
     const uint64_t pix = (uint64_t)blockIdx.x * SPARSE_BLOCK + threadIdx.x;
-    const uint32_t c = pix < n_pixels ? counts[pix] : 0u;
+    const uint32_t c = pix < n_pixels ? min((uint32_t)counts[pix], (uint32_t)L) : 0u;
     uint32_t total = 0;
     const uint32_t before = block_scan_256(c, wave_sums, &total);
     const kb_compact_result* src = lists + pix * (uint64_t)L;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void kb_compact_counted_full_kernel(const kb_t
     __shared__ uint32_t wave_sums[4];
     if (block_totals[blockIdx.x] == 0) return;
     const uint64_t pix = (uint64_t)blockIdx.x * SPARSE_BLOCK + threadIdx.x;
-    const uint32_t c = pix < n_pixels ? counts[pix] : 0u;
+    const uint32_t c = pix < n_pixels ? min((uint32_t)counts[pix], (uint32_t)L) : 0u;
     uint32_t total = 0;
     const uint32_t before = block_scan_256(c, wave_sums, &total);
     const int lane = threadIdx.x & 63;
@@ -185,11 +185,13 @@ __global__ __launch_bounds__(1024) void kb_sparse_scan_kernel(const uint32_t* __
 // counts[list][pixel] -> totals[list][block]
 __global__ __launch_bounds__(256) void kb_sparse_blocksum_kernel(const uint8_t* __restrict__ headers, uint64_t header_stride,
                                                                  uint64_t n_pixels, uint64_t n_blocks,
-                                                                 uint32_t* __restrict__ totals) {
+                                                                 uint32_t* __restrict__ totals, uint32_t cap) {
     __shared__ uint32_t wave_sums[4];
     const uint64_t blk = blockIdx.x, list = blockIdx.y;
     const uint64_t pix = blk * SPARSE_BLOCK + threadIdx.x;
-    const uint32_t c = pix < n_pixels ? headers[list * header_stride + pix] : 0u;
+    // (a count byte is the caller's: one above the list length is cut to it here and in every kernel that reads through the
+    // counts, so that no record behind a pixel's list -- or behind the buffer -- is ever touched)
+    const uint32_t c = pix < n_pixels ? min((uint32_t)headers[list * header_stride + pix], cap) : 0u;
     uint32_t total = 0;
     (void)block_scan_256(c, wave_sums, &total);
     if (threadIdx.x == 0) totals[list * n_blocks + blk] = total;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void kb_merge_sparse_exact_kernel(const uint8_
         cnt[r] = 0;
         off[r] = 0;
         if (r < n_lists) {  // (uniform)
-            const uint32_t c = live ? headers[(uint64_t)r * header_stride + pix] : 0u;
+            const uint32_t c = live ? min((uint32_t)headers[(uint64_t)r * header_stride + pix], (uint32_t)K2) : 0u;
             uint32_t total = 0;
             off[r] = block_scan_256(c, wave_sums, &total);
             cnt[r] = c;
@@ -448,7 +450,7 @@ int kb_sparsify_counted(const kb_compact_result* lists_dev, uint64_t n_pixels, i
     uint64_t* total_dev = reinterpret_cast<uint64_t*>(header_dev + (n_pixels + 15) / 16 * 16);
     KB_HIP_TRY(hipMemsetAsync(header_dev + n_pixels, 0, kb_sparse_header_bytes(n_pixels) - n_pixels, stream));
     hipLaunchKernelGGL(kb_sparse_blocksum_kernel, dim3((unsigned)n_blocks, 1), dim3(256), 0, stream, header_dev, (uint64_t)0, n_pixels,
-                       n_blocks, totals);
+                       n_blocks, totals, (uint32_t)list_len);
     KB_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(kb_sparse_scan_kernel, dim3(1), dim3(1024), 0, stream, totals, n_blocks, bases, total_dev);
     KB_HIP_TRY(hipGetLastError());
@@ -487,7 +489,7 @@ int compact_counted_full(const kb_trajectory* lists_dev, uint64_t n_pixels, int 
     uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + n_blocks * 8);
     uint64_t* total_dev = reinterpret_cast<uint64_t*>(static_cast<char*>(scratch) + (n_blocks * 12 + 15) / 16 * 16);
     hipLaunchKernelGGL(kb_sparse_blocksum_kernel, dim3((unsigned)n_blocks, 1), dim3(256), 0, stream, counts_dev, (uint64_t)0, n_pixels,
-                       n_blocks, totals);
+                       n_blocks, totals, (uint32_t)L);
     KB_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(kb_sparse_scan_kernel, dim3(1), dim3(1024), 0, stream, totals, n_blocks, bases, total_dev);
     KB_HIP_TRY(hipGetLastError());
@@ -526,9 +528,9 @@ int kb_merge_sparse_exact_counted(const uint8_t* headers_dev, uint64_t header_st
     const int64_t sh = (int64_t)params.y_start_max - params.y_start_min;
     const int K = (int)params.results_per_pixel;
     if (sw <= 0 || sh <= 0) return fail("merge_sparse_exact: invalid search bounds");
-    if (K <= 0 || list_len < K || list_len > MERGE_EXACT_MAX_K2) {
+    if (K <= 0 || list_len < std::max(K, 2 * K - 1) || list_len > MERGE_EXACT_MAX_K2) {
         return fail("merge_sparse_exact: lists of " + std::to_string(list_len) + " records per pixel for " + std::to_string(K) +
-                    " results (need K <= list length <= 32; exact from 2 K - 1 on)");
+                    " results (need 2 K - 1 <= list length <= 32: the merge is exact from there on)");
     }
     const uint64_t n_pixels = (uint64_t)sw * (uint64_t)sh;
     if (header_stride < kb_sparse_header_bytes(n_pixels)) return fail("merge_sparse_exact: header stride shorter than a header");
@@ -548,7 +550,7 @@ int kb_merge_sparse_exact_counted(const uint8_t* headers_dev, uint64_t header_st
     uint64_t* bases = reinterpret_cast<uint64_t*>(scratch);
     uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + (uint64_t)n_lists * n_blocks * 8);
     hipLaunchKernelGGL(kb_sparse_blocksum_kernel, dim3((unsigned)n_blocks, (unsigned)n_lists), dim3(256), 0, stream, headers_dev,
-                       header_stride, n_pixels, n_blocks, totals);
+                       header_stride, n_pixels, n_blocks, totals, (uint32_t)list_len);
     KB_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(kb_sparse_scan_kernel, dim3((unsigned)n_lists), dim3(1024), 0, stream, totals, n_blocks, bases,
                        static_cast<uint64_t*>(nullptr));

@@ -27,7 +27,6 @@ using conv_array = py::array_t<float, py::array::c_style | py::array::forcecast>
 // Non-converting image argument (image utils are bound with noconvert).
 using strict_array = py::array_t<float, py::array::c_style>;
 
-static uint64_t g_last_merge_ambiguous = 0;  // of the last host-twin merge (last_merge_ambiguous)
 
 static Image to_image(const py::array& arr) {
     if (arr.ndim() != 2) throw std::runtime_error("Expected a 2-dimensional array.");
@@ -389,9 +388,6 @@ PYBIND11_MODULE(search, m) {
               return res;
           });
 
-    m.def("last_merge_ambiguous", []() { return g_last_merge_ambiguous; },
-          "Pixels of the last merge_compact_exact_host / merge_sparse_exact_host call whose lists were too short to decide a tie at\n"
-          "the K-th value (lists of fewer than 2 K - 1 records with a hidden-tie mark on their last record; search_math.h).");
     m.def("merge_compact_exact_host",
           [](py::array_t<uint8_t, py::array::c_style> raw, int n_lists, int list_len, int K, int x_min, int x_max, int y_min,
              int y_max, const std::vector<Trajectory>& all_cands) {
@@ -400,11 +396,9 @@ PYBIND11_MODULE(search, m) {
               if ((uint64_t)raw.size() != (uint64_t)n_lists * n_pixels * list_len * sizeof(kb_compact_result)) {
                   throw std::runtime_error("merge_compact_exact_host: buffer size does not match n_lists * n_pixels * list_len * 16");
               }
-              uint64_t n_ambiguous = 0;
               std::vector<Trajectory> out = merge_compact_exact_host(
                       reinterpret_cast<const kb_compact_result*>(raw.data()), n_lists, n_pixels, list_len, K, x_max - x_min,
-                      x_min, y_min, all_cands.data(), all_cands.size(), &n_ambiguous);
-              g_last_merge_ambiguous = n_ambiguous;
+                      x_min, y_min, all_cands.data(), all_cands.size());
               py::array_t<uint8_t> res((py::ssize_t)(out.size() * sizeof(Trajectory)));
               if (!out.empty()) std::memcpy(res.mutable_data(), out.data(), out.size() * sizeof(Trajectory));
               return res;
@@ -448,11 +442,8 @@ PYBIND11_MODULE(search, m) {
                   }
                   ptrs.push_back(reinterpret_cast<const kb_compact_result*>(packed[r].data()));
               }
-              uint64_t n_ambiguous = 0;
               std::vector<Trajectory> out = merge_sparse_exact_host(headers.data(), header_stride, ptrs, n_pixels, list_len, K,
-                                                                    x_max - x_min, x_min, y_min, all_cands.data(), all_cands.size(),
-                                                                    &n_ambiguous);
-              g_last_merge_ambiguous = n_ambiguous;
+                                                                    x_max - x_min, x_min, y_min, all_cands.data(), all_cands.size());
               py::array_t<uint8_t> res((py::ssize_t)(out.size() * sizeof(Trajectory)));
               if (!out.empty()) std::memcpy(res.mutable_data(), out.data(), out.size() * sizeof(Trajectory));
               return res;

@@ -244,11 +244,9 @@ inline std::vector<Trajectory> merge_compact_host(const kb_compact_result* lists
 // (kb::merge_exact_pixel of search_math.h, the routine the device kernel runs).
 inline std::vector<Trajectory> merge_compact_exact_host(const kb_compact_result* lists, int n_lists, uint64_t n_pixels,
                                                         int list_len, int K, int sw, int x_min, int y_min,
-                                                        const Trajectory* all_cands, uint64_t n_all_cands,
-                                                        uint64_t* n_ambiguous = nullptr) {
-    if (n_ambiguous != nullptr) *n_ambiguous = 0;
-    if (K <= 0 || list_len < K || list_len > kb::MERGE_EXACT_MAX_K2) {
-        throw std::runtime_error("merge_compact_exact: need K <= list length <= 32");
+                                                        const Trajectory* all_cands, uint64_t n_all_cands) {
+    if (K <= 0 || list_len < std::max(K, 2 * K - 1) || list_len > kb::MERGE_EXACT_MAX_K2) {
+        throw std::runtime_error("merge_compact_exact: need 2 K - 1 <= list length <= 32");
     }
     std::vector<Trajectory> out(n_pixels * (uint64_t)K);
     const uint64_t stride = n_pixels * (uint64_t)list_len;
@@ -258,9 +256,7 @@ inline std::vector<Trajectory> merge_compact_exact_host(const kb_compact_result*
     for (uint64_t pix = 0; pix < n_pixels; ++pix) {
         const kb_compact_result* mine = lists + pix * (uint64_t)list_len;
         auto read = [&](int r, int pos) { return mine[(uint64_t)r * stride + pos]; };
-        bool ambiguous = false;
-        const int n_out = kb::merge_exact_pixel(read, n_lists, list_len, K, merged, heads.data(), slots, &ambiguous);
-        if (ambiguous && n_ambiguous != nullptr) *n_ambiguous += 1;
+        const int n_out = kb::merge_exact_pixel(read, n_lists, list_len, K, merged, heads.data(), slots);
         const int y_i = (int)(pix / (uint64_t)sw), x_i = (int)(pix % (uint64_t)sw);
         for (int s = 0; s < K; ++s) {
             Trajectory t;
@@ -275,7 +271,7 @@ inline std::vector<Trajectory> merge_compact_exact_host(const kb_compact_result*
                     t.vy = all_cands[rec.cand].vy;
                     t.lh = rec.lh;
                     t.flux = rec.flux;
-                    t.obs_count = rec.obs_count & ~kb::HIDDEN_TIE_BIT;
+                    t.obs_count = rec.obs_count;
                 }
             }
             out[pix * K + s] = t;
@@ -312,12 +308,10 @@ inline void sparsify_compact_host(const kb_compact_result* lists, uint64_t n_pix
 inline std::vector<Trajectory> merge_sparse_exact_host(const uint8_t* headers, uint64_t header_stride,
                                                        const std::vector<const kb_compact_result*>& packed, uint64_t n_pixels,
                                                        int list_len, int K, int sw, int x_min, int y_min,
-                                                       const Trajectory* all_cands, uint64_t n_all_cands,
-                                                       uint64_t* n_ambiguous = nullptr) {
-    if (n_ambiguous != nullptr) *n_ambiguous = 0;
+                                                       const Trajectory* all_cands, uint64_t n_all_cands) {
     const int n_lists = (int)packed.size();
-    if (K <= 0 || list_len < K || list_len > kb::MERGE_EXACT_MAX_K2) {
-        throw std::runtime_error("merge_sparse_exact: need K <= list length <= 32");
+    if (K <= 0 || list_len < std::max(K, 2 * K - 1) || list_len > kb::MERGE_EXACT_MAX_K2) {
+        throw std::runtime_error("merge_sparse_exact: need 2 K - 1 <= list length <= 32");
     }
     if (header_stride < sparse_header_bytes(n_pixels)) throw std::runtime_error("merge_sparse_exact: header stride shorter than a header");
     std::vector<Trajectory> out(n_pixels * (uint64_t)K);
@@ -331,9 +325,7 @@ inline std::vector<Trajectory> merge_sparse_exact_host(const uint8_t* headers, u
             if (pos < (int)headers[(uint64_t)r * header_stride + pix]) rec = packed[r][at[r] + (uint64_t)pos];
             return rec;
         };
-        bool ambiguous = false;
-        const int n_out = kb::merge_exact_pixel(read, n_lists, list_len, K, merged, heads.data(), slots, &ambiguous);
-        if (ambiguous && n_ambiguous != nullptr) *n_ambiguous += 1;
+        const int n_out = kb::merge_exact_pixel(read, n_lists, list_len, K, merged, heads.data(), slots);
         const int y_i = (int)(pix / (uint64_t)sw), x_i = (int)(pix % (uint64_t)sw);
         for (int s = 0; s < K; ++s) {
             Trajectory t;
@@ -348,7 +340,7 @@ inline std::vector<Trajectory> merge_sparse_exact_host(const uint8_t* headers, u
                     t.vy = all_cands[rec.cand].vy;
                     t.lh = rec.lh;
                     t.flux = rec.flux;
-                    t.obs_count = rec.obs_count & ~kb::HIDDEN_TIE_BIT;
+                    t.obs_count = rec.obs_count;
                 }
             }
             out[pix * K + s] = t;

@@ -13,12 +13,15 @@ namespace kb {
 
 // Arrays the library built itself (kb_build_psi_phi_*: it allocated them and is their only writer) are known to be
 // unchanged between searches unless a library call wrote into them, so a search may keep the padded copy it made of one
-// (search_kernels.hip) without the caller vouching for it (flag 256).  note_array_built: registers [p, p + bytes) and drops
-// whatever was remembered about that address range; note_array_written: a library call stored into the range (the copy of a
-// containing array is stale); note_array_gone: the block was freed.
+// (search_kernels.hip) without the caller vouching for it (flag 256).  Every such array has a generation that is renewed by
+// whatever writes it; a padded copy stands while the generation it was made from is still the array's.
+// note_array_built: registers [p, p + bytes) with a fresh generation and drops whatever was remembered about blocks it
+// overlaps; note_array_written: something stored into the range (library calls that write say so themselves, a caller that
+// writes by its own means says so through kb_note_array_written); note_array_gone: the block was freed.
 void note_array_built(const void* p, uint64_t bytes);
 void note_array_written(const void* p);
 void note_array_gone(const void* p);
+uint64_t array_generation(const void* p);  // 0: not an array the library built
 bool array_is_library_owned(const void* p);
 
 // Thread-local message behind kb_last_error().

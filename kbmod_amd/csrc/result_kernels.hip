@@ -526,8 +526,9 @@ extern "C" int kb_filter_sort_results_counted(const kb_trajectory* results_dev, 
     kb_trajectory* compact = reinterpret_cast<kb_trajectory*>(base);
     kb_trajectory* counted = reinterpret_cast<kb_trajectory*>(base + rec_bytes + 256 + tmp_all + 4 * key_bytes);
     size_t kept = (size_t)total;
-    if (min_obs > 0) {
-        // (a counted record passes the likelihood test by construction; the observation count is tested here)
+    {
+        // Both tests run over the counted records, whatever the counts were made with: the counts are the caller's (a search
+        // with another min_lh, a merge), and a record they admit that this call's thresholds do not must not come through.
         if (compact_counted_full(results_dev, n_pixels, list_len, counts_dev, counted, total, &total, stream)) return 1;
         unsigned long long* count = reinterpret_cast<unsigned long long*>(base + rec_bytes);
         if (select_records(counted, total, pred, base + rec_bytes + 256, compact, count, stream)) return 1;
@@ -535,8 +536,6 @@ extern "C" int kb_filter_sort_results_counted(const kb_trajectory* results_dev, 
         KB_HIP_TRY(hipMemcpyAsync(&kept_dev, count, sizeof(kept_dev), hipMemcpyDeviceToHost, stream));
         KB_HIP_TRY(hipStreamSynchronize(stream));
         kept = (size_t)kept_dev;
-    } else {
-        if (compact_counted_full(results_dev, n_pixels, list_len, counts_dev, compact, total, &total, stream)) return 1;
     }
     *n_out_host = kept;
     if (kept == 0) return 0;

@@ -547,9 +547,10 @@ struct PaddedKey {
     int num_bytes = 0, fmt = 0, canon = 0;
     float scale[4] = {0, 0, 0, 0};
     int64_t Hp = 0, Wp = 0, px0 = 0, py0 = 0;
+    uint64_t generation = 0;  // of a library-built array when the copy was made (0: an array the caller vouches for, flag 256)
     bool valid = false;
     bool same(const PaddedKey& o) const {
-        return valid && o.valid && src == o.src && copy == o.copy && T == o.T && H == o.H && W == o.W &&
+        return valid && o.valid && src == o.src && copy == o.copy && generation == o.generation && T == o.T && H == o.H && W == o.W &&
                num_bytes == o.num_bytes && fmt == o.fmt && canon == o.canon && scale[0] == o.scale[0] &&
                scale[1] == o.scale[1] && scale[2] == o.scale[2] && scale[3] == o.scale[3] && Hp == o.Hp && Wp == o.Wp &&
                px0 == o.px0 && py0 == o.py0;
@@ -558,36 +559,36 @@ struct PaddedKey {
 static PaddedKey g_padded_key[MAX_DEVICES];
 
 // ---- arrays built (hence owned) by the library: kb_common.h ----
+// Every owned array carries a generation, drawn from one counter and renewed whenever a library call builds or writes the
+// array (or the caller says it wrote: kb_note_array_written).  A padded copy remembers the generation it was made from
+// (PaddedKey::generation) and stands only while the array still has it -- nothing here reaches into another device's key, so
+// the per-device lock of the searches is the only lock a key ever needs.
 struct OwnedArray {
     const char* ptr;
     uint64_t bytes;
+    uint64_t generation;
 };
 static std::mutex g_owned_mutex;
 static std::vector<OwnedArray> g_owned;
-static void forget_padded_copies_of(const char* lo, const char* hi) {  // (g_owned_mutex held)
-    for (int dev = 0; dev < MAX_DEVICES; ++dev) {
-        const char* src = static_cast<const char*>(g_padded_key[dev].src);
-        // (no device lock: a search of that very array cannot be running while it is rebuilt, written or freed)
-        if (g_padded_key[dev].valid && src >= lo && src < hi) g_padded_key[dev].valid = false;
-    }
-}
+static uint64_t g_next_generation = 1;  // (g_owned_mutex held; 0 = "not an owned array")
 void note_array_built(const void* p, uint64_t bytes) {
     std::lock_guard<std::mutex> lock(g_owned_mutex);
     const char* c = static_cast<const char*>(p);
-    forget_padded_copies_of(c, c + bytes);
-    for (OwnedArray& o : g_owned) {
-        if (o.ptr == c) {
-            o.bytes = bytes;
-            return;
+    // whatever was remembered about blocks this one overlaps is about memory that has been handed out again
+    for (size_t i = 0; i < g_owned.size();) {
+        if (g_owned[i].ptr < c + bytes && c < g_owned[i].ptr + g_owned[i].bytes) {
+            g_owned.erase(g_owned.begin() + (long)i);
+        } else {
+            ++i;
         }
     }
-    g_owned.push_back(OwnedArray{c, bytes});
+    g_owned.push_back(OwnedArray{c, bytes, g_next_generation++});
 }
 void note_array_written(const void* p) {
     std::lock_guard<std::mutex> lock(g_owned_mutex);
     const char* c = static_cast<const char*>(p);
-    for (const OwnedArray& o : g_owned) {
-        if (c >= o.ptr && c < o.ptr + o.bytes) forget_padded_copies_of(o.ptr, o.ptr + o.bytes);
+    for (OwnedArray& o : g_owned) {
+        if (c >= o.ptr && c < o.ptr + o.bytes) o.generation = g_next_generation++;
     }
 }
 void note_array_gone(const void* p) {
@@ -595,19 +596,19 @@ void note_array_gone(const void* p) {
     const char* c = static_cast<const char*>(p);
     for (size_t i = 0; i < g_owned.size(); ++i) {
         if (g_owned[i].ptr == c) {
-            forget_padded_copies_of(c, c + g_owned[i].bytes);
             g_owned.erase(g_owned.begin() + (long)i);
             return;
         }
     }
 }
-bool array_is_library_owned(const void* p) {
+uint64_t array_generation(const void* p) {
     std::lock_guard<std::mutex> lock(g_owned_mutex);
     for (const OwnedArray& o : g_owned) {
-        if (o.ptr == static_cast<const char*>(p)) return true;
+        if (o.ptr == static_cast<const char*>(p)) return o.generation;
     }
-    return false;
+    return 0;
 }
+bool array_is_library_owned(const void* p) { return array_generation(p) != 0; }
 
 static int current_device_slot() {
     int dev = 0;
@@ -1048,7 +1049,8 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                     // The copy (and its NO_DATA counter) of the previous search stands when nothing that determines it has
                     // changed and the array is known to be the same bits: the caller vouches for it (flag 256), or the library
                     // built the array itself and no library call has written into it since (kb_common.h).  Flag 2048: never.
-                    const bool unchanged = (flags & 256u) != 0 || array_is_library_owned(psi_phi_dev);
+                    key.generation = array_generation(psi_phi_dev);  // (read once: a write noted from here on renews it)
+                    const bool unchanged = (flags & 256u) != 0 || key.generation != 0;
                     if (unchanged && (flags & 2048u) == 0 && have_key.same(key)) {
                         padded_reused = 1;
                     } else {
@@ -1377,6 +1379,11 @@ int kb_release_workspaces(void) {
     return 0;
 }
 
+int kb_note_array_written(const void* ptr_dev) {
+    if (ptr_dev != nullptr) kb::note_array_written(ptr_dev);
+    return 0;
+}
+
 int kb_merge_topk(const kb_trajectory* lists_dev, int32_t n_lists, uint64_t n_pixels, int32_t K,
                   kb_trajectory* out_dev, void* stream_v) {
     using namespace kb;
@@ -1428,9 +1435,9 @@ int kb_merge_compact_exact(const kb_compact_result* lists_dev, int32_t n_lists, 
     const int64_t sh = (int64_t)params.y_start_max - params.y_start_min;
     const int K = (int)params.results_per_pixel;
     if (sw <= 0 || sh <= 0) return fail("merge_compact_exact: invalid search bounds");
-    if (K <= 0 || list_len < K || list_len > MERGE_EXACT_MAX_K2) {
+    if (K <= 0 || list_len < std::max(K, 2 * K - 1) || list_len > MERGE_EXACT_MAX_K2) {
         return fail("merge_compact_exact: lists of " + std::to_string(list_len) + " records per pixel for " + std::to_string(K) +
-                    " results (need K <= list length <= 32; exact from 2 K - 1 on)");
+                    " results (need 2 K - 1 <= list length <= 32: the merge is exact from there on)");
     }
     KB_REQUIRE_DEVICE("the list merge.");
     (void)hipGetLastError();

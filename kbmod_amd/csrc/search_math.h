@@ -310,16 +310,9 @@ KB_HD void evaluate_trajectory_full(const kb_psi_phi_meta& m, const void* arr, c
 // final list.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int MERGE_EXACT_MAX_K2 = 32;
-// Lists of fewer than 2 K - 1 records (down to K) merge exactly too, as long as nothing they hide can matter.  A device's
-// stable list of L records is its top L under (likelihood descending, candidate ascending); what it hides lies below its
-// last record, and the only hidden candidates the replay could need are those EQUAL to the pixel's K-th value v (everything
-// above v is among the first K of the union, and every list supplies its own first K).  A producer of such
-// lists marks a list's last record -- bit 30 of obs_count -- when a candidate equal to it was refused or fell off the end; a
-// pixel is AMBIGUOUS when a full list whose last record carries the mark ends on v: then, and only then, lists of 2 K records
-// are needed (*ambiguous).  The mark never reaches an output record.  (No search of this library sets the mark any more: the
-// marking of the packed register lists was built, measured and reverted -- border pixels tie by the thousand and the marking
-// cost every search 1.5 % --; the lists the exchange uses hold 2 K records and never carry it.)
-constexpr int32_t HIDDEN_TIE_BIT = 1 << 30;
+// Exact from lists of 2 K - 1 records on (G lies inside the first 2 K - 1 entries of the union under that order); the entry
+// points refuse shorter lists.  (A K-record form with a "hidden tie" mark on a list's last record was built, measured and
+// taken out again in round 4 -- LABNOTES.md --; nothing of it is left here.)
 struct MergedEntry {
     float lh;
     int cand;
@@ -328,7 +321,7 @@ struct MergedEntry {
 
 template <typename ReadRecord>
 KB_HD int merge_exact_pixel(const ReadRecord& read, int n_lists, int K2, int K, MergedEntry* merged,
-                                                 int* heads, int* slots, bool* ambiguous = nullptr) {
+                                                 int* heads, int* slots) {
     // (1) the first entries of the union by (lh descending, candidate ascending) -- K2 of them, 2 K - 1 when the lists are
     // shorter than that --; every list is in that order
     for (int r = 0; r < n_lists; ++r) heads[r] = 0;
@@ -358,16 +351,6 @@ KB_HD int merge_exact_pixel(const ReadRecord& read, int n_lists, int K2, int K, 
         merged[n].at = (uint32_t)(best * K2 + heads[best]);
         heads[best] += 1;
         n += 1;
-    }
-    if (ambiguous != nullptr) {
-        *ambiguous = false;
-        if (n >= K) {
-            const float kth = merged[K - 1].lh;
-            for (int r = 0; r < n_lists; ++r) {
-                const kb_compact_result last = read(r, K2 - 1);
-                if (last.cand >= 0 && (last.obs_count & HIDDEN_TIE_BIT) != 0 && last.lh == kth) *ambiguous = true;
-            }
-        }
     }
     // (2) nothing equal among the first K + 1: the prefix is the list
     bool strict = true;

@@ -63,6 +63,39 @@ def shard_bounds(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_last_merge_events = None
+
+
+class _MergeTimer:
+    """HIP events around the last device merge on the current stream (read later by last_merge_ms: no sync here)."""
+
+    def __init__(self, on_device):
+        self.on = on_device
+
+    def __enter__(self):
+        if self.on:
+            import torch
+
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        global _last_merge_events
+        if self.on:
+            self.e1.record()
+            _last_merge_events = (self.e0, self.e1)
+        return False
+
+
+def last_merge_ms():
+    """Device time of this process's last merge launch sequence (None before the first, or for host-twin merges)."""
+    if _last_merge_events is None:
+        return None
+    _last_merge_events[1].synchronize()
+    return float(_last_merge_events[0].elapsed_time(_last_merge_events[1]))
+
+
 def device_lib():
     """libkbmod_hip.so via ctypes (kbmod_amd.capi); raises when it is not built (no fallback)."""
     from kbmod_amd import capi
@@ -103,8 +136,9 @@ def merge_compact(gathered, x_bounds, y_bounds, K, all_cands, out=None):
     if gathered.is_cuda:
         lib = device_lib()
         stream = torch.cuda.current_stream().cuda_stream
-        rc = lib.kb_merge_compact(gathered.data_ptr(), world, _bounds(x_bounds, y_bounds, K), all_cands.data_ptr(),
-                                  all_cands.shape[0], out.data_ptr(), stream)
+        with _MergeTimer(True):
+            rc = lib.kb_merge_compact(gathered.data_ptr(), world, _bounds(x_bounds, y_bounds, K), all_cands.data_ptr(),
+                                      all_cands.shape[0], out.data_ptr(), stream)
         if rc != 0:
             raise RuntimeError(lib.kb_last_error().decode())
     else:
@@ -135,8 +169,9 @@ def merge_compact_exact(gathered, x_bounds, y_bounds, K, list_len, all_cands, ou
     if gathered.is_cuda:
         lib = device_lib()
         stream = torch.cuda.current_stream().cuda_stream
-        rc = lib.kb_merge_compact_exact(gathered.data_ptr(), world, int(list_len), _bounds(x_bounds, y_bounds, K),
-                                        all_cands.data_ptr(), all_cands.shape[0], out.data_ptr(), stream)
+        with _MergeTimer(True):
+            rc = lib.kb_merge_compact_exact(gathered.data_ptr(), world, int(list_len), _bounds(x_bounds, y_bounds, K),
+                                            all_cands.data_ptr(), all_cands.shape[0], out.data_ptr(), stream)
         if rc != 0:
             raise RuntimeError(lib.kb_last_error().decode())
     else:
@@ -270,10 +305,11 @@ def merge_sparse_exact(headers, packed_list, x_bounds, y_bounds, K, list_len, al
         if counts_out is not None and not (counts_out.dtype == torch.uint8 and counts_out.numel() == n_pixels
                                            and counts_out.is_contiguous() and counts_out.device == headers.device):
             raise ValueError(f"counts_out: expected a contiguous uint8 tensor of {n_pixels} bytes on the headers' device")
-        rc = lib.kb_merge_sparse_exact_counted(headers.data_ptr(), int(headers.shape[1]), ptrs, n_lists, int(list_len),
-                                               _bounds(x_bounds, y_bounds, K), all_cands.data_ptr(), all_cands.shape[0],
-                                               out.data_ptr(), None if counts_out is None else counts_out.data_ptr(),
-                                               torch.cuda.current_stream().cuda_stream)
+        with _MergeTimer(True):
+            rc = lib.kb_merge_sparse_exact_counted(headers.data_ptr(), int(headers.shape[1]), ptrs, n_lists, int(list_len),
+                                                   _bounds(x_bounds, y_bounds, K), all_cands.data_ptr(), all_cands.shape[0],
+                                                   out.data_ptr(), None if counts_out is None else counts_out.data_ptr(),
+                                                   torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError(lib.kb_last_error().decode())
     else:
@@ -303,7 +339,11 @@ def gather_and_merge_sparse(local_records, x_bounds, y_bounds, K, list_len, min_
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    me = dist.get_rank()
+    # `dst` is a GLOBAL rank (what gather / send take); the lists are ordered by GROUP rank, and with a sub-group, or a
+    # group whose ranks do not start at 0, the two differ: peers of the point-to-point messages are named globally
+    me_global = dist.get_rank()
+    me = dist.get_rank(group)
+    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
     n_pixels = (int(x_bounds[1]) - int(x_bounds[0])) * (int(y_bounds[1]) - int(y_bounds[0]))
     if counted:
         header, packed, total = sparsify_counted(local_records, n_pixels, list_len, header, packed)
@@ -314,7 +354,7 @@ def gather_and_merge_sparse(local_records, x_bounds, y_bounds, K, list_len, min_
     p_send = packed[:total].cpu() if via_host else packed[:total]
     if stats is not None:
         stats["wire_bytes"] = int(header.numel()) + 16 * total
-    if me != dst:
+    if me_global != dst:
         dist.gather(h_send, None, dst=dst, group=group)
         if total:
             dist.send(p_send, dst=dst, group=group)
@@ -331,7 +371,7 @@ def gather_and_merge_sparse(local_records, x_bounds, y_bounds, K, list_len, min_
             continue
         bufs.append(torch.empty((int(totals[r]), COMPACT_WORDS), dtype=torch.int32, device=h_send.device))
         if totals[r]:
-            ops.append(dist.P2POp(dist.irecv, bufs[r], r, group))
+            ops.append(dist.P2POp(dist.irecv, bufs[r], peer(r), group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()

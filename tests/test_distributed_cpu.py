@@ -122,6 +122,34 @@ def _sparse_worker(rank, world, port, out_dir, min_lh):
         dist.destroy_process_group()
 
 
+def _subgroup_worker(rank, world, port, out_dir):
+    """Both exchanges inside a sub-group whose ranks do not start at 0: global ranks 1 and 2 of a world of 3 search the two
+    halves of the candidate list, the root is GLOBAL rank 1 (group rank 0); global rank 0 takes no part."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kbmod_amd import distributed as kdist
+        from oracle import oracle as orc
+
+        group = dist.new_group([1, 2])   # (every rank of the world calls this)
+        if rank == 0:
+            return
+        K = 4
+        pp, vx, vy, local_t, all_cands = _stable_rank_lists(dist.get_rank(group), 2, K)
+        sparse = kdist.gather_and_merge_sparse(local_t, (0, 40), (0, 24), K, 2 * K, 2.5, all_cands, group=group, dst=1)
+        dense = kdist.gather_and_merge_compact(local_t, (0, 40), (0, 24), K, all_cands, list_len=2 * K, group=group, dst=1)
+        assert (sparse is None) == (rank != 1) and (dense is None) == (rank != 1)
+        if rank == 1:
+            full = pp.search_kernel_semantics(orc.make_candidates(vx, vy), pp.default_params(results_per_pixel=K))
+            np.save(os.path.join(out_dir, "sparse.npy"), sparse.numpy().reshape(-1).view(orc.TRJ_DTYPE))
+            np.save(os.path.join(out_dir, "dense.npy"), dense.numpy().reshape(-1).view(orc.TRJ_DTYPE))
+            np.save(os.path.join(out_dir, "full.npy"), full)
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -233,3 +261,18 @@ def test_sparse_gather_and_merge(tmp_path, orc, kb, world, min_lh):
         assert 0 < n_pass < full.size // 2 and wire < dense_bytes // 2  # a thresholded search: fewer bytes than the dense lists
     else:
         assert n_pass > full.size // 2 and wire > dense_bytes // 2
+
+
+def test_exchange_inside_a_subgroup(tmp_path, orc, kb):
+    """`dst` is a global rank, the lists are ordered by group rank: a sub-group {1, 2} with root 1 must gather, receive from the
+    right peers and merge exactly as the default group does."""
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    full = np.load(tmp_path / "full.npy").reshape(-1, 4)
+    dense = np.load(tmp_path / "dense.npy").reshape(-1, 4)
+    sparse = np.load(tmp_path / "sparse.npy").reshape(-1, 4)
+    assert dense.tobytes() == full.tobytes()
+    empty = np.float32(-3.4028234663852886e38)
+    for p in range(full.shape[0]):
+        want = full[p][(full[p]["lh"] != empty) & ~(full[p]["lh"] < np.float32(2.5))]
+        assert sparse[p, :len(want)].tobytes() == want.tobytes()
+        assert (sparse[p, len(want):]["lh"] == empty).all()

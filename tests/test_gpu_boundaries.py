@@ -178,6 +178,20 @@ def test_padded_copy_of_a_library_built_array_is_made_once(kb, orc):
     assert s8.padded_copy_reused == 0 and not torch.equal(changed, first)
     direct, _ = d.search(p, cands, 2)      # kb_search_direct reads the array itself
     assert torch.equal(changed, direct)
+    # the caller writes by means the library cannot see (a device-to-device copy of its own) and says so:
+    # kb_note_array_written renews the array's generation, the copy made from the old one no longer stands
+    _, s8b = d.search(p, cands, 4)
+    assert s8b.padded_copy_reused == 1
+    host[:, 41, 60, 0] += 700.0
+    mine = torch.from_numpy(host).to(f"cuda:{torch.cuda.current_device()}")
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(d.arr, mine.data_ptr(), host.nbytes, 3) == 0   # hipMemcpyDeviceToDevice
+    torch.cuda.synchronize()
+    capi.check(d.lib.kb_note_array_written(C.c_void_p(d.arr.value + 12345)))   # (any address inside the array)
+    noted, s8c = d.search(p, cands, 4)
+    direct2, _ = d.search(p, cands, 2)
+    assert s8c.padded_copy_reused == 0 and torch.equal(noted, direct2) and not torch.equal(noted, changed)
     # freed and rebuilt (most likely at the same address): nothing of the old array's copy is taken over
     d.close()
     st2 = util.make_stack(16, 70, 130, seed=78, objects=[(60, 20, -9.0, 12.0, 300.0)], times=np.arange(16) / 16.0)

@@ -85,9 +85,10 @@ def _oracle_view(orc, lib, meta, arr, times):
     return pp
 
 
-@pytest.mark.parametrize("num_bytes,sigmag", [(-1, False), (1, True)])
-def test_headline_search_windows_against_the_oracle(orc, num_bytes, sigmag):
-    """configs[1] / configs[2] at full size (64 x 512 x 512, 1024 candidates, the bench's own stack): windows of
+@pytest.mark.parametrize("num_bytes,sigmag,mask_fraction", [(-1, False, 0.0), (1, True, 0.0), (-1, False, 0.01)])
+def test_headline_search_windows_against_the_oracle(orc, num_bytes, sigmag, mask_fraction):
+    """configs[1] / configs[2] at full size (64 x 512 x 512, 1024 candidates, the bench's own stack; and configs[1] on the
+    stack with 1 % of its science pixels masked, the bench line's `masked` entry): windows of
     the product's result buffer against the ORACLE on the same array -- the kernel-semantics search bit for bit
     and, for configs[1] (min_obs 0, no sigma-G: the regime where the reference's CPU and GPU searches select the
     same trajectories), the reference CPU StackSearch semantics as per-pixel likelihood lists."""
@@ -103,7 +104,7 @@ def test_headline_search_windows_against_the_oracle(orc, num_bytes, sigmag):
     lib = capi.load_lib()
     dev = torch.device("cuda")
     T, H, W, K = 64, 512, 512, 8
-    sci, var, times, psf = bench.synthetic_stack(torch, dev, T, H, W)
+    sci, var, times, psf = bench.synthetic_stack(torch, dev, T, H, W, mask_fraction)
     psf_all = np.ascontiguousarray(np.tile(psf.ravel(), T), dtype=np.float32)
     psf_dims = np.full(T, psf.shape[0], dtype=np.int32)
     meta, arr = capi.Meta(), C.c_void_p()
@@ -155,6 +156,107 @@ def test_headline_search_windows_against_the_oracle(orc, num_bytes, sigmag):
             assert untied.any()
             for i, name in ((0, "vx"), (1, "vy"), (3, "flux")):
                 assert np.array_equal(win[..., i][untied], cpu[name][untied]), ("cpu semantics", name, (x0, y0))
+    lib.kb_free_gpu_block(arr)
+
+
+def _row_band_view(orc, lib, meta, arr, times, y_lo, y_hi):
+    """Rows [y_lo, y_hi) of every epoch of the device array, full width, wrapped for the oracle as an array of y_hi - y_lo
+    rows (start row y of the band = image row y + y_lo).  The arrays of configs[3] / configs[4] do not fit a host copy in
+    seconds; a window's trajectories only ever read the rows between the window and its farthest shift, and with epochs at
+    i / T days (T a power of two) every predicted position x + v t + 0.5 is exact in double, so the translation changes no
+    rounding: the band search equals the full-array search of the same start pixels as long as the band holds every row they
+    reach -- rows beyond the band's end are beyond the image's end too (the caller clips y_hi to H), or unreachable."""
+    import numpy as np
+
+    T, H, W = int(meta.num_times), int(meta.height), int(meta.width)
+    rows = y_hi - y_lo
+    per_px = 2 * int(meta.block_size)
+    dtype = {4: np.float32, 2: np.uint16, 1: np.uint8}[meta.num_bytes]
+    host = np.empty((T, rows, W, 2), dtype=dtype)
+    for t in range(T):   # one contiguous block of rows per epoch
+        src = arr.value + (t * H + y_lo) * W * per_px
+        assert lib.kb_copy_block_to_cpu(host[t].ctypes.data, src, rows * W * per_px) == 0
+    pp = orc.PsiPhi.__new__(orc.PsiPhi)
+    pp.meta = orc.Meta(T, W, rows, meta.num_bytes, meta.psi_min_val, meta.psi_max_val, meta.psi_scale, meta.phi_min_val,
+                       meta.phi_max_val, meta.phi_scale)
+    pp.array = host.reshape(-1)
+    pp.times = np.ascontiguousarray(times, dtype=np.float64)
+    pp.T, pp.H, pp.W, pp.nb = T, rows, W, int(meta.num_bytes)
+    return pp
+
+
+BIG = {
+    # configs[3], one GPU's share: 128 x 4096 x 4096 float32, 64 candidates (bench.py --frames 128 --size 4096 --vel-steps 32 --ang-steps 2)
+    "cfg4_shard": dict(T=128, N=4096, vel=32, ang=2, num_bytes=-1, win=(96, 8)),
+    # configs[4]: 512 x 2048 x 2048 uint16, 4096 candidates (3e8 oracle evaluations per 24 x 6 window)
+    "cfg5_deep_u16": dict(T=512, N=2048, vel=64, ang=64, num_bytes=2, win=(24, 6)),
+}
+
+
+@pytest.mark.parametrize("name", list(BIG))
+def test_hbm_resident_search_windows_against_the_oracle(orc, name):
+    """configs[3] (one GPU's share) and configs[4] AT FULL SIZE against the oracle itself: the bench's own stack and candidate
+    list, one whole-grid search through the C ABI, then four windows of the result buffer -- an image corner (trajectories
+    start on the border), the interior, a mover's neighbourhood, the far edge (trajectories leave the image) -- compared on all
+    seven fields with the oracle's kernel-semantics search over the band of rows those start pixels can reach."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    import bench
+    from kbmod_amd import capi
+    from kbmod_amd import fake_data as fd
+
+    cfg = BIG[name]
+    lib = capi.load_lib()
+    dev = torch.device("cuda")
+    T, H, W, K = cfg["T"], cfg["N"], cfg["N"], 8
+    sci, var, times, psf = bench.synthetic_stack(torch, dev, T, H, W)
+    psf_all = np.ascontiguousarray(np.tile(psf.ravel(), T), dtype=np.float32)
+    psf_dims = np.full(T, psf.shape[0], dtype=np.int32)
+    meta, arr = capi.Meta(), C.c_void_p()
+    stream = torch.cuda.current_stream().cuda_stream
+    capi.check(lib.kb_build_psi_phi_from_device(sci.data_ptr(), var.data_ptr(), psf_all.ctypes.data, psf_dims.ctypes.data,
+                                                T, H, W, cfg["num_bytes"], C.byref(meta), C.byref(arr), stream))
+    torch.cuda.synchronize()
+    del sci, var
+    vx, vy = fd.kbmod_v1_candidates(cfg["vel"], 5.0, 40.0, cfg["ang"], 0.0, 1.5)
+    cands_np = np.zeros((len(vx), 7), dtype=np.float32)
+    cands_np[:, 0], cands_np[:, 1] = vx, vy
+    cands = torch.from_numpy(cands_np).to(dev)
+    nb = -1 if cfg["num_bytes"] in (-1, 4) else cfg["num_bytes"]
+    params = capi.Params(0, 0.0, 0, 0.25, 0.75, -1.0, nb, 0, W, 0, H, K, 0)
+    results = torch.empty((H * W * K, 7), dtype=torch.float32, device=dev)
+    st = capi.Stats()
+    capi.check(lib.kb_device_search_filter(C.byref(meta), arr, times.data_ptr(), params, cands.data_ptr(), len(vx),
+                                           results.data_ptr(), H * W * K, 0, stream, C.byref(st)))
+    torch.cuda.synchronize()
+    assert st.kernel_variant // 10000 == 2, st.kernel_name   # kb_search_lds on the canonical float copy
+    grid = results.view(H, W, K, 7)
+
+    tcpu = times.cpu().numpy()
+    assert float(vy.min()) >= 0.0 and float(vx.min()) >= 0.0   # (the grid's angles: shifts towards +x, +y only)
+    reach = int(np.ceil(float(max(vx.max(), vy.max())) * float(tcpu[-1]))) + 2
+    ocands = orc.make_candidates(vx, vy)
+    obj_rng = np.random.default_rng(99)
+    mx, my = int(obj_rng.integers(20, W - 60)), int(obj_rng.integers(20, H - 60))
+    w, h = cfg["win"]
+    for (x0, y0) in [(0, 0), (W // 2 - 19, H // 2 + 7), (max(0, mx - w // 3), max(0, my - 2)), (W - w, H - h)]:
+        y_lo, y_hi = y0, min(H, y0 + h + reach)
+        pp = _row_band_view(orc, lib, meta, arr, tcpu, y_lo, y_hi)
+        p = pp.default_params(x_start_min=x0, x_start_max=x0 + w, y_start_min=0, y_start_max=h, results_per_pixel=K)
+        exp = pp.search_kernel_semantics(ocands, p).reshape(h, w, K)
+        win = grid[y0:y0 + h, x0:x0 + w].cpu().numpy()
+        for i, field in enumerate(("vx", "vy", "lh", "flux", "x", "y", "obs_count")):
+            col = win[..., i]
+            want = exp[field]
+            if field in ("x", "y", "obs_count"):
+                col = col.view(np.int32)
+            if field == "y":
+                want = want + y_lo   # band rows -> image rows
+            assert np.array_equal(col, want), (name, field, (x0, y0))
+        assert (exp["lh"] > -1e30).all()   # (every slot filled: min_lh 0 on noise)
     lib.kb_free_gpu_block(arr)
 
 

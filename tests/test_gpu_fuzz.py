@@ -56,3 +56,38 @@ def test_random_configuration(kb, orc, seed):
     if num_bytes != -1:
         c, _, _ = util.run_both(kb, orc, stack, vx, vy, cfg, num_bytes=num_bytes, flags=LDS | ENCODED_STAGING)
         assert np.array_equal(c, exp)
+
+
+# The code-path switches of the search entry points (include/kbmod_hip.h `flags`) and the environment switches the library reads
+# per search (KBMOD_LIST_MODE, KBMOD_CHUNK, KBMOD_EDGE_COUNTS): none of them may change a bit of the result.
+FLAG_BITS = [8,      # double-precision decode of encoded samples
+             32,     # never the count-free specialisation
+             1024,   # the lists' floor (search_all applies the post-filter the flag relies on)
+             2048]   # re-make the padded copy
+SWITCHES = {"KBMOD_LIST_MODE": ["0", "1", "2", "3", "4"], "KBMOD_CHUNK": ["8", "16", "32"], "KBMOD_EDGE_COUNTS": ["0", "1"]}
+
+
+@pytest.mark.parametrize("seed", range(2000, 2040))
+def test_random_flags_and_switches(kb, orc, seed, monkeypatch):
+    """Every seed draws its own subset of the flag bits and of the environment switches on top of a random configuration; the
+    staged kernel (either tile height, drawn too) must still equal the oracle bit for bit, and must say which switches were set."""
+    stack, vx, vy, cfg, num_bytes = _config(seed)
+    rng = np.random.default_rng(seed + 77)
+    flags = LDS | int(rng.choice([TALL_TILES, WIDE_TILES, 0]))
+    for bit in FLAG_BITS:
+        if rng.random() < 0.35:
+            flags |= bit
+    if num_bytes != -1 and rng.random() < 0.3:
+        flags |= ENCODED_STAGING
+    set_names = []
+    for name, values in SWITCHES.items():
+        if rng.random() < 0.5:
+            monkeypatch.setenv(name, str(rng.choice(values)))
+            set_names.append(name)
+    got, exp, s = util.run_both(kb, orc, stack, vx, vy, cfg, num_bytes=num_bytes, flags=flags)
+    stats = s.last_search_stats()
+    assert got.shape == exp.shape and np.array_equal(got, exp), \
+        f"flags {flags} switches {set_names} kernel variant {stats['kernel_variant']} differ from the oracle (seed {seed})"
+    order = ["KBMOD_CHUNK", "KBMOD_LIST_MODE", "KBMOD_EDGE_COUNTS"]   # bit i of env_overrides (search_kernels.hip: kSwitches)
+    for name in set_names:
+        assert stats["env_overrides"] & (1 << order.index(name)), (name, stats["env_overrides"])
