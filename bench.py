@@ -623,7 +623,13 @@ def main():
         sci_f, var_f, _, _ = synthetic_stack(torch, dev, T, H, W, args.mask_fraction)
         meta_f, arr_f = Meta(), C.c_void_p()
         res_f = torch.empty((S * K, 7), dtype=torch.float32, device=dev)
+        # (one untimed build + free first: the device allocator then holds a block of the array's size, and what is timed below
+        # is the builder and the search, not a fresh multi-gigabyte hipMalloc)
+        check(lib, lib.kb_build_psi_phi_from_device_ex(sci_f.data_ptr(), var_f.data_ptr(), psf_all.ctypes.data, psf_dims.ctypes.data,
+                                                       T, H, W, args.num_bytes, build_flags, C.byref(meta_f), C.byref(arr_f), stream))
         torch.cuda.synchronize()
+        lib.kb_free_gpu_block(arr_f)
+        arr_f = C.c_void_p()
         t0 = time.perf_counter()
         check(lib, lib.kb_build_psi_phi_from_device_ex(sci_f.data_ptr(), var_f.data_ptr(), psf_all.ctypes.data, psf_dims.ctypes.data,
                                                        T, H, W, args.num_bytes, build_flags, C.byref(meta_f), C.byref(arr_f), stream))

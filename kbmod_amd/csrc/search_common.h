@@ -25,6 +25,10 @@ constexpr int CHUNK = KB_CHUNK;    // candidates accumulated together per wave
 // ... and by the packed-list float-staged instance of kb_search_lds (K <= 8, one slab in flight): twice the candidates per
 // staged slab halve the passes over the stack, and with them the bytes that cross the fabric (what bounds that kernel)
 constexpr int WIDE_CHUNK = 2 * CHUNK;
+// ... and by the instance for arrays beyond the 256 MiB Infinity Cache (packed lists, K <= 8, a stack without NO_DATA pixels):
+// there the kernel is bound by the bytes that cross the fabric -- N_candidates / chunk passes over the padded copy --, and four
+// times the candidates per staged slab are worth more than sixteen samples in flight (64 accumulator registers leave eight)
+constexpr int XWIDE_CHUNK = 4 * CHUNK;
 #ifndef KB_DIRECT_ROWS
 #define KB_DIRECT_ROWS 4
 #endif
@@ -61,6 +65,10 @@ constexpr int LDS_COLS = KB_LDS_COLS;  // widest slab in pixels: 64 start column
 #ifndef KB_LDS_ALIGN_PX
 #define KB_LDS_ALIGN_PX 2
 #endif
+// ... 64 + up to 48 for chunks of XWIDE_CHUNK candidates (a whole row of speeds of the reference's grids: 35 pixels of spread a
+// day at 5 .. 40 pixels a day); the padded frame is sized for this width whatever the chunk, so that one copy serves every search
+constexpr int LDS_COLS_XWIDE = 112;
+__host__ __device__ constexpr int lds_cols(int chunk) { return chunk >= XWIDE_CHUNK ? LDS_COLS_XWIDE : LDS_COLS; }
 constexpr int LDS_ALIGN_PX = KB_LDS_ALIGN_PX;  // slab origins are multiples of this many columns of the padded frame
 #ifndef KB_LDS_SLOTS
 #define KB_LDS_SLOTS 2

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(DIRECT_ROWS * WAVE, (KS <= 8 ? 4 : (KS <= 16 ? 3 : 
             accumulate_chunk_direct_all<C, NB, 1>(a, chunk, tc.x, tc.y, pix0, ps, ph, cnt);
         }
         if constexpr (RECORDS && KS <= 8) {
-            finish_chunk_packed<KS, C>(a, chunk, ps, ph, cnt, packed);
+            finish_chunk_packed<KS, C>(a, chunk * C, ps, ph, cnt, packed);
         } else if constexpr (RECORDS) {
             finish_chunk_records<KS, C>(a, chunk, ps, ph, cnt, rec);
         } else {

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
                                                              EpochBox* __restrict__ boxes,
                                                              int* __restrict__ lds_off,
                                                              int* __restrict__ n_not_lds,
-                                                             int* __restrict__ global_box, int tile_rows, int col_quantum) {
+                                                             int* __restrict__ global_box, int tile_rows, int col_quantum,
+                                                             int max_cols) {
     // One workgroup per chunk, one thread per epoch (strided): the thread owns the
     // C shifts of its epoch, their bounding box and the LDS offsets derived from it.
     const int chunk = blockIdx.x;
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
     int rows_max = tile_rows;
     int sx_min = INT32_MAX, sx_max = INT32_MIN, sy_min = INT32_MAX, sy_max = INT32_MIN;  // staged epochs only
     int n_per_lane = 0;
+    int not_monotone = 0;  // (chunks of XWIDE_CHUNK) a candidate whose shift shrinks or changes sign from one epoch to the next
     int cols_max = WAVE + col_quantum;  // widest staged footprint of the chunk
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
         const double tm = times[t];
@@ -158,6 +160,20 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
                     ey0 = min(ey0, sh[c].y - (ky ? 1 : 0));
                     ey1 = max(ey1, sh[c].y + (ky ? 1 : 0));
                 }
+                if constexpr (C == XWIDE_CHUNK) {
+                    // What the edge tables need (kb_edge_count_kernel checks it again on the device: the instance for chunks
+                    // of 32 has no counting loop to fall back on, so its host must know before the launch): along both axes
+                    // the magnitude of a candidate's shift never shrinks and its sign never changes from epoch to epoch.
+                    if (t > 0 && kx == 0 && ky == 0) {
+                        int jx = 0, jy = 0;
+                        const int px = uniform_shift(cands[ci].vx, times[t - 1], &jx), py = uniform_shift(cands[ci].vy, times[t - 1], &jy);
+                        const int ax = sh[c].x < 0 ? -sh[c].x : sh[c].x, ay = sh[c].y < 0 ? -sh[c].y : sh[c].y;
+                        const int bx = px < 0 ? -px : px, by = py < 0 ? -py : py;
+                        if (jx != 0 || jy != 0 || ax < bx || ay < by || (long long)sh[c].x * px < 0 || (long long)sh[c].y * py < 0) {
+                            not_monotone += 1;
+                        }
+                    }
+                }
                 if (kx != 0 || ky != 0) {
                     sh[c].x = SHIFT_UNSAFE;
                     epoch_unsafe = true;
@@ -176,9 +192,9 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
         // before and after); it is kept because it costs nothing and removes one variable, not because
         // the memory pipe was shown to need it.
         if (ex0 <= ex1) ex0 -= ((ex0 % LDS_ALIGN_PX) + LDS_ALIGN_PX) % LDS_ALIGN_PX;
-        // A slab of (tile rows + dy spread) x LDS_COLS 8-byte pairs must fit one group buffer.
-        const bool fits = !epoch_wild && ex0 <= ex1 && (ex1 - ex0) <= (LDS_COLS - WAVE) &&
-                          (tile_rows + ey1 - ey0) * LDS_COLS * 8 <= lds_group_bytes(tile_rows) && ex0 > -30000 && ex1 < 30000 &&
+        // A slab of (tile rows + dy spread) x max_cols 8-byte pairs (lds_cols of the chunk width) must fit one group buffer.
+        const bool fits = !epoch_wild && ex0 <= ex1 && (ex1 - ex0) <= (max_cols - WAVE) &&
+                          (tile_rows + ey1 - ey0) * max_cols * 8 <= lds_group_bytes(tile_rows) && ex0 > -30000 && ex1 < 30000 &&
                           ey0 > -30000 && ey1 < 30000;
         EpochBox box = make_int2(0, (tile_rows << 16) | WAVE);
         if (fits) {
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
             dy_max = max(dy_max, ey1);
         }
     }
-    __shared__ int red[13][256];
+    __shared__ int red[14][256];
     red[0][threadIdx.x] = dx_min;
     red[1][threadIdx.x] = dx_max;
     red[2][threadIdx.x] = dy_min;
@@ -226,6 +242,7 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
     red[10][threadIdx.x] = sy_max;
     red[11][threadIdx.x] = n_per_lane;
     red[12][threadIdx.x] = cols_max;
+    red[13][threadIdx.x] = not_monotone;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
@@ -242,6 +259,7 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
             red[10][threadIdx.x] = max(red[10][threadIdx.x], red[10][threadIdx.x + s]);
             red[11][threadIdx.x] += red[11][threadIdx.x + s];
             red[12][threadIdx.x] = max(red[12][threadIdx.x], red[12][threadIdx.x + s]);
+            red[13][threadIdx.x] += red[13][threadIdx.x + s];
         }
         __syncthreads();
     }
@@ -254,8 +272,10 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
         ci.unsafe = red[4][0];
         ci.lds_ok = (red[5][0] == 0) ? 1 : 0;
         ci.rows_max = red[6][0];
-        ci.cols = min(LDS_COLS, (red[12][0] + col_quantum - 1) / col_quantum * col_quantum);
+        ci.cols = min(max_cols, (red[12][0] + col_quantum - 1) / col_quantum * col_quantum);
         chunks[chunk] = ci;
+        atomicMax(&global_box[6], ci.rows_max * ci.cols);  // largest slab of the search, in pixels
+        if (red[13][0] != 0) atomicAdd(&global_box[7], red[13][0]);
         if (red[5][0] != 0) atomicAdd(n_not_lds, red[5][0]);  // (chunk, epoch) pairs that are not staged
         if (red[11][0] != 0) atomicAdd(&global_box[5], red[11][0]);  // ... staged, but summed per lane
         atomicMax(&global_box[4], ci.rows_max);
@@ -268,7 +288,7 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
     }
     // Second pass: slab offsets of the uniformly shifted tile at the chunk's pitch (>= 0; LDS_OFF_PER_LANE: staged,
     // but the lanes find their own pixel inside the slab; LDS_OFF_UNSTAGED: not staged at all).
-    const int cols = min(LDS_COLS, (red[12][0] + col_quantum - 1) / col_quantum * col_quantum);
+    const int cols = min(max_cols, (red[12][0] + col_quantum - 1) / col_quantum * col_quantum);
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
         const EpochBox box = boxes[(size_t)chunk * T + t];  // written by this thread above
         if (box.x == BOX_NOT_STAGED) continue;
@@ -376,7 +396,9 @@ __global__ __launch_bounds__(256) void kb_slab_ref_kernel(const EpochBox* __rest
     // the offsets of the hand-scheduled loop (float-staged kernels: 8-byte pairs in LDS).  Groups start at multiples of E
     // epochs (chunk_plan of search_lds.h), slab e of a group sits e strides into the group buffer.
     const int stride = (ci.rows_max * ci.cols * 8 + 1023) & ~1023;
-    const int E = group_epochs(T, tile_rows, stride, true);  // (the table is read by the hand-scheduled instances only)
+    // (the table is read by the hand-scheduled instances only: groups of an even number of epochs for chunks of 8 and 16, of
+    // any number for chunks of 32 -- chunk_plan of search_lds.h)
+    const int E = group_epochs(T, tile_rows, stride, chunk_c != XWIDE_CHUNK);
     const int place = (t % E) * stride;
 #pragma unroll
     for (int c = 0; c < chunk_c; ++c) {
@@ -548,6 +570,7 @@ struct PaddedKey {
     float scale[4] = {0, 0, 0, 0};
     int64_t Hp = 0, Wp = 0, px0 = 0, py0 = 0;
     uint64_t generation = 0;  // of a library-built array when the copy was made (0: an array the caller vouches for, flag 256)
+    int n_invalid_host = -1;  // the copy's NO_DATA counter once some search has read it back (-1: not yet); not part of same()
     bool valid = false;
     bool same(const PaddedKey& o) const {
         return valid && o.valid && src == o.src && copy == o.copy && generation == o.generation && T == o.T && H == o.H && W == o.W &&
@@ -822,22 +845,25 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     a.tiles_x = (a.sw + WAVE - 1) / WAVE;
     // Tile height of kb_search_lds: 64 x 16 when the search area
     // gives every CU a tile of that size, 64 x 8 otherwise; flags bits 6 / 7 force one or the other (tests).
-    // Encoded staging is built for 64 x 8 only.
-    int lds_rows = LDS_ROWS_WIDE_K;
-    {
-        const bool list_fits = params.do_sigmag_filter != 0 || params.results_per_pixel <= 32;  // (kb_search_large_k beyond)
-        const int64_t tall_tiles = (int64_t)a.tiles_x * ((sh + LDS_ROWS_TALL - 1) / LDS_ROWS_TALL);
+    // Encoded staging is built for 64 x 8 only; chunks of XWIDE_CHUNK candidates for 64 x 16 only.
+    const bool list_fits = params.do_sigmag_filter != 0 || params.results_per_pixel <= 32;  // (kb_search_large_k beyond)
+    const int64_t tall_tiles = (int64_t)a.tiles_x * ((sh + LDS_ROWS_TALL - 1) / LDS_ROWS_TALL);
+    auto rows_for = [&](int chunk) {
         const bool keep_encoded = meta->num_bytes != 4 && (flags & 16u) != 0;
         // A short candidate list (up to four chunks of 16) is mostly list-filling: the first chunks of a search insert in
         // nearly every round, the sixteen waves of a 64 x 16 tile then wait at every group change for the wave with the most
         // rounds.  Two 64 x 8 workgroups per CU have separate barriers and overlap one tile's finish with the other's sums, which
         // is worth more there than the taller tile's smaller apron: 128 x 4096 x 4096 with 32 / 64 / 128 / 256 candidates 10.5 /
         // 20.2 / 40.4 / 78.8 ms against 12.7 / 22.1 / 40.4 / 74.8 ms (profiles/r04_tile_height.log).  The sigma-G emit keeps no list.
+        // (Chunks of 32: the bytes a slab's apron costs are what that instance exists to save -- tall tiles.)
+        if (chunk == XWIDE_CHUNK) return LDS_ROWS_TALL;  // (the one tile height that instance is built for)
         const bool short_list = n_cands <= 64 && params.do_sigmag_filter == 0;
         if (list_fits && !keep_encoded && ((tall_tiles >= 128 && (flags & 128u) == 0 && !short_list) || (flags & 64u) != 0)) {
-            lds_rows = LDS_ROWS_TALL;
+            return LDS_ROWS_TALL;
         }
-    }
+        return LDS_ROWS_WIDE_K;
+    };
+    int lds_rows = rows_for(CHUNK);
     a.tiles_y = (a.sh + lds_rows - 1) / lds_rows;
     a.n_tiles = a.tiles_x * a.tiles_y;
     a.K = (int)params.results_per_pixel;
@@ -868,7 +894,7 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     uint64_t padded_copy_bytes = 0;
     // (the offset tables of the hand-scheduled instances are indexed with 32-bit byte offsets: a candidate list x epochs beyond
     // that goes to kb_search_direct, which reads none of them, instead of failing)
-    const bool fold_fits = ((uint64_t)n_cands + 2 * WIDE_CHUNK) * (uint64_t)a.T * sizeof(int) <= 0x7fff0000ull;
+    const bool fold_fits = ((uint64_t)n_cands + 2 * XWIDE_CHUNK) * (uint64_t)a.T * sizeof(int) <= 0x7fff0000ull;
     const bool want_lds = (flags & 2u) == 0 && (flags & 1u) == 0 && a.K <= 32 && fold_fits &&
                           (n_cands >= 8 || (flags & 4u) != 0);
     // Candidates per chunk.  WIDE_CHUNK for the two instances of kb_search_lds built for it -- float staging; lists of up to
@@ -881,17 +907,50 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                     (emitting || ((a.K <= 8 || (a.K <= 16 && a.stable_lists != 0)) && n_cands < 65535 && a.T < 65535));
         // (list modes of the wide instances: 3 = packed records in registers, K <= 8; 4 = pooled stable lists in the store, K <= 16)
         if (const char* env = std::getenv("KBMOD_LIST_MODE")) wide = wide && (emitting || std::atoi(env) == (a.K <= 8 ? 3 : 4));
-        if (const char* env = std::getenv("KBMOD_CHUNK")) wide = wide && std::atoi(env) == WIDE_CHUNK;
-        if (wide) a.chunk = WIDE_CHUNK;
+        // Chunks of XWIDE_CHUNK: the packed-list instance again (K <= 8, reference or stable insertion), for arrays whose float
+        // copy lies beyond the Infinity Cache -- there the kernel is bound by the bytes that cross the fabric, and those fall
+        // with the candidates a staged slab serves (configs[3]'s share 88 -> 50 GB, configs[4] 5.2 -> 2.9 TB per launch) --,
+        // on 64 x 16 tiles.  The instance is count-free: it takes stacks without NO_DATA pixels whose border tiles get their
+        // counts from the edge tables; everything else that the tables must confirm is checked below.
+        const uint64_t float_copy = (uint64_t)a.T * (uint64_t)a.H * (uint64_t)a.W * 8ull;
+        // Measured (profiles/r05_chunk_width.log): per chunk of 32 the finish runs in two halves with the second half's sums parked
+        // in scratch memory, a fixed cost the sums of a deep stack amortise -- 512 epochs -13 %, 384 -10 %, 256 -5 ... -7 %, 128
+        // epochs +7 ... +11 % against chunks of 16; hence from 192 epochs on.
+        bool xwide = wide && !emitting && a.K <= 8 && n_cands >= (uint64_t)XWIDE_CHUNK && float_copy > (256ull << 20) && a.T >= 192 &&
+                     tall_tiles >= 128 && (flags & (16u | 32u | 128u)) == 0 && params.x_start_min >= 0 && params.y_start_min >= 0 &&
+                     params.x_start_max <= a.W && params.y_start_max <= a.H;
+        if (const char* env = std::getenv("KBMOD_CHUNK")) {
+            const int want = std::atoi(env);
+            // (32 asks for the instance wherever it CAN run, cache-resident arrays and small search areas included: tests)
+            xwide = want == XWIDE_CHUNK && wide && !emitting && a.K <= 8 && n_cands >= (uint64_t)XWIDE_CHUNK &&
+                    (flags & (16u | 32u | 128u)) == 0 && params.x_start_min >= 0 && params.y_start_min >= 0 &&
+                    params.x_start_max <= a.W && params.y_start_max <= a.H;
+            wide = wide && (want == WIDE_CHUNK || xwide);
+        }
+        if (const char* env = std::getenv("KBMOD_EDGE_COUNTS")) xwide = xwide && std::atoi(env) != 0;
+        {
+            // an array a previous search has found NO_DATA pixels in is not tried again (the attempt costs a pad pass)
+            const PaddedKey& prev = g_padded_key[current_device_slot()];
+            if (prev.valid && prev.src == psi_phi_dev && prev.n_invalid_host > 0 && (flags & 2048u) == 0 &&
+                ((flags & 256u) != 0 || (prev.generation != 0 && prev.generation == array_generation(psi_phi_dev)))) {
+                xwide = false;
+            }
+        }
+        if (wide) a.chunk = xwide ? XWIDE_CHUNK : WIDE_CHUNK;
     }
     bool wide_has_special = false;
     bool wide_store_failed = false;  // lists of 9 to 16 with wide chunks live in the list store: without it, chunks of CHUNK
     void* wide_lists = nullptr;
     int special_epochs = 0;
     int shift_box[4] = {0, 0, 0, 0};  // staged shift box of the tables that settled: dx_min, dx_max, dy_min, dy_max
+    bool xwide_refused = false;  // chunks of XWIDE_CHUNK were asked for and the tables (or the array) said no
+    int learned_n_invalid = -1;  // the array's NO_DATA count, once this search has read it back (a property of the array)
     for (bool settled = n_cands == 0; !settled;) {
         a.n_chunks = (int)((n_cands + a.chunk - 1) / a.chunk);
         which = 0;
+        lds_rows = rows_for(a.chunk);
+        a.tiles_y = (a.sh + lds_rows - 1) / lds_rows;
+        a.n_tiles = a.tiles_x * a.tiles_y;
         const size_t table_bytes = (size_t)a.n_chunks * a.T * a.chunk * sizeof(int2);
         const size_t off_bytes = ((size_t)a.n_chunks * a.T * a.chunk + 4 * a.chunk) * sizeof(int);  // + prefetch slack
         const size_t box_bytes = (size_t)a.n_chunks * a.T * sizeof(EpochBox);
@@ -899,8 +958,8 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         const size_t fold_bytes = want_lds ? ((size_t)a.n_chunks * a.T + SLAB_REF_SLACK) * a.chunk * sizeof(int) : 0;  // (read by kb_search_lds only)
         const size_t chunk_bytes = (size_t)a.n_chunks * sizeof(ChunkInfo);
         // NO_DATA pixel counter [1], unstaged (chunk, epoch) counter [1], staged shift box + tallest slab [5],
-        // per-lane (chunk, epoch) counter [1]
-        const size_t inv_bytes = 8 * sizeof(int);
+        // per-lane (chunk, epoch) counter [1], largest slab in pixels [1], spare [3]
+        const size_t inv_bytes = 12 * sizeof(int);
         void* ws = nullptr;
         if (fold_bytes > 0x7fffff00ull) return fail("deviceSearchFilter: candidate list x epochs too long for the offset tables");
         if (ensure_workspace(0, table_bytes + off_bytes + box_bytes + chunk_bytes + inv_bytes + org_bytes + fold_bytes + 64, &ws)) return 1;
@@ -924,27 +983,37 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         const bool tables_for_encoded = meta->num_bytes != 4 && (flags & 16u) != 0;
         const int col_quantum = tables_for_encoded ? 8 : 2;
         table_timer.begin();
-        static const int inv_init[8] = {0, 0, INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN, 0, 0};
+        static const int inv_init[12] = {0, 0, INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN, 0, 0, 0, 0, 0, 0};
         KB_HIP_TRY(hipMemcpyAsync(inv, inv_init, sizeof(inv_init), hipMemcpyHostToDevice, stream));
-        if (a.chunk == WIDE_CHUNK) {
+        const int max_cols = lds_cols(a.chunk);
+        if (a.chunk == XWIDE_CHUNK) {
+            hipLaunchKernelGGL((kb_shift_table_kernel<XWIDE_CHUNK>), dim3(a.n_chunks), dim3(256), 0, stream, cands_dev,
+                               times_dev, a.n_cands, a.T, reinterpret_cast<int2*>(wsc),
+                               reinterpret_cast<ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes),
+                               reinterpret_cast<EpochBox*>(wsc + table_bytes + off_bytes),
+                               reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox, lds_rows, col_quantum, max_cols);
+        } else if (a.chunk == WIDE_CHUNK) {
             hipLaunchKernelGGL((kb_shift_table_kernel<WIDE_CHUNK>), dim3(a.n_chunks), dim3(256), 0, stream, cands_dev,
                                times_dev, a.n_cands, a.T, reinterpret_cast<int2*>(wsc),
                                reinterpret_cast<ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes),
                                reinterpret_cast<EpochBox*>(wsc + table_bytes + off_bytes),
-                               reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox, lds_rows, col_quantum);
+                               reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox, lds_rows, col_quantum, max_cols);
         } else {
             hipLaunchKernelGGL((kb_shift_table_kernel<CHUNK>), dim3(a.n_chunks), dim3(256), 0, stream, cands_dev,
                                times_dev, a.n_cands, a.T, reinterpret_cast<int2*>(wsc),
                                reinterpret_cast<ChunkInfo*>(wsc + table_bytes + off_bytes + box_bytes),
                                reinterpret_cast<EpochBox*>(wsc + table_bytes + off_bytes),
-                               reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox, lds_rows, col_quantum);
+                               reinterpret_cast<int*>(wsc + table_bytes), n_not_lds, gbox, lds_rows, col_quantum, max_cols);
         }
         KB_HIP_TRY(hipGetLastError());
+        int largest_slab_px = 0;
         if (want_lds) {
             // The choice and the apron of the padded copy need six ints back.
-            int back[7] = {0, 0, 0, 0, 0, 0, 0};  // unstaged epochs, dx_min, dx_max, dy_min, dy_max, rows_max, per-lane epochs
+            // unstaged epochs, dx_min, dx_max, dy_min, dy_max, rows_max, per-lane epochs, largest slab, shifts that are not monotone
+            int back[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             KB_HIP_TRY(hipMemcpyAsync(back, n_not_lds, sizeof(back), hipMemcpyDeviceToHost, stream));
             KB_HIP_TRY(hipStreamSynchronize(stream));
+            largest_slab_px = back[7];
             // (the wide-chunk instance has no path for epochs that are not staged with uniform shifts)
             wide_has_special = back[0] != 0 || back[6] != 0;
             for (int k = 0; k < 4; ++k) shift_box[k] = back[1 + k];
@@ -967,14 +1036,16 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                 back[3] = std::min(back[3], 0);
                 back[4] = std::max(back[4], 0);
                 const int64_t x_lo = (int64_t)params.x_start_min + back[1];
-                const int64_t x_hi = (int64_t)params.x_start_min + (int64_t)WAVE * (a.tiles_x - 1) + back[2] + LDS_COLS;
+                // (the frame is sized for the widest pitch of any chunk width, so that the copy of one search serves the next
+                // whatever instance it launches)
+                const int64_t x_hi = (int64_t)params.x_start_min + (int64_t)WAVE * (a.tiles_x - 1) + back[2] + LDS_COLS_XWIDE;
                 const int64_t y_lo = (int64_t)params.y_start_min + back[3];
                 // rows a slab's staging rounds can touch (whole rounds are loaded, see load_slab), for either
                 // staged format
                 auto rows_touched = [&](uint64_t pair_b) {
                     // (the widest slab for the rounds, the narrowest for the rows they span: a chunk's pitch
                     // lies between 64 + quantum and LDS_COLS)
-                    const uint64_t row_b = (uint64_t)LDS_COLS * pair_b, row_b_min = (uint64_t)(WAVE + col_quantum) * pair_b;
+                    const uint64_t row_b = (uint64_t)LDS_COLS_XWIDE * pair_b, row_b_min = (uint64_t)(WAVE + col_quantum) * pair_b;
                     const uint64_t round_b = (uint64_t)stage_round(lds_rows);
                     const uint64_t rounds = ((uint64_t)back[5] * row_b + round_b - 1) / round_b;
                     return (int64_t)((rounds * round_b + row_b_min - 1) / row_b_min);
@@ -1059,6 +1130,26 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                         launch_pad(a, cold, fmt, canon, padded, n_invalid, stream);
                         KB_HIP_TRY(hipGetLastError());
                         have_key = key;
+                        have_key.n_invalid_host = learned_n_invalid;
+                    }
+                    if (a.chunk == XWIDE_CHUNK) {
+                        // The instance for chunks of 32 is count-free: what the tables must confirm, and the array.
+                        const int D = std::max(std::max(-back[1], back[2]), std::max(std::max(-back[3], back[4]), 0));
+                        void* edge_ws = nullptr;
+                        if (back[0] != 0 || back[6] != 0 || back[8] != 0 || a.all_staged == 0 || D > 200 ||
+                            (uint64_t)largest_slab_px * 8ull > 2ull * (uint64_t)stage_round(LDS_ROWS_TALL) ||
+                            !try_workspace(7, (size_t)a.n_chunks * 4 * (size_t)(D + 1) * XWIDE_CHUNK * sizeof(unsigned short) + 64, &edge_ws)) {
+                            xwide_refused = true;
+                        } else {
+                            if (have_key.n_invalid_host < 0) {  // (a sync behind the pad pass; once per copy)
+                                int n_inv = 0;
+                                KB_HIP_TRY(hipMemcpyAsync(&n_inv, n_invalid, sizeof(int), hipMemcpyDeviceToHost, stream));
+                                KB_HIP_TRY(hipStreamSynchronize(stream));
+                                have_key.n_invalid_host = n_inv;
+                            }
+                            learned_n_invalid = have_key.n_invalid_host;
+                            if (learned_n_invalid != 0) xwide_refused = true;
+                        }
                     }
                     const int64_t n_org = (int64_t)a.n_chunks * a.T;
                     hipLaunchKernelGGL(kb_slab_ref_kernel, dim3((unsigned)((n_org + SLAB_REF_SLACK + 255) / 256)), dim3(256), 0, stream,
@@ -1076,6 +1167,8 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         }
         if (a.chunk != CHUNK && (which != 2 || wide_has_special || wide_store_failed)) {
             a.chunk = CHUNK;  // the instance the wide chunks are for will not (or cannot) run: tables for the others
+        } else if (a.chunk == XWIDE_CHUNK && xwide_refused) {
+            a.chunk = WIDE_CHUNK;  // NO_DATA pixels, shifts beyond the edge tables, slabs of more than two rounds: chunks of 16
         } else {
             settled = true;
         }
@@ -1142,26 +1235,37 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     cold.edge_ok = nullptr;
     cold.edge_D = 0;
     int edge_tables = 0;
-    if (which == 2 && a.chunk == WIDE_CHUNK && a.all_staged && shift_box[0] <= shift_box[1] &&
+    if (which == 2 && a.chunk >= WIDE_CHUNK && a.all_staged && shift_box[0] <= shift_box[1] &&
         params.x_start_min >= 0 && params.y_start_min >= 0 && params.x_start_max <= a.W && params.y_start_max <= a.H) {
         const int D = std::max(std::max(-shift_box[0], shift_box[1]), std::max(std::max(-shift_box[2], shift_box[3]), 0));
         const char* env = std::getenv("KBMOD_EDGE_COUNTS");
-        const size_t tab_bytes = (size_t)a.n_chunks * 4 * (size_t)(D + 1) * WIDE_CHUNK * sizeof(unsigned short);
+        const size_t tab_bytes = (size_t)a.n_chunks * 4 * (size_t)(D + 1) * (size_t)a.chunk * sizeof(unsigned short);
         void* et = nullptr;
         if (!(env != nullptr && std::atoi(env) == 0) && D <= 200 && tab_bytes <= (256ull << 20) &&
             try_workspace(7, tab_bytes + 64, &et)) {
             int* ok = reinterpret_cast<int*>(static_cast<char*>(et) + tab_bytes);
             static const int one = 1;
             KB_HIP_TRY(hipMemcpyAsync(ok, &one, sizeof(int), hipMemcpyHostToDevice, stream));
-            hipLaunchKernelGGL((kb_edge_count_kernel<WIDE_CHUNK>), dim3(a.n_chunks), dim3(256),
-                               4 * WIDE_CHUNK * (size_t)(D + 1) * sizeof(unsigned int), stream, a.table, a.n_cands, a.T, D,
-                               reinterpret_cast<unsigned short*>(et), ok);
+            const size_t hist_bytes = 4 * (size_t)a.chunk * (size_t)(D + 1) * sizeof(unsigned int);
+            if (a.chunk == XWIDE_CHUNK) {
+                // (up to 103 KB of histograms: beyond the 64 KiB a launch gets without asking)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb_edge_count_kernel<XWIDE_CHUNK>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes);
+                hipLaunchKernelGGL((kb_edge_count_kernel<XWIDE_CHUNK>), dim3(a.n_chunks), dim3(256), hist_bytes, stream, a.table,
+                                   a.n_cands, a.T, D, reinterpret_cast<unsigned short*>(et), ok);
+            } else {
+                hipLaunchKernelGGL((kb_edge_count_kernel<WIDE_CHUNK>), dim3(a.n_chunks), dim3(256), hist_bytes, stream, a.table,
+                                   a.n_cands, a.T, D, reinterpret_cast<unsigned short*>(et), ok);
+            }
             KB_HIP_TRY(hipGetLastError());
             cold.edge_tab = reinterpret_cast<const uint4*>(et);
             cold.edge_ok = ok;
             cold.edge_D = D;
             edge_tables = 1;
         }
+    }
+    if (which == 2 && a.chunk == XWIDE_CHUNK && !edge_tables) {
+        return fail("deviceSearchFilter: internal error -- the instance for chunks of 32 candidates was chosen without its edge tables");
     }
 
     // the cold block of the kernel arguments (search_common.h) lives in device memory

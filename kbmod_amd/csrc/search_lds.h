@@ -229,24 +229,28 @@ __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) 
 template <int C>
 __device__ __forceinline__ void edge_counts(const SearchArgs& a, const TileCoords& tq, int chunk, const uint4* edge_tab,
                                             int edge_D, uint32_t (&cnte)[C / 2]) {
-    static_assert(C == 16, "rows of the edge tables hold 16 counts");
+    static_assert(C == 16 || C == 32, "rows of the edge tables hold C counts of 16 bits: whole 16-byte words");
     typedef unsigned short Us2 __attribute__((ext_vector_type(2)));
+    constexpr int Q = C / 8;  // 16-byte words per row
     const int D1 = edge_D + 1;
-    const uint4* base = edge_tab + (size_t)chunk * 4 * D1 * 2;
+    const uint4* base = edge_tab + (size_t)chunk * 4 * D1 * Q;
     auto clampd = [&](int d) { return min(max(d, 0), edge_D); };
     const int d[4] = {clampd(a.W - 1 - tq.x), clampd(tq.x), clampd(a.H - 1 - tq.y), clampd(tq.y)};
     uint32_t m[C / 2];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint4 lo = base[(k * D1 + d[k]) * 2], hi = base[(k * D1 + d[k]) * 2 + 1];
-        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-        for (int j = 0; j < C / 2; ++j) {
-            if (k == 0) {
-                m[j] = w[j];
-            } else {
-                const Us2 r = __builtin_elementwise_min(__builtin_bit_cast(Us2, m[j]), __builtin_bit_cast(Us2, w[j]));
-                m[j] = __builtin_bit_cast(uint32_t, r);
+        for (int q = 0; q < Q; ++q) {
+            const uint4 v = base[(k * D1 + d[k]) * Q + q];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (k == 0) {
+                    m[4 * q + j] = w[j];
+                } else {
+                    const Us2 r = __builtin_elementwise_min(__builtin_bit_cast(Us2, m[4 * q + j]), __builtin_bit_cast(Us2, w[j]));
+                    m[4 * q + j] = __builtin_bit_cast(uint32_t, r);
+                }
             }
         }
     }
@@ -266,8 +270,12 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     constexpr int SF = CANON ? 4 : NB;  // staged format
     using R = RawPair<SF>;
     constexpr int BYTES = 2 * fmt_bytes(SF);
-    // the float-staged, depth-1 instances run their epochs through search_lds_asm.h
-    constexpr bool HAND_SCHEDULED = CANON && (C == 8 || C == 16);
+    // the float-staged, depth-1 instances run their epochs through search_lds_asm.h (chunks of XWIDE_CHUNK: their one statement
+    // is count-free -- a tile that has to count samples, which the host keeps from this instance where it can, is summed by
+    // the compiler-scheduled loops below)
+    constexpr bool HAND_SCHEDULED = CANON && (C == 8 || C == 16 || (C == XWIDE_CHUNK && FAST));
+    // groups of an even number of epochs: the statements for chunks of 8 and 16 work in pairs of epochs
+    constexpr bool EVEN_GROUPS = CANON && (C == 8 || C == 16);
     // (the counting statements that read sixteen samples per wait take eight more registers: not for the pooled lists)
     [[maybe_unused]] constexpr bool KB_LDS_WIDE_COUNT = LM != LIST_STORE_POOLED;
     const int T = a.T;
@@ -286,7 +294,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     uint64_t prof_t = __builtin_amdgcn_s_memtime();
 #endif
     int chunk = a.chunk_lo, t0 = 0, buf = 0;
-    ChunkPlan plan = chunk_plan<BYTES, ROWS, HAND_SCHEDULED>(a, chunk);
+    ChunkPlan plan = chunk_plan<BYTES, ROWS, EVEN_GROUPS>(a, chunk);
     SlabRegs regs;
     typedef int Int4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) Int4* ConstSlabPtr;  // a SlabRef as four dwords
@@ -336,14 +344,16 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #else
             const int ng = (T - t0) / plan.E - 1;
 #endif
-            if (plan.clean && (plan.E & 1) == 0 && plan.slab_bytes <= 2 * stage_round(ROWS) && ng >= 2) {
+            constexpr bool EPOCH_TRIPS = C == XWIDE_CHUNK;  // a trip of the statement is one epoch (chunks of 32), not two
+            if (plan.clean && (EPOCH_TRIPS || (plan.E & 1) == 0) && plan.slab_bytes <= 2 * stage_round(ROWS) &&
+                ng >= (EPOCH_TRIPS ? 1 : 2)) {
                 KB_PROF_MARK(1)
                 const ConstSlabPtr first = (ConstSlabPtr)(uintptr_t)(a.slabs + (size_t)chunk * T + t0 + plan.E);
                 const int GB = lds_group_bytes(ROWS);
                 uint32_t rb = (uint32_t)(uintptr_t)(smem + buf * GB + (tc.wv * plan.cols + tq.lane) * BYTES);
                 uint32_t wd = (uint32_t)(uintptr_t)(smem + (1 - buf) * GB + 16 * tid);
                 uint32_t dr = sgpr32((uint32_t)((1 - 2 * buf) * GB));
-                const uint32_t pg = sgpr32((uint32_t)plan.E >> 1);
+                const uint32_t pg = sgpr32(EPOCH_TRIPS ? (uint32_t)plan.E : (uint32_t)plan.E >> 1);
                 uint32_t gc = pg, pairs = sgpr32((uint32_t)ng * pg);
                 const uint32_t es = sgpr32((uint32_t)(plan.E * plan.stride)), st = sgpr32((uint32_t)plan.stride);
                 const uint32_t go = n_sl.goff[0];
@@ -394,7 +404,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             n_chunk = chunk + 1;
             n_t0 = 0;
             if (n_chunk < a.chunk_hi) {
-                n_plan = chunk_plan<BYTES, ROWS, HAND_SCHEDULED>(a, n_chunk);
+                n_plan = chunk_plan<BYTES, ROWS, EVEN_GROUPS>(a, n_chunk);
                 n_sl = stage_lanes<BYTES, ROWS>(a, n_plan.cols, n_plan.slab_bytes);
             }
         }
@@ -571,15 +581,17 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             auto asm_run = [&](uint32_t nq_of_wave) {  // pieces of every staged slab this wave copies
                 const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)nq_of_wave);
                 const int wave_piece_of_run = 1024 * tc.wv;
-                static_assert((C == 8 || C == 16) && sizeof(SlabRef) == 16, "search_lds_asm.h");
-                uint32_t pairs = sgpr32((uint32_t)(n_both - e) >> 1);
+                static_assert((C == 8 || C == 16 || C == XWIDE_CHUNK) && sizeof(SlabRef) == 16, "search_lds_asm.h");
+                constexpr bool EPOCH_TRIPS = C == XWIDE_CHUNK;
+                uint32_t pairs = sgpr32(EPOCH_TRIPS ? (uint32_t)(n_both - e) : (uint32_t)(n_both - e) >> 1);
                 const uint32_t odd = sgpr32((uint32_t)(n_both - e) & 1u);
                 const int done = n_both - e;
                 uint32_t wd = (uint32_t)(uintptr_t)(nb + 16 * tid + e * n_plan.stride);
                 const uint32_t rb = (uint32_t)(uintptr_t)cb;  // this lane's pixel at the start of the group buffer
                 const uint32_t go = n_sl.goff[0];
                 const uint64_t ob = sgpr64((uint64_t)(uintptr_t)(a.lds_fold + ((size_t)chunk * T + t0 + e) * C));
-                const uint64_t gb = sgpr64((uint64_t)(uintptr_t)(n_org + (e + 1)));
+                // (the statement for chunks of 32 fetches its slab references from one entry earlier, like every LDS-DMA statement)
+                const uint64_t gb = sgpr64((uint64_t)(uintptr_t)(n_org + (EPOCH_TRIPS ? e : e + 1)));
                 const uint64_t tb = sgpr64((uint64_t)(uintptr_t)tile_base);
                 const uint64_t b0 = sgpr64(tb + (uint64_t)org_cur);
                 const uint32_t tl = (uint32_t)tb, th = (uint32_t)(tb >> 32);
@@ -588,7 +600,20 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 const uint32_t st = sgpr32((uint32_t)n_plan.stride);
                 const uint32_t gq = n_sl.goff[LDS_SLOTS >= 2 ? 1 : 0];
                 const uint32_t wq = sgpr32(wp + (uint32_t)stage_round(ROWS));
-                KB_LDS_RUN_LOOP
+                if constexpr (EPOCH_TRIPS) {
+                    // Chunks of 32 have ONE statement, the run of whole groups; a single group that stages into the other
+                    // buffer is that run without a group change: the count to the next barrier never reaches zero.
+                    uint32_t rbw = rb;
+                    uint32_t gc = sgpr32(pairs + 1u), dr = sgpr32(0u);
+                    const uint32_t pg = gc, es = sgpr32(0u);
+                    uint32_t& rb = rbw;  // (read-write operand of the statement; unchanged without a group change)
+                    [[maybe_unused]] uint32_t fc = 0;  // (named by the counting statements of the other chunk widths)
+                    [[maybe_unused]] const uint32_t fg = 0;
+                    (void)odd;
+                    KB_LDS_RUN_STREAM
+                } else {
+                    KB_LDS_RUN_LOOP
+                }
                 e += done;
                 if constexpr (!FAST) {
                     // (the counting statements subtract the NO_DATA samples from the counts, see search_lds_asm.h)
@@ -682,7 +707,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     }
                     static_assert(KS == 16, "pooled lists hold 16 slots");
                     bool by_table = false;
-                    if constexpr (FAST && C == WIDE_CHUNK) {
+                    if constexpr (FAST && C >= WIDE_CHUNK) {
                         if (edge_tab != nullptr) {  // (uniform) a tile at the image's edge: counts out of the tables
                             uint32_t cnte[C / 2];
                             edge_counts<C>(a, tq, chunk, edge_tab, edge_D, cnte);
@@ -699,13 +724,15 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             } else if (tc.row_active) {
                 float ps[C], ph[C];
                 int cnt[C];
+                // (chunks of 32 keep their counts packed two to a word all the way into the rounds: finish_half_packed)
+                constexpr bool PACKED_COUNTS = TileLists<KS, LM>::PACKED && C == XWIDE_CHUNK;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     ps[c] = acc[c].x;
                     ph[c] = acc[c].y;
-                    cnt[c] = FAST ? T : (int)((cntp[c >> 1] >> (16 * (c & 1))) & 0xffffu);
+                    if constexpr (!PACKED_COUNTS) cnt[c] = FAST ? T : (int)((cntp[c >> 1] >> (16 * (c & 1))) & 0xffffu);
                 }
-                if constexpr (FAST && C == WIDE_CHUNK) {
+                if constexpr (FAST && C >= WIDE_CHUNK && !PACKED_COUNTS) {
                     if (edge_tab != nullptr) {  // (uniform) a tile at the image's edge: counts out of the tables
                         uint32_t cnte[C / 2];
                         edge_counts<C>(a, tq, chunk, edge_tab, edge_D, cnte);
@@ -717,7 +744,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                 if constexpr (TileLists<KS, LM>::PACKED) {
                     float sink = 0.0f;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) sink += ps[c] + ph[c] + (float)cnt[c];
+                    for (int c = 0; c < C; ++c) sink += ps[c] + ph[c] + (PACKED_COUNTS ? 0.0f : (float)cnt[c]);
                     lists.packed.lh[0] = fmaxf(lists.packed.lh[0], sink);
                 } else
 #endif
@@ -728,8 +755,45 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                     finish_chunk_stored<KS, C, TileLists<KS, LM>::RECORDS>(a, chunk, ps, ph, cnt, lists.state, lists.store,
                                                                       TileLists<KS, LM>::SLOT_BYTES * threadIdx.x,
                                                                       ROWS * WAVE * TileLists<KS, LM>::SLOT_BYTES);
+                } else if constexpr (TileLists<KS, LM>::PACKED && C == XWIDE_CHUNK) {
+                    // Two halves of 16, in candidate order (the second half is screened against what the first left).  The
+                    // second half's 32 sums are PARKED in scratch memory while the first half's rounds run (handing the array's
+                    // address to an empty asm statement is what makes it a block of memory instead of registers again), and an
+                    // interior tile -- every candidate has all T observations -- carries no count registers at all: next to 64
+                    // live sums, the lists and sixteen count words the rounds reloaded a dozen spilled registers each.
+                    constexpr int HC = C / 2;
+                    float park[2 * HC];
+#pragma unroll
+                    for (int c = 0; c < HC; ++c) {
+                        park[c] = ps[HC + c];
+                        park[HC + c] = ph[HC + c];
+                    }
+                    asm volatile("" ::"v"(&park[0]) : "memory");
+                    auto halves = [&](auto counts_tag, const uint32_t (&cw)[C / 2]) {
+                        constexpr bool COUNTS = decltype(counts_tag)::value;
+                        finish_half_packed<KS, COUNTS>(a, chunk * C, reinterpret_cast<const float(&)[HC]>(ps[0]),
+                                                       reinterpret_cast<const float(&)[HC]>(ph[0]),
+                                                       reinterpret_cast<const uint32_t(&)[HC / 2]>(cw[0]), lists.packed);
+                        asm volatile("" ::"v"(&park[0]) : "memory");
+                        float ps2[HC], ph2[HC];
+#pragma unroll
+                        for (int c = 0; c < HC; ++c) {
+                            ps2[c] = park[c];
+                            ph2[c] = park[HC + c];
+                        }
+                        finish_half_packed<KS, COUNTS>(a, chunk * C + HC, ps2, ph2, reinterpret_cast<const uint32_t(&)[HC / 2]>(cw[HC / 2]),
+                                                       lists.packed);
+                    };
+                    if (edge_tab != nullptr) {  // (uniform) a tile at the image's edge: counts out of the tables
+                        uint32_t cnte[C / 2];
+                        edge_counts<C>(a, tq, chunk, edge_tab, edge_D, cnte);
+                        halves(std::true_type{}, cnte);
+                    } else {
+                        const uint32_t none[C / 2] = {};
+                        halves(std::false_type{}, none);
+                    }
                 } else if constexpr (TileLists<KS, LM>::PACKED) {
-                    finish_chunk_packed<KS, C>(a, chunk, ps, ph, cnt, lists.packed);
+                    finish_chunk_packed<KS, C>(a, chunk * C, ps, ph, cnt, lists.packed);
                 } else {
                     finish_chunk<KS, C, false>(a, tc, chunk, ps, ph, cnt, lists.top);
                 }
@@ -783,7 +847,7 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
     // the candidates' epochs per shift built and valid): the count-free loops + counts out of the tables (edge_counts)
     const uint4* edge_tab = nullptr;
     int edge_D = 0;
-    if constexpr (C == WIDE_CHUNK && (SIGMAG || LM == LIST_REGISTER_RECORDS || LM == LIST_STORE_POOLED)) {
+    if constexpr (C >= WIDE_CHUNK && (SIGMAG || LM == LIST_REGISTER_RECORDS || LM == LIST_STORE_POOLED)) {
         if (!fast && a.all_staged && as_const_ints(a.n_invalid)[0] == 0) {
             const SearchCold* cold = a.cold;
             const uint4* tab = cold->edge_tab;
@@ -799,6 +863,12 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
     if (fast || edge_tab != nullptr) {
 #endif
         lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, true>(a, tc, smem, lists, edge_tab, edge_D);
+    } else if constexpr (C == XWIDE_CHUNK) {
+        // The instance for chunks of 32 holds no counting loop (64 accumulators leave no registers for one: compiled in, it put
+        // 500 bytes per lane into scratch memory, and a launch with that much scratch pays tens of milliseconds for it).  The
+        // host launches it only after it has seen that no tile needs one -- no NO_DATA pixel (read back), every epoch staged
+        // with uniform shifts, start pixels on the image, edge tables built, shifts monotone (kb_shift_table_kernel).
+        __builtin_trap();
     } else {
         lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, false>(a, tc, smem, lists);
     }

@@ -30,6 +30,8 @@ void launch_search_lds_canon(const SearchArgs& a, int rows, bool sigmag, int lis
         } else {
             launch_lds<8, LDS_ROWS_WIDE_K, 4, true, true, LIST_REGISTERS>(a, stream);
         }
+    } else if (a.K <= 8 && a.chunk == XWIDE_CHUNK) {  // (arrays beyond the Infinity Cache: 32 candidates per staged slab, 64 x 16 tiles)
+        launch_lds<8, LDS_ROWS_TALL, 4, true, false, LIST_REGISTER_RECORDS, XWIDE_CHUNK>(a, stream);
     } else if (a.K <= 8 && a.chunk == WIDE_CHUNK) {  // (the host pairs the wide chunks with this list mode, search_kernels.hip)
         if (tall) {
             launch_lds<8, LDS_ROWS_TALL, 4, true, false, LIST_REGISTER_RECORDS, WIDE_CHUNK>(a, stream);

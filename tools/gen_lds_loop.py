@@ -43,6 +43,15 @@ v[92:123] before one wait (WIDE_BATCH).  The request of an odd epoch sits at the
 when there was one (slot 0 of the group after next lies in the buffer everybody reads until that barrier), and its slab
 reference is fetched in the even half of the same trip; %[gb] therefore counts from one entry earlier (KB_LDS_DMA in the
 generated header tells search_lds.h).  `s_waitcnt vmcnt(0)` stands in front of every group's barrier.
+
+Round 5: ONE more statement, STREAM_FAST_C32 (stream32 below), for chunks of 32 candidates on arrays beyond the Infinity
+Cache, where the kernel is bound by the bytes that cross the fabric and those fall with the candidates a staged slab
+serves.  It is the two-epochs-per-trip plan read differently: a trip is ONE epoch, its "even half" sums candidates 0-15 with
+the A offsets (a0-a15), its "odd half" candidates 16-31 of the SAME epoch with the B offsets (a16-a31) -- a table row is 32
+offsets, A and B its two halves --, so the scalar registers are those of C = 16.  One slab is requested per trip, at its end
+(behind the barrier when the group changed), its reference fetched in the trip's first half; groups may hold any number of
+epochs.  64 accumulator registers leave room for eight samples in flight (v[108:123]), not sixteen.  Count-free only: the
+host gives this instance stacks without NO_DATA pixels and edge tables for the border tiles (search_kernels.hip).
 """
 import os
 
@@ -71,14 +80,14 @@ class Plan:
             self.ws, self.m0s = 96, 97           # DMA: LDS address of the wave's piece in the slot requested next; M0 of the caller
             self.bc, self.bo = 98, 99            # BURST: requests left in a burst (pairs), running offset into the slab references
             self.bits = [92 + c for c in range(8)]
-        else:
+        else:   # (C = 32 runs on the plan of 16: a trip is one epoch in two halves of 16 candidates, see stream32)
             self.A, self.B, self.gA, self.gB, self.addr, self.o1, self.o2 = 36, 52, 68, 72, 76, 78, 79
             self.sregs = range(36, (84 if BURST_REGS else 82) if DMA else 80)   # (s32 - s35 are the stack registers of a kernel that has scratch memory)
             self.ws, self.m0s = 80, 81
             self.bc, self.bo = 82, 83
             self.bits = [84 + c for c in range(8)] * 2   # candidate k and k + 8 share a register (alternate bits)
         self.row = 4 * C                    # bytes of a table row (one epoch's offsets)
-        self.loadx = f"s_load_dwordx{C}"
+        self.loadx = f"s_load_dwordx{min(C, 16)}"
         self.raw = [108 + 2 * c for c in range(8)]
 
     def nbatch(self, fast, np_):
@@ -357,9 +366,61 @@ def stream_dma(p, fast, np_):
     return s
 
 
+def half32(p, which, np_, refill):
+    """Candidates 0-15 (A) or 16-31 (B) of one epoch: two batches of eight reads; behind the second wait the half's offsets of
+    the NEXT epoch are fetched (and, in the first half, the reference of the slab this trip requests at its end)."""
+    base, acc0, imm = (p.A, 0, "") if which == "A" else (p.B, 16, " offset:0x40")
+    s = ""
+    for b in range(2):
+        s += reads(p, base, b, 8)
+        s += ln("s_waitcnt lgkmcnt(0)")
+        if b == 1 and refill and not NO_REFILL:
+            s += ln(f"s_load_dwordx16 s[{base}:{base + 15}], %[ob], s{p.o1}{imm}")
+            if np_ and which == "A":
+                s += ln(f"s_load_dwordx4 s[{p.gB}:{p.gB + 3}], %[gb], s{p.o2}")
+        for c in range(8):
+            k = acc0 + 8 * b + c
+            s += ln(f"v_pk_add_f32 %[a{k}], %[a{k}], v[{p.raw[c]}:{p.raw[c] + 1}]")
+    return s
+
+
+def stream32(p, fast, np_):
+    """%[np]: epochs in total (>= 1), %[gc]: epochs until the next barrier, %[pg]: epochs per group; the rest as stream_dma.
+    Requests: the prologue asks for the first slab of the group staged next (%[b0]), every trip but the last for the one after
+    (its reference sits one entry behind the trip's own: %[gb] counts from one entry earlier, like the DMA statements of 16)."""
+    assert fast
+    s = ln(f"s_load_dwordx16 s[{p.A}:{p.A + 15}], %[ob], 0x0")
+    s += ln(f"s_load_dwordx16 s[{p.B}:{p.B + 15}], %[ob], 0x40")
+    s += ln(f"s_mov_b32 s{p.o1}, 0x80\\n\\ts_mov_b32 s{p.o2}, 0x10")
+    s += ln(f"v_readfirstlane_b32 s{p.ws}, %[wd]")
+    if np_:
+        s += ln(f"s_mov_b32 m0, s{p.ws}\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 %[go], %[b0]")
+    if np_ == 2:
+        s += ln(f"s_add_u32 m0, s{p.ws}, %[so]\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 %[gq], %[b0]")
+    s += ln(f"s_add_u32 s{p.ws}, s{p.ws}, %[st]")
+    s += ln("s_waitcnt lgkmcnt(0)")
+    s += f'"s_cmp_eq_u32 %[np], 1\\n\\ts_cbranch_scc1 kb_sfin_%=_{np_}\\n"\n'
+    s += f'"kb_sloop_%=_{np_}:\\n\\t"\n'
+    s += half32(p, "A", np_, True)
+    s += half32(p, "B", np_, True)
+    s += ln(f"s_add_u32 s{p.o1}, s{p.o1}, 0x80\\n\\ts_add_u32 s{p.o2}, s{p.o2}, 0x10")
+    s += ln(f"s_sub_u32 %[gc], %[gc], 1\\n\\ts_cmp_lg_u32 %[gc], 0\\n\\ts_cbranch_scc1 kb_snb_%=_{np_}")
+    s += ln("s_waitcnt vmcnt(0) lgkmcnt(0)" + ("" if NO_BARRIER else "\\n\\ts_barrier"))
+    s += ln(f"v_add_u32 %[rb], %[dr], %[rb]\\n\\ts_sub_u32 s{p.ws}, s{p.ws}, %[es]\\n\\ts_sub_u32 s{p.ws}, s{p.ws}, %[dr]")
+    s += ln("s_sub_u32 %[dr], 0, %[dr]\\n\\ts_mov_b32 %[gc], %[pg]")
+    s += '"\\n"\n'
+    s += f'"kb_snb_%=_{np_}:\\n\\t"\n'
+    s += dma_request(p, "B", np_)
+    s += f'"s_sub_u32 %[np], %[np], 1\\n\\ts_cmp_lg_u32 %[np], 1\\n\\ts_cbranch_scc1 kb_sloop_%=_{np_}\\n"\n'
+    s += f'"kb_sfin_%=_{np_}:\\n\\t"\n'
+    s += half32(p, "A", np_, False)
+    s += half32(p, "B", np_, False)
+    return s
+
+
 def combined(p, body, fast):
     """One statement for every wave: %[nq] (0, 1 or 2: the pieces of each slab this wave copies) picks the body."""
-    dma = body is stream_dma
+    dma = body is stream_dma or body is stream32
     s = ln(f"s_mov_b32 s{p.m0s}, m0") if dma else ""
     s += ln("s_cmp_eq_u32 %[nq], 2\\n\\ts_cbranch_scc1 kb_two_%=\\n\\ts_cmp_eq_u32 %[nq], 1\\n\\ts_cbranch_scc1 kb_one_%=")
     s += body(p, fast, 0)
@@ -402,6 +463,8 @@ def operands(p, family, fast):
 
 
 def clobbers(p, fast):
+    if p.C == 32:  # (64 accumulator registers: eight samples in flight + the address temporary, nothing else)
+        return ", ".join([f'"v{i}"' for i in range(108, 125)] + [f'"s{i}"' for i in p.sregs] + ['"vcc"', '"scc"', '"memory"'])
     v = [f'"v{i}"' for i in range(92, 100)] if fast else [f'"v{b}"' for b in p.bit_regs()]
     if not fast and CUR["wide_count"] and DMA and p.C == 16:
         v += [f'"v{i}"' for i in range(92, 100)]
@@ -434,8 +497,23 @@ def main():
                 out.append(f"        : {ins} \\")
                 out.append(f"        : {clobbers(p, fast)});")
                 out.append('')
+    if DMA:
+        p = Plan(32)
+        outs, ins = operands(p, "STREAM", True)
+        lines = combined(p, stream32, True).rstrip("\n").split("\n")
+        out.append('#define KB_LDS_STREAM_FAST_C32 \\')
+        out.append("    asm volatile( \\")
+        out.append(" \\\n".join("        " + x for x in lines) + " \\")
+        out.append(f"        : {outs} \\")
+        out.append(f"        : {ins} \\")
+        out.append(f"        : {clobbers(p, True)});")
+        out.append('')
     for family in ("LOOP", "STREAM"):
         out.append(f'#define KB_LDS_RUN_{family} \\')
+        if family == "STREAM" and DMA:
+            out.append('    if constexpr (C == 32) { \\')
+            out.append('        if constexpr (FAST) { KB_LDS_STREAM_FAST_C32 } \\')
+            out.append('    } else \\')
         out.append('    if constexpr (C == 8) { \\')
         out.append(f'        if constexpr (FAST) {{ KB_LDS_{family}_FAST_C8 }} else {{ KB_LDS_{family}_COUNT_C8 }} \\')
         out.append('    } else { \\')
