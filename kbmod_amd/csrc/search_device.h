@@ -23,22 +23,34 @@ __device__ __forceinline__ ConstIntPtr as_const_ints(const P* p) {
 }
 
 
-// Screen of a finished candidate against the likelihood its list's last slot holds: true when the candidate
-// CANNOT enter, decided on an approximate likelihood (psi * rsq(phi): three instructions instead of the thirty of
-// the correctly rounded sqrt and divide).  The threshold is lowered by a relative 2^-18 and one smallest normal,
-// which no rounding of either computation bridges (v_rsq_f32 and the product are good to 2^-21 relative; the exact
-// value to 2^-22), so a candidate that fails the screen also fails `lh > threshold` with the exact likelihood;
-// everything else -- passes, NaN, a phi sum too small for v_rsq_f32 -- is left to the exact test.
+// Screen of a finished candidate against the likelihood its list's last slot holds: true when the candidate CANNOT enter,
+// decided without the thirty instructions of the correctly rounded sqrt and divide -- and, since round 5, without the
+// quarter-rate v_rsq_f32 of the first form (psi * rsq(phi) < floor: twelve instruction slots a candidate, 40 % of a chunk's
+// finish).  x -> x |x| is strictly increasing, so for phi > 0
+//     psi / sqrt(phi) > F   <=>   psi |psi| > F |F| phi :
+// two multiplies and ONE compare decide every combination of signs.  F is the threshold lowered by a relative 2^-18 and one
+// smallest normal (screen_floor); the three roundings of the products move the comparison by less than 2^-22 relative and the
+// exact likelihood is good to 2^-22, so a candidate that fails the screen also fails `lh > threshold` with the exact value.
+// Everything the products cannot be trusted with is left to the exact test: phi <= 0 or NaN, and a right-hand side that is
+// not a normal number (F |F| or F |F| phi underflowed, overflowed or is NaN -- thresholds below 1e-19 in magnitude, i.e. never
+// in practice, merely lose their screen).  screen_key(threshold) = F |F|, once per lane and chunk.  The property is held over
+// the whole float range by tests/test_screen_property.py (a numpy restatement, operation for operation).
 __device__ __forceinline__ float screen_floor(float threshold) {
     return threshold - fabsf(threshold) * 3.814697265625e-06f - 1.17549435e-38f;  // -FLT_MAX -> -inf, NaN stays NaN
 }
-__device__ __forceinline__ bool screened_out(float psi_sum, float phi_sum, float floor_lh) {
-    // straight-line on purpose (bitwise, not short-circuit: as branches the screen of a chunk was ~360 instructions, the
-    // largest single piece of the finish): v_rsq_f32 of a non-positive or denormal sum yields a value that is not used
-    const bool pos = phi_sum > 0.0f;
-    const float approx = pos ? psi_sum * __builtin_amdgcn_rsqf(phi_sum) : -1.0f;
-    const bool denormal = pos & (phi_sum < 1.17549435e-38f);  // (no argument for v_rsq_f32: left to the exact test)
-    return (approx < floor_lh) & !denormal;                   // NaN compares false: left to the exact test
+__device__ __forceinline__ float screen_key(float threshold) {
+    const float f = screen_floor(threshold);
+    const float k = f * fabsf(f);
+    // (a key that is not a normal number -- F |F| underflowed into the denormals, where it keeps a bit or two, or is infinite:
+    // an empty slot -- becomes NaN: every product with it is then "not trusted")
+    return __builtin_amdgcn_classf(k, 0x108) ? k : __builtin_nanf("");
+}
+__device__ __forceinline__ bool screened_out(float psi_sum, float phi_sum, float key) {
+    // straight-line on purpose (bitwise, not short-circuit: as branches the screen of a chunk was ~360 instructions)
+    const float s = psi_sum * fabsf(psi_sum);
+    const float t = key * phi_sum;
+    const bool trusted = (phi_sum > 0.0f) & __builtin_amdgcn_classf(t, 0x108);  // +-normal
+    return trusted & (s <= t);                                                     // NaN compares false: left to the exact test
 }
 
 // Threshold / insertion of one chunk's C finished candidates.  With the sigma-G filter on nothing is
@@ -60,7 +72,7 @@ __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoor
         // `lh < min_lh` is decided on the approximate likelihood wherever that is safe (screened_out: a candidate it rejects
         // also fails the exact test); the correctly rounded sqrt and divide run only for candidates some lane cannot
         // decide that way -- a fraction of a percent of cfg3's
-        const float floor_lh = screen_floor(a.min_lh);
+        const float floor_lh = screen_key(a.min_lh);
         uint32_t pass_bits = 0;
         int n_items = 0;
 #pragma unroll
@@ -223,7 +235,7 @@ __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int can
                                                     const int (&cnt)[C], TopKPacked<KS>& top) {
     static_assert(C <= 16, "chunks of 32 are finished as two halves of 16 (lds_search_tile): the selection out of 32 register "
                            "sets next to 64 live sums put the sums into scratch memory, reloaded in every round");
-    const float floor_lh = screen_floor(fmaxf(top.lh[KS - 1], a.min_lh));  // (min_lh: the lists' floor, flag 1024; else -FLT_MAX)
+    const float floor_lh = screen_key(fmaxf(top.lh[KS - 1], a.min_lh));  // (min_lh: the lists' floor, flag 1024; else -FLT_MAX)
     uint32_t pending = 0;
 #pragma unroll
     for (int c = C - 1; c >= 0; --c) {  // (downwards: the mask is built by shifting)
@@ -258,7 +270,7 @@ template <int KS, bool COUNTS>
 __device__ __forceinline__ void finish_half_packed(const SearchArgs& a, int cand_base, const float (&ps)[16], const float (&ph)[16],
                                                    const uint32_t (&cw)[8], TopKPacked<KS>& top) {
     constexpr int C = 16;
-    const float floor_lh = screen_floor(fmaxf(top.lh[KS - 1], a.min_lh));
+    const float floor_lh = screen_key(fmaxf(top.lh[KS - 1], a.min_lh));
     uint32_t pending = 0;
 #pragma unroll
     for (int c = C - 1; c >= 0; --c) {
@@ -423,7 +435,7 @@ template <int C, bool FAST>
 __device__ __forceinline__ void finish_chunk_pooled(const SearchArgs& a, int chunk, const float (&ps)[C], const float (&ph)[C],
                                                     const uint32_t (&cntp)[C / 2], ListState& ls, char* tile_list,
                                                     const PooledLayout lay, uint32_t tid) {
-    const float floor_lh = screen_floor(ls.threshold);
+    const float floor_lh = screen_key(ls.threshold);
     uint32_t pending = 0;
 #pragma unroll
     for (int c = C - 1; c >= 0; --c) {
