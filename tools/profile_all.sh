@@ -1,14 +1,20 @@
 #!/bin/bash
-# The round's profile set (run on the GPU box): tools/profile_all.sh r03
-R=${1:-r03}
+# The round's profile set (run on the GPU box): tools/profile_all.sh r05
+R=${1:-r05}
 tools/profile_round.sh ${R}_f32
 tools/profile_round.sh ${R}_cfg3 --num-bytes 1 --sigmag
 STEPS=3 WARMUP=1 tools/profile_round.sh ${R}_cfg4 --frames 128 --size 4096 --vel-steps 32 --ang-steps 2
 STEPS=2 WARMUP=1 tools/profile_round.sh ${R}_cfg5 --frames 512 --size 2048 --vel-steps 64 --ang-steps 64 --num-bytes 2
 tools/sq_profile.sh ${R}_f32
 tools/sq_build.sh ${R}_builder 32 4096 > /dev/null
-bash tools/p2.sh > gpurun_out/${R}_builder_variants.md 2>&1
+{ # the psi/phi builder variants (tools/exp_build.py T N [build_flags] [num_bytes]: 0 2-D strip, 1 separable strip, 4 general tiles)
+  export TMPDIR=/tmp
+  for args in "32 4096 0" "32 4096 1" "32 4096 4" "32 4096 0 2" "64 512 0" "64 512 1"; do
+    rm -rf /tmp/kt3; rocprofv3 --kernel-trace --stats -d /tmp/kt3 -o r -- python tools/exp_build.py $args > /tmp/kt3.log 2>&1
+    echo "== $args"; python tools/rocprof_summary.py /tmp/kt3/r_results.db | grep "kb::"
+  done; } > gpurun_out/${R}_builder_variants.md 2>&1
 python bench.py > gpurun_out/${R}_bench_default.json 2>/dev/null
+python bench.py --separable-psf --no-cpu-baseline --no-masked --no-live-traffic 2>/dev/null | grep '^{' > gpurun_out/${R}_bench_separable_builder.json
 ls gpurun_out | grep ${R}_ | head -80
 # the FITS ingest kernels (tools/fits_ingest_timing.py): kernel-trace stats + the HBM-side byte counters
 export TMPDIR=/tmp
