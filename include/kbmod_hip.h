@@ -68,13 +68,16 @@ typedef struct kb_search_stats {
                                      (equal ratios from different (psi, phi) pairs, stacks deeper than 256 epochs) */
     char kernel_name[96];         /* the search kernel instance that ran, spelled as rocprofv3 prints it
                                      (e.g. "kb::kb_search_lds<8, 8, 16, 4, true, false, 3, 1>") */
-    int32_t padded_copy_reused;   /* flag 256 was honoured: no decode-and-pad pass in this search */
+    int32_t padded_copy_reused;   /* the padded copy of an earlier search was reused (an array the library built and nobody has
+                                     written since, or flag 256): no decode-and-pad pass in this search */
     int32_t special_epochs;       /* kb_search_lds: (chunk of candidates, epoch) pairs summed per lane -- not staged, or a shift
                                      inside the guard band of a rounding boundary -- instead of by the uniform loops */
     int32_t edge_count_tables;    /* kb_search_lds: tables of epochs per shift were built, so that tiles at the image's edge of a
                                      stack without NO_DATA pixels take their observation counts from them instead of counting samples */
     int32_t env_overrides;        /* bit i: environment switch i was set while this search chose its kernels (they exist for tests
-                                     and comparisons and change the kernel instance, never the result): 0 KBMOD_CHUNK, 1 KBMOD_LIST_MODE,
+                                     and comparisons and change the kernel instance, never the result): 0 KBMOD_CHUNK (8 / 16 / 32
+                                     candidates per staged slab; 32 asks for the instance the library otherwise takes only for
+                                     arrays beyond the Infinity Cache with 192 epochs or more), 1 KBMOD_LIST_MODE,
                                      2 KBMOD_EDGE_COUNTS, 3 KBMOD_UNSTAGED_LIMIT, 4 KBMOD_SIGMAG_CAP, 5 KBMOD_DEBUG */
 } kb_search_stats;
 

@@ -39,7 +39,11 @@ __device__ __forceinline__ float screen_floor(float threshold) {
     return threshold - fabsf(threshold) * 3.814697265625e-06f - 1.17549435e-38f;  // -FLT_MAX -> -inf, NaN stays NaN
 }
 __device__ __forceinline__ float screen_key(float threshold) {
-    const float f = screen_floor(threshold);
+    float f = screen_floor(threshold);
+    // A threshold too close to zero for its square -- min_lh = 0 under a list that is not full yet is the common one -- is
+    // lowered to -2^-40: lower is always safe, the key stays a normal number, and the screen keeps rejecting what it used to
+    // reject there: every candidate with a (really) negative likelihood.
+    if (fabsf(f) < 0x1p-40f) f = -0x1p-40f;
     const float k = f * fabsf(f);
     // (a key that is not a normal number -- F |F| underflowed into the denormals, where it keeps a bit or two, or is infinite:
     // an empty slot -- becomes NaN: every product with it is then "not trusted")

@@ -26,6 +26,7 @@ def screen_floor(thr):
 def screen_key(thr):
     with np.errstate(all="ignore"):
         f = screen_floor(thr)
+        f = np.where(np.abs(f) < F32(2.0 ** -40), F32(-(2.0 ** -40)), f).astype(F32)   # (NaN compares false: stays NaN)
         k = _mul(f, np.abs(f))
         normal = np.isfinite(k) & (np.abs(k) >= FLT_MIN)
     return np.where(normal, k, F32(np.nan)).astype(F32)
@@ -97,5 +98,10 @@ def test_rejected_candidates_fail_the_exact_test_at_the_edges():
     phi = (mant() * np.exp2(rng.integers(-140, 127, n)).astype(F32)).astype(F32)
     thr = (mant() * np.exp2(rng.integers(-140, 127, n)).astype(F32) * rng.choice([-1, 1], n)).astype(F32)
     _check(psi, phi, thr)
+    # thresholds at and around zero (min_lh = 0 under a list that is not full): negative likelihoods ARE rejected
+    zero = np.zeros(n, dtype=F32)
+    out0 = _check(psi, phi, zero)
+    _check(psi, phi, np.full(n, -1.4e-45, dtype=F32))
+    assert out0[(psi < -1e-3) & (phi > 1e-3) & (phi < 1e3)].all()
     # an empty slot's threshold: nothing may be rejected
     assert not screened_out(psi, phi, screen_key(np.full(n, -3.4028234663852886e38, dtype=F32))).any()
