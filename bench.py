@@ -331,6 +331,32 @@ def main():
         torch.cuda.synchronize()
         build_call_ms = e0.elapsed_time(e1)           # whole call on the device timeline (allocation gaps included)
         build_kernel_ms = float(lib.kb_last_build_kernel_ms())  # the correlation launch alone (HIP events inside the library)
+        # ... and the OTHER builder kernel on the same stack (the north star's separable kernel when the default 2-D one was
+        # measured above, and the other way round), with the largest relative difference between the two arrays where both
+        # hold data (float arrays; the NO_DATA pattern must be identical) -- so that one driver record holds both
+        other_build = None
+        if not args.child and args.num_bytes in (-1, 4):
+            meta3, arr3 = Meta(), C.c_void_p()
+            check(lib, lib.kb_build_psi_phi_from_device_ex(sci.data_ptr(), var.data_ptr(), psf_all.ctypes.data, psf_dims.ctypes.data,
+                                                           T, H, W, args.num_bytes, build_flags ^ 1, C.byref(meta3), C.byref(arr3), stream))
+            torch.cuda.synchronize()
+            other_ms = float(lib.kb_last_build_kernel_ms())
+            n_el = int(meta3.num_entries)
+            a_t = torch.empty(n_el, dtype=torch.float32, device=dev)
+            b_t = torch.empty(n_el, dtype=torch.float32, device=dev)
+            hip_rt = C.CDLL("libamdhip64.so")
+            hip_rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            assert hip_rt.hipMemcpy(a_t.data_ptr(), arr2, n_el * 4, 3) == 0 and hip_rt.hipMemcpy(b_t.data_ptr(), arr3, n_el * 4, 3) == 0
+            same_nan = bool(torch.equal(torch.isnan(a_t), torch.isnan(b_t)))
+            ok = ~torch.isnan(a_t) & ~torch.isnan(b_t)
+            # relative to the array's own scale (psi crosses zero: a per-element ratio there says nothing)
+            scale = float(torch.abs(a_t[ok]).max().item()) if bool(ok.any()) else 1.0
+            max_rel = float((torch.abs(a_t[ok] - b_t[ok]).max() / scale).item()) if bool(ok.any()) else 0.0
+            other_build = {"kernel": "2-D strip (bit-identical)" if args.separable_psf else "separable strip (<= 1e-4)",
+                           "kernel_ms": other_ms, "same_no_data_pattern": same_nan,
+                           "max_abs_diff_over_array_max": max_rel}
+            del a_t, b_t
+            lib.kb_free_gpu_block(arr3)
         lib.kb_free_gpu_block(arr2)
     del sci, var
 
@@ -586,6 +612,10 @@ def main():
                                 "kernel_ms": build_kernel_ms, "call_device_ms": build_call_ms, "bytes_in_plus_out": in_out,
                                 "GBps": in_out / (build_kernel_ms * 1e-3) / 1e9,
                                 "frac_of_achievable": in_out / (build_kernel_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBPS}
+        if other_build is not None:
+            other_build.update(GBps=in_out / (other_build["kernel_ms"] * 1e-3) / 1e9,
+                               frac_of_achievable=in_out / (other_build["kernel_ms"] * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBPS)
+            out["psi_phi_build"]["other_kernel"] = other_build
     if args.sigmag:
         out["config"]["sigmag_work_items"] = int(last.sigmag_work_items)
         out["config"]["sigmag_trajectories_clipped"] = int(last.sigmag_trajectories)

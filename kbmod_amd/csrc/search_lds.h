@@ -54,11 +54,16 @@ struct SlabRegs {
 template <int BYTES, int ROWS>
 __device__ __forceinline__ StageLane stage_lanes(const SearchArgs& a, int cols, int slab_bytes) {
     StageLane out;
+    // p / cols by one multiplication: inv = ceil(2^20 / cols) is exact for p < 2^20 / cols (p < 16 K pixels of two staging
+    // rounds, cols <= 112) -- the division itself cost every thread ~25 instructions per slot and chunk, and the reciprocal is
+    // the same for the whole workgroup (one division on a uniform value)
+    const uint32_t inv = ((1u << 20) + (uint32_t)cols - 1u) / (uint32_t)cols;
+    static_assert(16 * (ROWS * WAVE) * LDS_SLOTS / BYTES <= (1 << 20) / 128, "the reciprocal's range");
 #pragma unroll
     for (int j = 0; j < LDS_SLOTS; ++j) {
         const int o = 16 * ((int)threadIdx.x + (ROWS * WAVE) * j);
         const int p = o / BYTES;  // first pixel of this thread's 16 bytes
-        const int r = p / cols, c = p - r * cols;
+        const int r = (int)(((uint32_t)p * inv) >> 20), c = p - r * cols;
         out.goff[j] = (o < slab_bytes) ? (uint32_t)(r * a.Wp + c) * (uint32_t)BYTES : 0u;
     }
     return out;
