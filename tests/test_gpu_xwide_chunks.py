@@ -131,3 +131,26 @@ def test_what_the_instance_cannot_take_falls_back(kb, orc, case, monkeypatch):
     if case == "masked":
         again, _, s2 = util.run_both(kb, orc, st, vx, vy, cfg, flags=flags)
         assert np.array_equal(again, exp) and _name(s2) != XWIDE
+
+
+@pytest.mark.parametrize("case", ["epochs_out_of_order", "shifts_beyond_the_tables", "slabs_of_three_rounds"])
+def test_tables_that_refuse_the_instance(kb, orc, case, monkeypatch):
+    """What only the tables can tell: epochs out of time order (shifts not monotone: no edge tables), shifts of more than 200
+    pixels, slabs of more than two staging rounds.  The instance has no counting loop and traps if a tile needed one -- so the
+    host must refuse it here, run another instance, and still equal the oracle."""
+    T, H, W = 16, 80, 160
+    times = np.arange(T) / 16.0
+    vel = (16, 2.0, 25.0, 4, 0.0, 1.2)
+    if case == "epochs_out_of_order":
+        times = times[np.random.default_rng(3).permutation(T)].copy()
+        times[0], times[np.argmin(times)] = times[np.argmin(times)], times[0]   # (zeroed times start at the first epoch)
+    if case == "shifts_beyond_the_tables":
+        H, W, vel = 300, 400, (32, 150.0, 260.0, 1, 0.2, 0.3)
+    if case == "slabs_of_three_rounds":
+        vel = (32, 2.0, 60.0, 2, 0.7, 0.9)   # one chunk = the whole speed range at 45 degrees: (16 + 40) x (64 + 40) pixels
+    st = util.make_stack(T, H, W, seed=41, objects=[(30, 30, 15.0, 6.0, 300.0)], times=times - times[0])
+    vx, vy = fd.kbmod_v1_candidates(*vel)
+    monkeypatch.setenv("KBMOD_CHUNK", "32")
+    got, exp, s = util.run_both(kb, orc, st, vx, vy, {"K": 8, "min_obs": 2}, flags=LDS)
+    assert _name(s) != XWIDE, _name(s)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
