@@ -84,7 +84,13 @@ struct ChunkInfo {
     int rows_max;                        // tile rows + largest dy spread of any epoch (slab height)
     int cols;                            // slab pitch: 64 + largest dx spread of any staged epoch, rounded up to the
                                          // staging quantum (16 bytes of raw pairs)
+    // What kb_search_lds would otherwise divide out per chunk and loop trip on every wave (float-pair staging, the tile height
+    // the tables were built for): epochs per group in the even and in the any-number form (group_epochs), the whole groups
+    // T holds of each, and ceil(2^20 / cols), the reciprocal stage_lanes multiplies by.
+    int e_even, e_any, t_over_e_even, t_over_e_any, cols_inv;
+    int pad[3];
 };
+static_assert(sizeof(ChunkInfo) == 64, "kb_search_lds reads ChunkInfo as sixteen ints");
 
 // Per (chunk, epoch) footprint, packed for one 8-byte scalar load:
 //   x = (dy_min << 16) | (dx_min & 0xffff)   origin of the staged region relative to the tile

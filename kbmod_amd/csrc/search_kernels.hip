@@ -273,6 +273,15 @@ __global__ __launch_bounds__(256) void kb_shift_table_kernel(const kb_trajectory
         ci.lds_ok = (red[5][0] == 0) ? 1 : 0;
         ci.rows_max = red[6][0];
         ci.cols = min(max_cols, (red[12][0] + col_quantum - 1) / col_quantum * col_quantum);
+        {
+            const int stride = (ci.rows_max * ci.cols * 8 + 1023) & ~1023;  // (chunk_plan of search_lds.h, float pairs)
+            ci.e_even = group_epochs(T, tile_rows, stride, true);
+            ci.e_any = group_epochs(T, tile_rows, stride, false);
+            ci.t_over_e_even = T / ci.e_even;
+            ci.t_over_e_any = T / ci.e_any;
+            ci.cols_inv = (int)(((1u << 20) + (unsigned)ci.cols - 1u) / (unsigned)ci.cols);
+            ci.pad[0] = ci.pad[1] = ci.pad[2] = 0;
+        }
         chunks[chunk] = ci;
         atomicMax(&global_box[6], ci.rows_max * ci.cols);  // largest slab of the search, in pixels
         if (red[13][0] != 0) atomicAdd(&global_box[7], red[13][0]);

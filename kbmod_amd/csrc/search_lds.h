@@ -52,12 +52,10 @@ struct SlabRegs {
 // Staging map of a thread for the slabs of one chunk (pitch `cols` pixels, slab_bytes): where its 16 bytes of
 // round j sit in the padded copy relative to the slab origin; 0 (re-read the slab's first bytes) past the slab's end.
 template <int BYTES, int ROWS>
-__device__ __forceinline__ StageLane stage_lanes(const SearchArgs& a, int cols, int slab_bytes) {
+__device__ __forceinline__ StageLane stage_lanes(const SearchArgs& a, int cols, int slab_bytes, uint32_t inv) {
     StageLane out;
-    // p / cols by one multiplication: inv = ceil(2^20 / cols) is exact for p < 2^20 / cols (p < 16 K pixels of two staging
-    // rounds, cols <= 112) -- the division itself cost every thread ~25 instructions per slot and chunk, and the reciprocal is
-    // the same for the whole workgroup (one division on a uniform value)
-    const uint32_t inv = ((1u << 20) + (uint32_t)cols - 1u) / (uint32_t)cols;
+    // p / cols by one multiplication: inv = ceil(2^20 / cols) (ChunkInfo::cols_inv) is exact for p < 2^20 / cols (p < 16 K
+    // pixels of two staging rounds, cols <= 112) -- the division itself cost every thread ~25 instructions per slot and chunk
     static_assert(16 * (ROWS * WAVE) * LDS_SLOTS / BYTES <= (1 << 20) / 128, "the reciprocal's range");
 #pragma unroll
     for (int j = 0; j < LDS_SLOTS; ++j) {
@@ -211,15 +209,25 @@ struct ChunkPlan {
                      // a wave can write all 64 of its pieces without a lane mask
     int E;           // epochs per group
     int clean;       // every epoch is staged with uniform shifts: the summing loop needs no per-epoch test
+    int whole;       // T / E
+    uint32_t inv;    // ceil(2^20 / cols)
 };
 template <int BYTES, int ROWS, bool EVEN>
 __device__ __forceinline__ ChunkPlan chunk_plan(const SearchArgs& a, int chunk) {
     ChunkPlan p;
-    const ConstIntPtr ci = as_const_ints(&a.chunks[chunk]);  // {dx_min, dx_max, dy_min, dy_max, unsafe, lds_ok, rows_max, cols}
+    // {dx_min, dx_max, dy_min, dy_max, unsafe, lds_ok, rows_max, cols, e_even, e_any, t_over_e_even, t_over_e_any, cols_inv}
+    const ConstIntPtr ci = as_const_ints(&a.chunks[chunk]);
     p.cols = ci[7];
     p.slab_bytes = ci[6] * p.cols * BYTES;
     p.stride = (p.slab_bytes + 1023) & ~1023;
-    p.E = group_epochs(a.T, ROWS, p.stride, EVEN);
+    if constexpr (BYTES == 8) {  // (float pairs: what the table kernel worked out for this tile height -- no division here)
+        p.E = EVEN ? ci[8] : ci[9];
+        p.whole = EVEN ? ci[10] : ci[11];
+    } else {
+        p.E = group_epochs(a.T, ROWS, p.stride, EVEN);
+        p.whole = a.T / p.E;
+    }
+    p.inv = (uint32_t)ci[12];
     p.clean = (ci[4] == 0 && ci[5] != 0) ? 1 : 0;
     return p;
 }
@@ -306,7 +314,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
     auto origin_of = [](Int4 r) { return (int64_t)(((uint64_t)(uint32_t)r.y << 32) | (uint64_t)(uint32_t)r.x); };
     // this tile's own pixel inside the padded copy
     const char* tile_base = reinterpret_cast<const char*>(a.padded) + ((int64_t)tc.tile_y0 * a.Wp + tc.tile_x0) * BYTES;
-    StageLane n_sl = stage_lanes<BYTES, ROWS>(a, plan.cols, plan.slab_bytes);  // staging map of the group being copied
+    StageLane n_sl = stage_lanes<BYTES, ROWS>(a, plan.cols, plan.slab_bytes, plan.inv);  // staging map of the group being copied
     {
         const ConstSlabPtr org = (ConstSlabPtr)(uintptr_t)(a.slabs + (size_t)chunk * T);
         const int n = min(plan.E, T);
@@ -347,7 +355,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
 #ifdef KB_EXP_NO_STREAM
             const int ng = 0;
 #else
-            const int ng = (T - t0) / plan.E - 1;
+            const int ng = (t0 == 0 ? plan.whole : (T - t0) / plan.E) - 1;  // (t0 == 0: the common case, no division)
 #endif
             constexpr bool EPOCH_TRIPS = C == XWIDE_CHUNK;  // a trip of the statement is one epoch (chunks of 32), not two
             if (plan.clean && (EPOCH_TRIPS || (plan.E & 1) == 0) && plan.slab_bytes <= 2 * stage_round(ROWS) &&
@@ -410,7 +418,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             n_t0 = 0;
             if (n_chunk < a.chunk_hi) {
                 n_plan = chunk_plan<BYTES, ROWS, EVEN_GROUPS>(a, n_chunk);
-                n_sl = stage_lanes<BYTES, ROWS>(a, n_plan.cols, n_plan.slab_bytes);
+                n_sl = stage_lanes<BYTES, ROWS>(a, n_plan.cols, n_plan.slab_bytes, n_plan.inv);
             }
         }
         const int n_next = (n_chunk < a.chunk_hi) ? min(n_plan.E, T - n_t0) : 0;
