@@ -69,6 +69,10 @@ NO_REFILL = os.environ.get("KB_GEN_NO_REFILL") is not None
 # from one entry earlier: the reference of an odd epoch is now fetched in the even half of its own trip).
 DMA = os.environ.get("KB_GEN_NO_DMA") is None  # (KB_GEN_NO_DMA: the register-staged STREAM statements, for comparisons)
 BURST_REGS = DMA and os.environ.get("KB_GEN_BURST") is not None  # (two more scalar registers in the clobber lists: see BURST)
+# Timing experiment (KB_GEN_STAGGER="<bit>:<sleep>"): behind every group barrier the waves whose %[wp] (1024 x wave number) has
+# that bit set sleep <sleep> x 64 cycles, so that the waves of a SIMD are not all in the read phase (then all in the add phase)
+# of an epoch at the same moment.
+STAGGER = os.environ.get("KB_GEN_STAGGER")
 
 
 class Plan:
@@ -347,6 +351,11 @@ def stream_dma(p, fast, np_):
     s += advance(p)
     s += ln(f"s_sub_u32 %[gc], %[gc], 1\\n\\ts_cmp_lg_u32 %[gc], 0\\n\\ts_cbranch_scc1 kb_snb_%=_{np_}")
     s += ln("s_waitcnt vmcnt(0) lgkmcnt(0)" + ("" if NO_BARRIER else "\\n\\ts_barrier"))
+    if STAGGER:
+        bit, sleep = STAGGER.split(":")
+        s += ln(f"s_bitcmp0_b32 %[wp], {bit}\\n\\ts_cbranch_scc1 kb_nosleep_%=_{np_}\\n\\ts_sleep {sleep}")
+        s += '"\\n"\n'
+        s += f'"kb_nosleep_%=_{np_}:\\n\\t"\n'
     s += ln(f"v_add_u32 %[rb], %[dr], %[rb]\\n\\ts_sub_u32 s{p.ws}, s{p.ws}, %[es]\\n\\ts_sub_u32 s{p.ws}, s{p.ws}, %[dr]")
     s += ln("s_sub_u32 %[dr], 0, %[dr]\\n\\ts_mov_b32 %[gc], %[pg]")
     if BURST:
