@@ -1,7 +1,10 @@
-"""Generates tests/golden/sigma_g_matrix.npz in THIS container (torch is importable here, the
-reference module kbmod.filters.sigma_g_filter is not: it imports the compiled kbmod.search).
+"""Generates tests/golden/sigma_g_matrix.npz in THIS container BY RUNNING THE REFERENCE'S OWN FUNCTION:
+`SigmaGClipping.compute_clipped_sigma_g_matrix` of /root/reference/src/kbmod/filters/sigma_g_filter.py, loaded from where it
+lies (round 5).  The module's one import that is not available here, `from kbmod.search import DebugTimer` (the compiled
+extension; the name is used by another method only), is satisfied by an empty placeholder module for the duration of the load --
+no line of the function under test is replaced.  `valid_*` in the fixture are that function's outputs.
 
-The vectors are the outputs of the reference's call sequence on torch (sigma_g_filter.py:132-165:
+Next to them the script keeps its own spelling of the same call sequence on torch (sigma_g_filter.py:132-165:
 torch.tensor(float32) -> optional torch.where(lh > 0, lh, nan) -> torch.nanquantile(q, dim=1) ->
 delta floor 1e-5 -> bounds -> isfinite & < & >) for seeded inputs, together with the bounds so that
 the consumers can exclude points within two ulps of a bound (torch's lerp kernels are fused
@@ -37,7 +40,33 @@ def reference_sequence(lh, lo, hi, n_sigma, clip_negative):
     return valid.numpy().astype(bool), lower.numpy().ravel(), upper.numpy().ravel()
 
 
+def load_reference_class():
+    """SigmaGClipping of the reference, loaded from its source file."""
+    import importlib.util
+    import sys
+    import types
+
+    path = "/root/reference/src/kbmod/filters/sigma_g_filter.py"
+    placeholder = types.ModuleType("kbmod.search")
+    placeholder.DebugTimer = object          # (imported by name at module level, used by apply_clipped_sigma_g only)
+    saved = {k: sys.modules.get(k) for k in ("kbmod", "kbmod.search")}
+    sys.modules.setdefault("kbmod", types.ModuleType("kbmod"))
+    sys.modules["kbmod.search"] = placeholder
+    try:
+        spec = importlib.util.spec_from_file_location("ref_sigma_g_filter", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod.SigmaGClipping
+
+
 def main():
+    SigmaGClipping = load_reference_class()
     rng = np.random.default_rng(20260929)
     out = {}
     cases = [(40, 20, 25, 75, 2.0, False), (40, 20, 25, 75, 2.0, True), (30, 57, 10, 90, 3.0, False),
@@ -53,14 +82,20 @@ def main():
             lh[7, :] = np.nan
             lh[8, :] = -np.abs(lh[8, :]) - 0.1
         valid, lower, upper = reference_sequence(lh, lo, hi, ns, clip)
+        # the reference's function itself; the bounds (which it does not return) come from the sequence above, whose mask must
+        # be the same
+        valid_ref = SigmaGClipping(lo, hi, ns, clip).compute_clipped_sigma_g_matrix(lh)
+        assert valid_ref.shape == valid.shape and np.array_equal(valid_ref, valid), i
+        valid = valid_ref
         out[f"lh_{i}"] = lh
         out[f"cfg_{i}"] = np.array([lo, hi, ns, float(clip)])
         out[f"valid_{i}"] = valid
         out[f"lower_{i}"] = lower
         out[f"upper_{i}"] = upper
     out["torch_version"] = np.array(torch.__version__)
+    out["source"] = np.array("kbmod.filters.sigma_g_filter.SigmaGClipping.compute_clipped_sigma_g_matrix (reference source, imported)")
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "sigma_g_matrix.npz"), **out)
-    print("wrote", len(cases), "cases with torch", torch.__version__)
+    print("wrote", len(cases), "cases from the reference's own function, torch", torch.__version__)
 
 
 if __name__ == "__main__":
