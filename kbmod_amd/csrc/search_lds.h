@@ -34,9 +34,11 @@ __device__ unsigned long long kb_exp_prof[8];
 // Staging map.  A slab (rows x cols raw pairs, dense; cols = the chunk's pitch) is copied in workgroup-wide
 // rounds of 16 * ROWS * 64 bytes: in round j thread tid moves the 16 bytes at slab offset
 // o = 16 * (tid + ROWS * 64 * j), i.e. pixel p = o / BYTES = (row, col) = divmod(p, cols) of the slab, from the
-// padded array at the slab origin plus (row * Wp + col) * BYTES (stage_lanes).  The copy goes through registers
-// (global_load_dwordx4 -> ds_write_b128): measured on MI355X the LDS-DMA form of the same copy
-// (global_load_lds_dwordx4) sustains only ~12 B/clk/CU and stalls the issuing wave.
+// padded array at the slab origin plus (row * Wp + col) * BYTES (stage_lanes).  The hand-scheduled STREAM statements
+// (search_lds_asm.h, KB_LDS_DMA) request a wave's 1 KiB piece of that map by LDS-DMA -- global_load_lds_dwordx4 with M0 = the
+// piece's place in LDS: no staging registers, no ds_write_b128 --; the LOOP statements and every compiler-scheduled path
+// below (first group of a launch, encoded staging, slabs of more than LDS_SLOTS rounds) copy through registers
+// (global_load_dwordx4 -> ds_write_b128: load_slab / write_slab).
 struct StageLane {
     uint32_t goff[LDS_SLOTS];
 };

@@ -9,6 +9,7 @@ so that the same shapes and value distributions are searched:
 * ``add_fake_object``        -- fake_data/fake_data_creator.py:128-172
 * ``kbmod_v1_candidates``    -- trajectory_generator.py:416-456 (upper bounds exclusive)
 * ``velocity_grid_candidates`` -- trajectory_generator.py:232-268 (inclusive grid)
+* ``ecliptic_centered_candidates`` -- trajectory_generator.py:496-625 (angle offsets around an ecliptic angle, inclusive grid)
 
 (paths relative to /root/reference/src/kbmod/).  Pure numpy; no GPU work here.
 """
@@ -127,3 +128,23 @@ def sigmag_coeff(lo=25.0, hi=75.0):
 
     nd = NormalDist()
     return 1.0 / (nd.inv_cdf(hi / 100.0) - nd.inv_cdf(lo / 100.0))
+
+
+def ecliptic_centered_candidates(velocities, angles, given_ecliptic=0.0):
+    """``EclipticCenteredSearch``: velocities = [min, max, steps] in pixels per day, angles = [min offset, max offset,
+    steps] in radians around ``given_ecliptic``; both grids inclusive, angle outer, velocity inner."""
+    v_lo, v_hi, v_n = velocities
+    a_lo, a_hi, a_n = angles
+    if a_n < 1 or v_n < 1 or v_hi < v_lo:
+        raise ValueError("invalid ecliptic-centred grid")
+    vel_step = (v_hi - v_lo) / float(v_n - 1)
+    min_ang = given_ecliptic + a_lo
+    ang_step = ((given_ecliptic + a_hi) - min_ang) / float(a_n - 1)
+    vxs, vys = [], []
+    for ang_i in range(int(a_n)):
+        for vel_i in range(int(v_n)):
+            ang = min_ang + ang_i * ang_step
+            vel = v_lo + vel_i * vel_step
+            vxs.append(math.cos(ang) * vel)
+            vys.append(math.sin(ang) * vel)
+    return np.asarray(vxs, dtype=np.float32), np.asarray(vys, dtype=np.float32)
