@@ -102,7 +102,7 @@ def self_launch(args_list, n):
 
 def roofline_block(*, kernel_ms, algorithmic_bytes, lds_read_bytes, evals_per_step, traffic, traffic_source, traffic_rejected,
                    compulsory_bytes, padded_copy_bytes_guess, is_lds_kernel, kernel, edge_count_tables, mask_fraction,
-                   padded_copy_reused, env_overrides, copy_gbps, read_gbps, lds_gbps, psi_phi_bytes):
+                   padded_copy_reused, env_overrides, copy_gbps, read_gbps, lds_gbps, psi_phi_bytes, traced=None):
     """The `roofline` object of the line, from plain measured values (no device, no library: tests/test_bench_contract.py
     calls this with stubbed numbers).  What bounds the dominant kernel, and every fraction with its yardstick and its clock
     (every rate divides by kernel_ms: the HIP-event duration of the search launch on its own stream, averaged over the run's
@@ -112,7 +112,11 @@ def roofline_block(*, kernel_ms, algorithmic_bytes, lds_read_bytes, evals_per_st
         and instructions issue.  SURVEY 8(d)'s "8 B per evaluation" ARE those LDS reads (one ds_read_b64 per sample):
         achieved = algorithmic bytes / kernel_ms against the LDS read peak of the guide; frac_algorithmic, the same bytes
         against the 8 TB/s of HBM, is above 1 for that reason and is not a roofline fraction.
-      arrays beyond the Infinity Cache (configs[3], [4]) -- bound "hbm": achieved = fabric bytes / kernel_ms against 8 TB/s."""
+      arrays beyond the Infinity Cache (configs[3], [4]) -- bound "hbm": achieved = fabric bytes / kernel_ms against 8 TB/s.
+    `traced` (live_traffic): what the run's own rocprofv3 sub-runs saw of the same kernel instance ON THIS BOX -- its mean
+    dispatch duration under the tracer (traced_kernel_ms), LDS instructions (lds_insts: one ds_read_b64 per 64 evaluations,
+    so lds_insts x 64 ~ evals per launch) and LDS-array cycles (lds_cycles) per launch: with them `frac` and the
+    one-read-per-64-evaluations identity can be recomputed from the line alone."""
     k_s = kernel_ms * 1e-3
     alg_rate = float(algorithmic_bytes) / k_s / 1e9
     cache_resident = padded_copy_bytes_guess <= INFINITY_CACHE_BYTES
@@ -177,6 +181,15 @@ def roofline_block(*, kernel_ms, algorithmic_bytes, lds_read_bytes, evals_per_st
         "frac_of_measured_lds": None if not (lds_read_bytes and lds_gbps) else lds_rate / float(lds_gbps),
         "psi_phi_bytes": int(psi_phi_bytes),
         "cache_resident": bool(cache_resident),
+        "traced_kernel_ms": (traced or {}).get("traced_kernel_ms"),
+        "traced_launches": (traced or {}).get("traced_launches"),
+        "frac_at_traced_kernel_ms": (None if not (traced or {}).get("traced_kernel_ms")
+                                     else achieved * kernel_ms / traced["traced_kernel_ms"] / peak),
+        "lds_insts": (traced or {}).get("lds_insts"),
+        "lds_cycles": (traced or {}).get("lds_cycles"),
+        "evals_per_lds_inst": (None if not (traced or {}).get("lds_insts") else evals_per_step / traced["lds_insts"]),
+        "lds_cycles_per_inst": (None if not ((traced or {}).get("lds_insts") and (traced or {}).get("lds_cycles"))
+                                else traced["lds_cycles"] / traced["lds_insts"]),
     }
 
 
@@ -543,10 +556,13 @@ def main():
     # prescribes) and takes the per-dispatch average of the instance that ran here.  Without rocprofv3, or with
     # --no-live-traffic: the stored profile of the same workload AND instance (profiles/traffic.json), said in traffic_source.
     traffic = traffic_source = traffic_rejected = None
+    traced = {}
     if rank == 0 and world == 1 and not dist_mode and not args.no_live_traffic:
         live = live_traffic(sys.argv[1:], instance)
         if "bytes" in live:
             traffic, traffic_source = live["bytes"], live["source"]
+            traced = {k: live.get(k) for k in ("traced_kernel_ms", "traced_launches", "lds_insts", "lds_cycles", "lds_error")
+                      if live.get(k) is not None}
         else:
             traffic_rejected = live["error"]
     if traffic is None:
@@ -572,7 +588,7 @@ def main():
                           is_lds_kernel=is_lds_kernel, kernel=instance, edge_count_tables=int(last.edge_count_tables),
                           mask_fraction=args.mask_fraction, padded_copy_reused=int(last.padded_copy_reused),
                           env_overrides=int(last.env_overrides), copy_gbps=copy_gbps.value, read_gbps=read_gbps.value,
-                          lds_gbps=lds_gbps.value, psi_phi_bytes=int(meta.total_array_size))
+                          lds_gbps=lds_gbps.value, psi_phi_bytes=int(meta.total_array_size), traced=traced)
     config = {
         "workload": f"{T}x{H}x{W} psi/phi ({'float32' if args.num_bytes in (-1, 4) else 'uint%d' % (8 * args.num_bytes)}), "
                     f"full {W}x{H} start grid x {n_local} (v,theta) candidates per GPU, K={K}, "
@@ -721,11 +737,13 @@ def main():
 
 
 def live_traffic(argv, instance):
-    """Fabric bytes per launch of the search kernel instance `instance`, measured now: two short sub-runs of this command
-    under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need separate passes: MI355X_MICROARCH.md, PMC slots), per-dispatch
-    average over the launches of that instance.  bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the counters are in KiB and
-    gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes (same guide, HBM section).  {"error": ...} when rocprofv3 is
-    missing or a pass fails."""
+    """Counters and traced durations of the search kernel instance `instance`, measured now: three short sub-runs of this
+    command under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need separate passes: MI355X_MICROARCH.md, PMC slots; the
+    third collects SQ_INSTS_LDS and SQ_LDS_IDX_ACTIVE), per-dispatch averages over the launches of that instance.
+    bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the counters are in KiB and gfx950's FETCH_SIZE tallies 128-byte requests
+    at 64 bytes (same guide, HBM section).  Every pass also records each dispatch's start and end, so the kernel's duration
+    ON THIS BOX under the tracer comes with the counters (traced_kernel_ms: the mean over the three passes' launches).
+    {"error": ...} when rocprofv3 is missing or a byte pass fails; the LDS pass is optional (its keys are then absent)."""
     import glob
     import shutil
     import sqlite3
@@ -741,32 +759,48 @@ def live_traffic(argv, instance):
             i = child.index(flag)
             del child[i:i + 2]
     cmd_tail = [sys.executable, os.path.abspath(__file__)] + child + ["--steps", "3", "--warmup", "1", "--child"]
-    found = {}
+    found, durations, lds_error = {}, [], None
     env = dict(os.environ, TMPDIR="/tmp")
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE")):
+        optional = counters[0].startswith("SQ_")
         d = tempfile.mkdtemp(prefix="kb_pmc_", dir="/tmp")
         try:
-            r = subprocess.run([prof, "--pmc", counter, "-d", d, "-o", "r", "--"] + cmd_tail, cwd="/tmp", env=env,
+            r = subprocess.run([prof, "--pmc"] + list(counters) + ["-d", d, "-o", "r", "--"] + cmd_tail, cwd="/tmp", env=env,
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
             dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
             if r.returncode != 0 or not dbs:
-                return {"error": f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"}
+                raise RuntimeError(f"rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode}): "
+                                   f"{r.stderr.decode(errors='replace')[-300:]}")
             con = sqlite3.connect(dbs[0])
-            rows = con.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? "
-                               "group by kernel_name", (counter,)).fetchall()
+            rows = con.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                               "group by kernel_name, counter_name").fetchall()
+            # (one row per dispatch and counter: the duration of a dispatch once)
+            dur = con.execute("select kernel_name, dispatch_id, max(duration) from counters_collection "
+                              "group by kernel_name, dispatch_id").fetchall()
             con.close()
-            hit = [(n, c, v) for n, c, v in rows if instance in n]
-            if not hit:
-                return {"error": f"no dispatch of {instance} in the --pmc {counter} pass"}
-            found[counter] = (hit[0][1], float(hit[0][2]))
-        except (subprocess.TimeoutExpired, sqlite3.Error, OSError) as err:
-            return {"error": f"--pmc {counter} pass: {err}"}
+            for counter in counters:
+                hit = [(c, v) for n, cn, c, v in rows if instance in n and cn == counter]
+                if not hit:
+                    raise RuntimeError(f"no dispatch of {instance} in the --pmc {counter} pass")
+                found[counter] = (hit[0][0], float(hit[0][1]))
+            durations += [float(t) * 1e-6 for n, _, t in dur if instance in n and t]
+        except (subprocess.TimeoutExpired, sqlite3.Error, OSError, RuntimeError) as err:
+            if not optional:
+                return {"error": f"--pmc {' '.join(counters)} pass: {err}"}
+            lds_error = str(err)
         finally:
             shutil.rmtree(d, ignore_errors=True)
     fetch, write = found["FETCH_SIZE"][1], found["WRITE_SIZE"][1]
-    return {"bytes": int((2.0 * fetch + write) * 1024), "fetch_kib": fetch, "write_kib": write,
-            "source": f"live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE sub-runs of this command, average of "
-                      f"{found['FETCH_SIZE'][0]} launches of the instance; (2 x FETCH_SIZE + WRITE_SIZE) x 1024"}
+    out = {"bytes": int((2.0 * fetch + write) * 1024), "fetch_kib": fetch, "write_kib": write,
+           "source": f"live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE sub-runs of this command, average of "
+                     f"{found['FETCH_SIZE'][0]} launches of the instance; (2 x FETCH_SIZE + WRITE_SIZE) x 1024",
+           "traced_kernel_ms": float(np.mean(durations)) if durations else None, "traced_launches": len(durations)}
+    if "SQ_INSTS_LDS" in found:
+        out["lds_insts"] = found["SQ_INSTS_LDS"][1]
+        out["lds_cycles"] = found["SQ_LDS_IDX_ACTIVE"][1]
+    elif lds_error:
+        out["lds_error"] = lds_error
+    return out
 
 
 def verify(lib, torch, meta, arr, times, params, cands, n_cands, results, S, K, ins, W, H, last, stream, list_flags=0):

@@ -29,6 +29,9 @@ constexpr int WIDE_CHUNK = 2 * CHUNK;
 // there the kernel is bound by the bytes that cross the fabric -- N_candidates / chunk passes over the padded copy --, and four
 // times the candidates per staged slab are worth more than sixteen samples in flight (64 accumulator registers leave eight)
 constexpr int XWIDE_CHUNK = 4 * CHUNK;
+// (SearchArgs::global_box[XWIDE_REFUSAL_WORD], the last int of the tables' counter block: raised by a tile of the count-free
+// chunk-of-32 instance that would have had to count samples -- search_lds.h; read back by the host behind that launch)
+constexpr int XWIDE_REFUSAL_WORD = 9;
 #ifndef KB_DIRECT_ROWS
 #define KB_DIRECT_ROWS 4
 #endif

@@ -214,27 +214,7 @@ __device__ __forceinline__ void select_by_bits(const float (&ps)[C], const float
 // still sees its candidates in list order, but the wave walks max-over-lanes(#passing) rounds per chunk (one or
 // two once the lists have filled) instead of one insertion round per candidate that passes in ANY lane (most of
 // the C): the insertion and the exact likelihoods were 0.68 of cfg2's 4.62 ms.
-// The same selection as a chain of compares: C - 1 compares more than select_by_bits, but three temporaries instead of three
-// halved copies of the register sets -- what the finish of a chunk of 32 can afford next to its 64 live sums.
-template <int C>
-__device__ __forceinline__ void select_by_chain(const float (&ps)[C], const float (&ph)[C], const int (&cnt)[C], uint32_t sel,
-                                                float* p_out, float* f_out, int* n_out) {
-    float p = ps[0], f = ph[0];
-    int n = cnt[0];
-#pragma unroll
-    for (int c = 1; c < C; ++c) {
-        const bool pick = sel == (uint32_t)c;
-        p = pick ? ps[c] : p;
-        f = pick ? ph[c] : f;
-        n = pick ? cnt[c] : n;
-        asm volatile("" : "+v"(p), "+v"(f), "+v"(n));  // (in this order: left to itself the scheduler hoists every compare)
-    }
-    *p_out = p;
-    *f_out = f;
-    *n_out = n;
-}
-
-template <int KS, int C, bool LIGHT = false>
+template <int KS, int C>
 __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int cand_base, const float (&ps)[C], const float (&ph)[C],
                                                     const int (&cnt)[C], TopKPacked<KS>& top) {
     static_assert(C <= 16, "chunks of 32 are finished as two halves of 16 (lds_search_tile): the selection out of 32 register "
@@ -254,11 +234,7 @@ __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int can
         const int c_sel = (int)__builtin_ctz(pending | (1u << C));  // (C: a lane with nothing left selects nothing)
         float p, f;
         int n;
-        if constexpr (LIGHT) {
-            select_by_chain<C>(ps, ph, cnt, (uint32_t)c_sel, &p, &f, &n);
-        } else {
-            select_by_bits<C>(ps, ph, cnt, (uint32_t)c_sel, &p, &f, &n);
-        }
+        select_by_bits<C>(ps, ph, cnt, (uint32_t)c_sel, &p, &f, &n);
         const float lh = lh_from_sums(p, f);
         if (pending != 0u && lh > top.lh[KS - 1]) {
             top.insert(lh, flux_from_sums(p, f), (uint32_t)(cand_base + c_sel) | ((uint32_t)n << 16), a.stable_lists != 0);

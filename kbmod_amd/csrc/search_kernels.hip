@@ -1138,8 +1138,12 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
                         KB_HIP_TRY(hipMemsetAsync(n_invalid, 0, sizeof(int), stream));
                         launch_pad(a, cold, fmt, canon, padded, n_invalid, stream);
                         KB_HIP_TRY(hipGetLastError());
+                        // (the NO_DATA count read back earlier in this search belongs to the frame it was counted in -- the pad
+                        // pass counts inside the padded frame only --: it carries over to a re-made copy of the same frame, no further)
+                        const bool same_frame = have_key.Hp == key.Hp && have_key.Wp == key.Wp && have_key.px0 == key.px0 &&
+                                                have_key.py0 == key.py0 && have_key.src == key.src;
                         have_key = key;
-                        have_key.n_invalid_host = learned_n_invalid;
+                        have_key.n_invalid_host = same_frame ? learned_n_invalid : -1;
                     }
                     if (a.chunk == XWIDE_CHUNK) {
                         // The instance for chunks of 32 is count-free: what the tables must confirm, and the array.
@@ -1376,6 +1380,18 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
     KB_HIP_TRY(hipGetLastError());
     search_ms = search_timer.end();
     table_ms = n_cands != 0 ? table_timer.elapsed() : 0.0f;
+    if (which == 2 && a.chunk == XWIDE_CHUNK && !sigmag && a.K <= 32) {
+        // The count-free instance for chunks of 32 leaves a tile it cannot serve alone and says so (search_lds.h); the host's
+        // checks above make that unreachable -- if it happens all the same, the caller gets an error, not a partial result.
+        // (One 4-byte read-back and a sync behind a launch of tens of milliseconds.)
+        int refused = 0;
+        KB_HIP_TRY(hipMemcpyAsync(&refused, a.global_box + XWIDE_REFUSAL_WORD, sizeof(int), hipMemcpyDeviceToHost, stream));
+        KB_HIP_TRY(hipStreamSynchronize(stream));
+        if (refused != 0) {
+            return fail("deviceSearchFilter: internal error -- the count-free instance for chunks of 32 candidates met a tile that "
+                        "has to count samples (set KBMOD_CHUNK=16 to search with chunks of 16)");
+        }
+    }
     if (which != 0 && std::getenv("KBMOD_DEBUG") != nullptr) {
         int bad = -1;
         KB_HIP_TRY(hipMemcpyAsync(&bad, a.n_invalid, sizeof(int), hipMemcpyDeviceToHost, stream));

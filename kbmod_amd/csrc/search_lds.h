@@ -882,8 +882,16 @@ __global__ __launch_bounds__(ROWS * WAVE, 4) void kb_search_lds(const SearchArgs
         // The instance for chunks of 32 holds no counting loop (64 accumulators leave no registers for one: compiled in, it put
         // 500 bytes per lane into scratch memory, and a launch with that much scratch pays tens of milliseconds for it).  The
         // host launches it only after it has seen that no tile needs one -- no NO_DATA pixel (read back), every epoch staged
-        // with uniform shifts, start pixels on the image, edge tables built, shifts monotone (kb_shift_table_kernel).
+        // with uniform shifts, start pixels on the image, edge tables built, shifts monotone (kb_shift_table_kernel).  Should
+        // a tile need one all the same (a drift between the host's checks and this predicate), the launch fails SOFT: the
+        // workgroup raises the refusal word of the tables' counter block and leaves its slots alone; the host reads the word
+        // back behind the launch and reports an error instead of results (KB_XWIDE_TRAP: abort the context instead, debugging).
+#ifdef KB_XWIDE_TRAP
         __builtin_trap();
+#else
+        if (threadIdx.x == 0) atomicExch(const_cast<int*>(a.global_box) + XWIDE_REFUSAL_WORD, 1);
+        return;
+#endif
     } else {
         lds_search_tile<KS, C, ROWS, NB, CANON, SIGMAG, LM, false>(a, tc, smem, lists);
     }

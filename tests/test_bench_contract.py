@@ -46,6 +46,28 @@ def test_assembly_cache_resident_line_names_lds_and_one_clock():
     assert "OUTSIDE the timed steps" in r["padded_copy"] and "tables" in r["obs_counts"]
 
 
+def test_assembly_traced_values_make_the_fraction_recomputable():
+    """roofline.traced_kernel_ms / lds_insts / lds_cycles (bench.live_traffic: the run's own rocprofv3 sub-runs): a reader
+    recomputes `frac` on the tracer's clock and the one-ds_read_b64-per-64-evaluations identity from the line alone."""
+    import bench
+
+    evals = 512 * 512 * 1024 * 64
+    traced = {"traced_kernel_ms": 2.1, "traced_launches": 12, "lds_insts": evals / 64 * 1.006, "lds_cycles": evals / 64 * 2.04}
+    r, kw = _stub_roofline(bench, traced=traced)
+    assert r["traced_kernel_ms"] == 2.1 and r["traced_launches"] == 12
+    assert abs(r["frac_at_traced_kernel_ms"] - kw["lds_read_bytes"] / 2.1e-3 / 1e9 / bench.LDS_PEAK_GBPS) < 1e-12
+    assert abs(r["evals_per_lds_inst"] - 64 / 1.006) < 1e-9 and abs(r["lds_cycles_per_inst"] - 2.04 / 1.006) < 1e-9
+    # without the sub-runs (N > 1, --no-live-traffic) the keys are there and empty
+    r0, _ = _stub_roofline(bench)
+    for key in ("traced_kernel_ms", "traced_launches", "frac_at_traced_kernel_ms", "lds_insts", "lds_cycles", "evals_per_lds_inst",
+                "lds_cycles_per_inst"):
+        assert key in r0 and r0[key] is None
+    # the LDS pass is optional: a byte-only measurement still carries the traced duration
+    r1, _ = _stub_roofline(bench, traced={"traced_kernel_ms": 2.2, "traced_launches": 8})
+    assert r1["traced_kernel_ms"] == 2.2 and r1["lds_insts"] is None and r1["evals_per_lds_inst"] is None
+    json.dumps(r)
+
+
 def test_assembly_hbm_resident_line_uses_fabric_bytes_or_says_lower_bound():
     import bench
 
