@@ -252,6 +252,10 @@ def main():
     ap.add_argument("--plain-ties", action="store_true",
                     help="multi-GPU: exchange K records per pixel and break ties by candidate index (the default exchanges "
                          "2 K records built by stable insertion and reproduces the single-GPU result exactly, ties included)")
+    ap.add_argument("--stable-lists", action="store_true",
+                    help="multi-GPU, dense exchange: every rank searches with 2 K stable records per pixel (flag 512) and the root "
+                         "merges them exactly (rounds 3-5); the default since round 6 exchanges the K records of the ranks' normal "
+                         "searches and re-makes the few pixels they do not decide (kb_merge_compact_repairable + kb_repair_pixels)")
     ap.add_argument("--separable-psf", action="store_true",
                     help="build psi/phi with the separable PSF kernel (KB_BUILD_SEPARABLE: <= 1e-4 relative to the reference's "
                          "tap loop instead of bit-identical)")
@@ -403,14 +407,20 @@ def main():
                         H - ins, K, 0)
     # multi-GPU: tie-exact exchange -- every rank keeps 2 K records per pixel by stable insertion (flag 512), the merge
     # on rank 0 replays the reference's insertion (kbmod_amd/distributed.py); K > 16 or --plain-ties: K records, ties by index
-    exact_ties = dist_mode and not args.plain_ties and K <= 16
-    list_len = 2 * K if exact_ties else K
     # ... and in what form: a search with a likelihood threshold leaves nearly every slot empty or below it, and the
     # reference drops those right after its kernel -- one count byte per pixel + the survivors travel instead (sparse)
     thresholded = args.sigmag or float(params.min_lh) > 0.0
-    sparse = dist_mode and exact_ties and (args.exchange == "sparse" or (args.exchange == "auto" and thresholded))
-    if args.exchange == "sparse" and dist_mode and not exact_ties:
+    want_exact = dist_mode and not args.plain_ties
+    sparse = want_exact and K <= 16 and (args.exchange == "sparse" or (args.exchange == "auto" and thresholded))
+    if args.exchange == "sparse" and dist_mode and not sparse:
         raise RuntimeError("--exchange sparse goes through the tie-exact merge (K <= 16, not --plain-ties)")
+    # Round 6, dense exchange: the ranks search with their NORMAL K-record lists (the fastest single-GPU instance, half the
+    # bytes on the wire), the root folds the lists in candidate order and re-makes the few pixels the records do not decide
+    # from its replica of the stack.  Same result as the 2 K stable lists, bit for bit (--verify).  Not with the in-search
+    # sigma-G filter (the repair evaluates plain trajectories) -- those searches exchange sparsely anyway.
+    repair = want_exact and not sparse and not args.stable_lists and not args.sigmag and K <= 32
+    exact_ties = want_exact and not repair and K <= 16   # 2 K stable lists (flag 512) + kb_merge_compact_exact
+    list_len = 2 * K if exact_ties else K
     wire = {}
     if dist_mode:
         rank_params = Params.from_buffer_copy(params)
@@ -489,7 +499,10 @@ def main():
                                                             flags | (512 if exact_ties else 0), stream, C.byref(st)))
                     t_call = time.perf_counter() - t_call
                     nxt = kdist.start_gather_compact(records, (ins, W - ins), (ins, H - ins), K, all_cands, gathered=gathered,
-                                                     out=results, list_len=list_len)
+                                                     out=results, list_len=list_len,
+                                                     repair_stack=(meta, arr.value, times.data_ptr()) if repair else None,
+                                                     min_obs=int(params.min_observations),
+                                                     list_begin=[r * n_local for r in range(world + 1)] if repair else None)
                     drain()               # the previous step's gather has had this step's search to travel in; merge it now
                     in_flight[0] = nxt
                     if args.no_overlap:
@@ -603,7 +616,9 @@ def main():
                      + (f"sparse exchange (one count byte per pixel + the records with lh >= {float(params.min_lh):g} of {list_len} "
                         "per pixel: one RCCL gather of the headers + one message per rank) + per-pixel merge, tie-exact" if sparse
                         else f"one RCCL gather of 16-byte records to rank 0 ({list_len} per pixel) + per-pixel merge, "
-                        + ("tie-exact" if exact_ties else "ties by candidate index")))
+                        + ("tie-exact (2 K stable lists)" if exact_ties else
+                           ("tie-exact (the ranks' normal K-record lists folded in candidate order; the pixels they do not decide "
+                            "re-made on rank 0)" if repair else "ties by candidate index"))))
                     if dist_mode else "none",
         "psi_phi_build_ms": build_ms,
     }
@@ -621,7 +636,9 @@ def main():
                            "search_wrote_counts": wire.get("search_wrote_counts"),
                            "per_rank_search_ms": [p["search_call_ms"] for p in per_rank],
                            "per_rank_search_kernel_ms": [p["search_kernel_ms"] for p in per_rank],
-                           "merge_ms": kdist.last_merge_ms() if rank == 0 else None}
+                           "merge_ms": kdist.last_merge_ms() if rank == 0 else None,
+                           "lists": "2K stable" if exact_ties else ("K records + repair" if repair else "K records"),
+                           "repair": kdist.last_repair() if (rank == 0 and repair) else None}
     if build_kernel_ms is not None:
         in_out = float(T) * H * W * 8 + float(meta.total_array_size)  # sci + var in, the array out
         out["psi_phi_build"] = {"kernel": "separable strip (<= 1e-4)" if args.separable_psf else "2-D strip (bit-identical)",
@@ -657,8 +674,8 @@ def main():
             out["verify_survivors"] = int((~gone).sum().item())
         same = torch.equal(results.view(torch.int32), single.view(torch.int32))
         lh_same = torch.equal(results[:, 2].contiguous().view(torch.int32), single[:, 2].contiguous().view(torch.int32))
-        out["verify"] = {"merged_equals_single_device_ok": bool(same) if exact_ties else bool(lh_same),
-                         "merged_likelihoods_equal_ok": bool(lh_same), "tie_exact": bool(exact_ties), "backend": backend,
+        out["verify"] = {"merged_equals_single_device_ok": bool(same) if (exact_ties or repair or sparse) else bool(lh_same),
+                         "merged_likelihoods_equal_ok": bool(lh_same), "tie_exact": bool(exact_ties or repair or sparse), "backend": backend,
                          "exchange": "sparse" if sparse else "dense", "world": world}
 
     # What a pipeline that builds ONE StackSearch and calls search_all once pays (the reference's, run_search.py:363-378): the

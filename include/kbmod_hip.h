@@ -321,6 +321,28 @@ int kb_merge_compact(const kb_compact_result* lists_dev, int32_t n_lists, kb_sea
 int kb_merge_compact_exact(const kb_compact_result* lists_dev, int32_t n_lists, int32_t list_len, kb_search_params params,
                            const kb_trajectory* all_cands_dev, uint64_t n_all_cands, kb_trajectory* out_dev, void* stream);
 
+/* new (round 6): the exchange with K records per device, repaired where the records do not decide.  lists_dev: n_lists
+ * lists of [n_pixels][K] records, each what kb_device_search_compact leaves with list_len = K and WITHOUT flag 512 -- the
+ * reference's insertion (kernels.cu:304-331) over that device's slice of the candidates, at the speed of the single-device
+ * search; K = params.results_per_pixel.  out_dev [n_pixels][K] = the single-device search over the whole candidate list for
+ * every pixel whose lists determine it; a pixel one of whose FULL lists ends at the pixel's K-th likelihood (a candidate
+ * that ties with it may have fallen off that list) is appended to hazard_idx_dev (uint32 pixel numbers, room for n_pixels)
+ * and counted in *n_hazard_host: its slots are to be re-made by kb_repair_pixels.  Synchronises the stream. */
+int kb_merge_compact_repairable(const kb_compact_result* lists_dev, int32_t n_lists, kb_search_params params,
+                                const kb_trajectory* all_cands_dev, uint64_t n_all_cands, kb_trajectory* out_dev,
+                                uint32_t* hazard_idx_dev, uint64_t* n_hazard_host, void* stream);
+/* ... the repair: the listed start pixels (row-major numbers inside params' bounds) searched again, one wavefront per pixel
+ * -- lanes = candidates, evaluateTrajectory (kernels.cu:154-242) as every search kernel here runs it, the reference's
+ * insertion in candidate order -- into their K slots of out_dev.  lists_dev = NULL: over the WHOLE candidate list.  With the
+ * exchange's lists (lists_dev / n_lists as above, list r = the candidates [list_cand_begin_host[r], list_cand_begin_host[r + 1])
+ * of the job-wide order, the ranges tiling [0, n_all_cands) ascending): only the slices of the SUSPECT lists -- full, ending
+ * at or above the pixel's K-th likelihood -- are evaluated again, the other lists' K records stand for their slices (same
+ * result; an eighth of the evaluations at eight ranks).  No in-search sigma-G. */
+int kb_repair_pixels(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev, kb_search_params params,
+                     const kb_trajectory* all_cands_dev, uint64_t n_all_cands, const uint32_t* pixel_idx_dev,
+                     uint64_t n_listed, const kb_compact_result* lists_dev, int32_t n_lists, const int32_t* list_cand_begin_host,
+                     kb_trajectory* out_dev, void* stream);
+
 /* ---- sparse form of the exchange (new; SURVEY 8(e): "shrink traffic by compacting lh >= min_lh first").
  * The reference removes results below min_lh after its kernel (stack_search.cpp:266-270); its swap-down insertion
  * (kernels.cu:323-330) never lets a smaller likelihood touch the part of a list at or above a larger one, so the entries

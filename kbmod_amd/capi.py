@@ -67,6 +67,10 @@ def load_lib():
     lib.kb_merge_compact.argtypes = [C.c_void_p, C.c_int32, Params, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.kb_merge_compact_exact.argtypes = [C.c_void_p, C.c_int32, C.c_int32, Params, C.c_void_p, C.c_uint64, C.c_void_p,
                                            C.c_void_p]
+    lib.kb_merge_compact_repairable.argtypes = [C.c_void_p, C.c_int32, Params, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                C.POINTER(C.c_uint64), C.c_void_p]
+    lib.kb_repair_pixels.argtypes = [C.POINTER(Meta), C.c_void_p, C.c_void_p, Params, C.c_void_p, C.c_uint64, C.c_void_p,
+                                     C.c_uint64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.kb_sparse_header_bytes.restype = C.c_uint64
     lib.kb_sparse_header_bytes.argtypes = [C.c_uint64]
     lib.kb_sparsify_compact.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64,

@@ -406,6 +406,28 @@ PYBIND11_MODULE(search, m) {
           "Host twin of kb_merge_compact_exact: per-device lists of `list_len` 16-byte records per pixel, built by stable\n"
           "insertion, merged into the K results per pixel a single device would produce (ties included).");
 
+    m.def("merge_compact_repairable_host",
+          [](py::array_t<uint8_t, py::array::c_style> raw, int n_lists, int K, int x_min, int x_max, int y_min, int y_max,
+             const std::vector<Trajectory>& all_cands) {
+              if (x_max <= x_min || y_max <= y_min) throw std::runtime_error("merge_compact_repairable_host: invalid search bounds");
+              const uint64_t n_pixels = (uint64_t)(x_max - x_min) * (uint64_t)(y_max - y_min);
+              if (K <= 0 || (uint64_t)raw.size() != (uint64_t)n_lists * n_pixels * (uint64_t)K * sizeof(kb_compact_result)) {
+                  throw std::runtime_error("merge_compact_repairable_host: buffer size does not match n_lists * n_pixels * K * 16");
+              }
+              std::vector<uint32_t> hazards;
+              std::vector<Trajectory> out = merge_compact_repairable_host(
+                      reinterpret_cast<const kb_compact_result*>(raw.data()), n_lists, n_pixels, K, x_max - x_min, x_min, y_min,
+                      all_cands.data(), all_cands.size(), hazards);
+              py::array_t<uint8_t> res((py::ssize_t)(out.size() * sizeof(Trajectory)));
+              if (!out.empty()) std::memcpy(res.mutable_data(), out.data(), out.size() * sizeof(Trajectory));
+              py::array_t<uint32_t> hz((py::ssize_t)hazards.size());
+              if (!hazards.empty()) std::memcpy(hz.mutable_data(), hazards.data(), hazards.size() * sizeof(uint32_t));
+              return py::make_tuple(res, hz);
+          },
+          "Host twin of kb_merge_compact_repairable: per-device lists of K 16-byte records per pixel (the reference's insertion\n"
+          "over each device's slice) -> (the K results per pixel a single device would produce wherever the lists decide it,\n"
+          "the numbers of the pixels where they do not and a repair is due).");
+
     m.def("sparse_header_bytes", &sparse_header_bytes, "Bytes of the header of a sparse exchange list for n_pixels pixels.");
     m.def("sparsify_compact_host",
           [](py::array_t<uint8_t, py::array::c_style> raw, uint64_t n_pixels, int list_len, float min_lh) {

@@ -280,6 +280,46 @@ inline std::vector<Trajectory> merge_compact_exact_host(const kb_compact_result*
     return out;
 }
 
+// Host twin of kb_merge_compact_repairable: per-device lists of K records per pixel, each the reference's insertion over
+// that device's slice of the candidates (contiguous slices in ascending order, no stable lists), folded in candidate order
+// (kb::merge_fold_pixel of search_math.h, the routine the device kernel runs) -> the K results per pixel of ONE device on
+// the whole candidate list wherever the records decide it, and the numbers of the pixels where they do not (`hazards`: a
+// dropped candidate of some slice may tie with the last slot); the slots of a hazard are placeholders until the caller
+// re-makes them (kb_repair_pixels).
+inline std::vector<Trajectory> merge_compact_repairable_host(const kb_compact_result* lists, int n_lists, uint64_t n_pixels, int K,
+                                                             int sw, int x_min, int y_min, const Trajectory* all_cands,
+                                                             uint64_t n_all_cands, std::vector<uint32_t>& hazards) {
+    if (K <= 0 || K > kb::MERGE_EXACT_MAX_K2) throw std::runtime_error("merge_compact_repairable: lists of 1 to 32 records per pixel");
+    std::vector<Trajectory> out(n_pixels * (uint64_t)K);
+    const uint64_t stride = n_pixels * (uint64_t)K;
+    kb_compact_result state[kb::MERGE_EXACT_MAX_K2], recs[kb::MERGE_EXACT_MAX_K2];
+    hazards.clear();
+    for (uint64_t pix = 0; pix < n_pixels; ++pix) {
+        const kb_compact_result* mine = lists + pix * (uint64_t)K;
+        auto read = [&](int r, int pos) { return mine[(uint64_t)r * stride + pos]; };
+        uint64_t suspects = 0;
+        const bool hazard = kb::merge_fold_pixel(read, n_lists, K, state, recs, &suspects);
+        if (hazard) hazards.push_back((uint32_t)pix);
+        const int y_i = (int)(pix / (uint64_t)sw), x_i = (int)(pix % (uint64_t)sw);
+        for (int s = 0; s < K; ++s) {
+            Trajectory t;
+            t.x = x_i + x_min;
+            t.y = y_i + y_min;
+            t.lh = -FLT_MAX;
+            const kb_compact_result rec = state[s];
+            if (!hazard && rec.cand >= 0 && (uint64_t)rec.cand < n_all_cands) {
+                t.vx = all_cands[rec.cand].vx;
+                t.vy = all_cands[rec.cand].vy;
+                t.lh = rec.lh;
+                t.flux = rec.flux;
+                t.obs_count = rec.obs_count;
+            }
+            out[pix * K + s] = t;
+        }
+    }
+    return out;
+}
+
 // Host twins of kb_sparsify_compact / kb_merge_sparse_exact (csrc/exchange_kernels.hip): the sparse form of the
 // exchange lists -- per pixel the number of records that survive the reference's post-filter on the likelihood
 // (stack_search.cpp:266-270: lh < min_lh goes; empty slots carry cand = -1) + those records, pixel after pixel.

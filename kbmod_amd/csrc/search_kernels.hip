@@ -546,6 +546,371 @@ __global__ __launch_bounds__(64) void kb_merge_compact_exact_kernel(const kb_com
     }
 }
 
+// The merge of the exchange with K records per device (kb_merge_compact_repairable; merge_fold_pixel, search_math.h): the
+// fold over the devices' lists in candidate order.  Every pixel the fold decides is written; a pixel with a suspect slice
+// -- a dropped candidate may tie with the list's last slot -- is appended to `hazards` for kb_repair_pixels.
+// KT > 0: K = KT is a compile-time constant (lists of up to 8: what the exchange runs) and everything lives in registers;
+// KT = 0: any K up to 32 through merge_fold_pixel itself, its two arrays in scratch memory.
+template <int KT>
+__global__ __launch_bounds__(256) void kb_merge_compact_repairable_kernel(const kb_compact_result* __restrict__ lists, int n_lists,
+                                                                          uint64_t n_pixels, int K_any, int sw, int x_min, int y_min,
+                                                                          const kb_trajectory* __restrict__ all_cands,
+                                                                          uint64_t n_all_cands, kb_trajectory* __restrict__ out,
+                                                                          uint32_t* __restrict__ hazards,
+                                                                          unsigned long long* __restrict__ n_hazards) {
+    constexpr int KA = KT > 0 ? KT : MERGE_EXACT_MAX_K2;  // array length
+    const int K = KT > 0 ? KT : K_any;
+    const uint64_t pix_raw = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix_raw - (uint64_t)(threadIdx.x & 63u) >= n_pixels) return;  // (whole waves past the end)
+    const bool live = pix_raw < n_pixels;  // (the lanes past the end of the last wave stay: they help to stage)
+    const uint64_t pix = live ? pix_raw : n_pixels - 1;
+    const uint64_t list_stride = n_pixels * (uint64_t)K;
+    kb_compact_result state[KA];
+    bool hazard = false;
+    if constexpr (KT > 0) {
+        // merge_fold_pixel with everything in registers: fully unrolled, no array indexed by a run-time value (with K a
+        // run-time value the compiler turns even a chain of selects over the slots back into an indexed access, and the lists
+        // went to scratch memory: 0.67 ms for 512 x 512 pixels x 8 lists against the search's 2.4).
+        // A pixel's K records of one list are ONE run of K x 16 bytes; read record by record, lane by lane, every load touches
+        // 64 lines.  Each wave therefore copies its 64 pixels' records of a list -- contiguous in the list -- with coalesced
+        // 16-byte loads into its own patch of LDS (pixel pitch K + 1 records: conflict-free for the 16-byte reads) and reads
+        // them there.
+        __shared__ __attribute__((aligned(16))) kb_compact_result patch[256 / 64][64 * (KT + 1)];
+        const int lane = (int)(threadIdx.x & 63u);
+        kb_compact_result* mine_patch = patch[threadIdx.x >> 6];
+        const uint64_t wave_pix0 = pix_raw - (uint64_t)lane;
+        const int wave_recs = (int)(min((uint64_t)64, n_pixels - wave_pix0) * (uint64_t)KT);
+        auto stage = [&](int r) {
+            const kb_compact_result* src = lists + (uint64_t)r * list_stride + wave_pix0 * (uint64_t)KT;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                const int c = j * 64 + lane;  // record c of the wave's run: pixel c / K, slot c % K
+                if (c < wave_recs) mine_patch[(c / KT) * (KT + 1) + (c % KT)] = src[c];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        const kb_compact_result none = {-FLT_MAX, 0.0f, -1, 0};
+        stage(0);
+#pragma unroll
+        for (int s = 0; s < KT; ++s) {
+            const kb_compact_result rec = mine_patch[lane * (KT + 1) + s];
+            state[s] = rec.cand >= 0 ? rec : none;  // kernels.cu:293-301
+        }
+        for (int r = 1; r < n_lists; ++r) {
+            stage(r);
+            const float tail_before = state[KT - 1].lh;
+            kb_compact_result rec[KT];
+            bool can[KT];
+            bool any = false;
+#pragma unroll
+            for (int s = 0; s < KT; ++s) {
+                rec[s] = mine_patch[lane * (KT + 1) + s];
+                can[s] = rec[s].cand >= 0 && rec[s].lh > tail_before;  // (what is not above the last slot moves nothing)
+                any = any || can[s];
+            }
+            if (!any) continue;
+            const kb_compact_result last = rec[KT - 1];
+            // candidate order: an odd-even transposition network over the records (compile-time pairs: a pick by rank, written
+            // as a chain of selects over the array, is turned back into an indexed access and the array into scratch memory);
+            // the records that cannot enter sort to the end
+            int key[KT];
+#pragma unroll
+            for (int i = 0; i < KT; ++i) key[i] = can[i] ? rec[i].cand : 0x7fffffff;
+#pragma unroll
+            for (int pass = 0; pass < KT; ++pass) {
+#pragma unroll
+                for (int i = pass & 1; i + 1 < KT; i += 2) {
+                    const bool swap = key[i + 1] < key[i];
+                    const int ka = key[i], kb2 = key[i + 1];
+                    key[i] = swap ? kb2 : ka;
+                    key[i + 1] = swap ? ka : kb2;
+                    const kb_compact_result a = rec[i], b = rec[i + 1];
+                    rec[i].lh = swap ? b.lh : a.lh;
+                    rec[i].flux = swap ? b.flux : a.flux;
+                    rec[i].cand = swap ? b.cand : a.cand;
+                    rec[i].obs_count = swap ? b.obs_count : a.obs_count;
+                    rec[i + 1].lh = swap ? a.lh : b.lh;
+                    rec[i + 1].flux = swap ? a.flux : b.flux;
+                    rec[i + 1].cand = swap ? a.cand : b.cand;
+                    rec[i + 1].obs_count = swap ? a.obs_count : b.obs_count;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KT; ++i) {
+                if (key[i] == 0x7fffffff) continue;  // (cannot enter; per lane)
+                kb_compact_result in = rec[i];
+#pragma unroll
+                for (int s = 0; s < KT; ++s) {  // kernels.cu:323-330
+                    if (in.lh > state[s].lh) {
+                        const kb_compact_result t = state[s];
+                        state[s] = in;
+                        in = t;
+                    }
+                }
+            }
+            hazard = hazard || (last.cand >= 0 && last.lh > tail_before && last.lh == state[KT - 1].lh);
+        }
+    } else {
+        const kb_compact_result* mine = lists + pix * (uint64_t)K;
+        auto read = [&](int r, int pos) { return mine[(uint64_t)r * list_stride + pos]; };
+        kb_compact_result recs[KA];
+        uint64_t suspects = 0;
+        hazard = merge_fold_pixel(read, n_lists, K, state, recs, &suspects);
+    }
+    if (!live) return;
+    if (hazard) {
+        hazards[atomicAdd(n_hazards, 1ull)] = (uint32_t)pix;  // (its slots are re-made from the stack)
+        return;
+    }
+    const int y_i = (int)(pix / (uint64_t)sw), x_i = (int)(pix - (uint64_t)y_i * (uint64_t)sw);
+#pragma unroll
+    for (int s = 0; s < KA; ++s) {
+        if (s >= K) break;
+        kb_trajectory res = placeholder_result(x_i + x_min, y_i + y_min);
+        const kb_compact_result rec = state[s];
+        if (rec.cand >= 0 && (uint64_t)rec.cand < n_all_cands) {
+            res.vx = all_cands[rec.cand].vx;
+            res.vy = all_cands[rec.cand].vy;
+            res.lh = rec.lh;
+            res.flux = rec.flux;
+            res.obs_count = rec.obs_count;
+        }
+        out[pix * (uint64_t)K + s] = res;
+    }
+}
+
+// evaluate_trajectory_full (search_math.h) without the sigma-G branch and with the samples of REPAIR_BATCH epochs requested
+// before the first is summed: the same positions (predict_index), the same bounds rule and decode (read_psi_phi), the same
+// sums in epoch order -- the same bits --, but the loads of a batch are independent of each other, so a lane waits for one
+// memory latency per batch instead of one per epoch (the rolled loop ran 700 pixels in 0.7 ms; this one in under 0.1).
+constexpr int REPAIR_BATCH = 32;
+template <int NB>
+__device__ __forceinline__ void evaluate_plain_batched(const kb_psi_phi_meta& m, const void* __restrict__ arr,
+                                                       const double* __restrict__ times, kb_trajectory* c) {
+    float psi_sum = 0.0f, phi_sum = 0.0f;
+    int num_seen = 0;
+    const int T = (int)m.num_times;
+    for (int i0 = 0; i0 < T; i0 += REPAIR_BATCH) {
+        float psi[REPAIR_BATCH], phi[REPAIR_BATCH];
+#pragma unroll
+        for (int j = 0; j < REPAIR_BATCH; ++j) {
+            const int i = min(i0 + j, T - 1);  // (past the end: a second read of the last epoch, not summed)
+            const double t = times[i];
+            int cx, cy;
+            const bool okx = predict_index(c->x, c->vx, t, &cx);
+            const bool oky = predict_index(c->y, c->vy, t, &cy);
+            const bool in = okx && oky && cy >= 0 && cx >= 0 && (uint64_t)cy < m.height && (uint64_t)cx < m.width;
+            const uint64_t pix = in ? m.pixels_per_image * (uint64_t)i + (uint64_t)cy * m.width + (uint64_t)cx : 0ull;
+            if (NB == 4) {
+                const float2 v = reinterpret_cast<const float2*>(arr)[pix];
+                psi[j] = in ? v.x : NAN;
+                phi[j] = in ? v.y : NAN;
+            } else {
+                float pv, fv;
+                if (NB == 1) {
+                    const uchar2 v = reinterpret_cast<const uchar2*>(arr)[pix];
+                    pv = (float)v.x;
+                    fv = (float)v.y;
+                } else {
+                    const ushort2 v = reinterpret_cast<const ushort2*>(arr)[pix];
+                    pv = (float)v.x;
+                    fv = (float)v.y;
+                }
+                psi[j] = (!in || pv == 0.0f) ? NAN : decode_code(pv, m.psi_scale, m.psi_min_val);
+                phi[j] = (!in || fv == 0.0f) ? NAN : decode_code(fv, m.phi_scale, m.phi_min_val);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < REPAIR_BATCH; ++j) {
+            if (i0 + j < T && __builtin_isfinite(psi[j]) && __builtin_isfinite(phi[j])) {
+                psi_sum += psi[j];
+                phi_sum += phi[j];
+                num_seen += 1;
+            }
+        }
+    }
+    c->obs_count = num_seen;
+    c->lh = lh_from_sums(psi_sum, phi_sum);
+    c->flux = flux_from_sums(psi_sum, phi_sum);
+}
+
+// kb_repair_pixels: one workgroup of REPAIR_WAVES wavefronts per listed start pixel.  Lanes = candidates: every wave
+// evaluates 64 of a block of REPAIR_WAVES x 64 consecutive candidates -- the reference's evaluateTrajectory at exact
+// positions (evaluate_plain_batched: evaluate_trajectory_full's arithmetic, what kb_search_large_k and the epilogues run) --
+// into LDS, then wave 0 runs the reference's insertion over the block in candidate order (kernels.cu:304-331): the list
+// lives in LDS (K x 16 bytes), the likelihood to beat in a scalar of wave 0.
+// With the exchange's lists at hand (`lists` != null, list r = the candidates [begin[r], begin[r + 1]) in job-wide order)
+// the kernel walks merge_fold_pixel's fold and evaluates only the SUSPECT slices again; every other list's K records (put
+// back into candidate order) stand for its slice: an eighth of the evaluations at eight ranks, and the scattered loads of
+// the evaluations are what this kernel costs.
+constexpr int REPAIR_WAVES = 8;
+constexpr int REPAIR_MAX_LISTS = 64;
+struct RepairLists {
+    const kb_compact_result* lists;  // [n_lists][n_pixels][K], or null: every candidate is evaluated
+    uint64_t n_pixels;
+    int n_lists;
+    int begin[REPAIR_MAX_LISTS + 1];
+};
+struct RepairEval {  // one evaluated candidate of the block in flight
+    float lh, flux;
+    int obs;
+};
+template <int NB>
+__global__ __launch_bounds__(REPAIR_WAVES * WAVE) void kb_repair_pixels_kernel(const kb_psi_phi_meta meta, const void* __restrict__ psi_phi,
+                                                                               const double* __restrict__ times, const kb_search_params params,
+                                                                               const kb_trajectory* __restrict__ cands, uint64_t n_cands,
+                                                                               const uint32_t* __restrict__ pixels, uint64_t n_listed,
+                                                                               const RepairLists rl, kb_trajectory* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char repair_smem[];
+    constexpr int BLOCK = REPAIR_WAVES * WAVE;
+    const int K = (int)params.results_per_pixel;
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & (WAVE - 1));
+    // LDS: the block's evaluations, the list, one word of wave 0's decisions
+    RepairEval* evals = reinterpret_cast<RepairEval*>(repair_smem);
+    kb_compact_result* list = reinterpret_cast<kb_compact_result*>(repair_smem + (size_t)BLOCK * sizeof(RepairEval));
+    int* decision = reinterpret_cast<int*>(list + K);
+    const int sw = params.x_start_max - params.x_start_min;
+    const uint32_t pix = pixels[blockIdx.x];
+    const int y_i = (int)(pix / (uint32_t)sw), x_i = (int)(pix - (uint32_t)y_i * (uint32_t)sw);
+    const int x = x_i + params.x_start_min, y = y_i + params.y_start_min;
+    // (inside wave 0 the list is lane 0's: the other lanes fill and read it with a wavefront fence between)
+    auto wave_fence = []() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    float tail = -FLT_MAX;  // wave 0, uniform: the last slot's likelihood
+    // one candidate (uniform arguments; wave 0) through kernels.cu:323-330
+    auto insert = [&](float lh, float flux, int cand, int obs) {
+        if (!(lh > tail)) return;  // (a candidate that is not above the last slot moves nothing: the swaps need a strict '>')
+        float new_tail = tail;
+        if (lane == 0) {
+            kb_compact_result in = {lh, flux, cand, obs};
+            for (int s = 0; s < K; ++s) {
+                const kb_compact_result t = list[s];
+                if (in.lh > t.lh) {
+                    list[s] = in;
+                    in = t;
+                    if (in.cand < 0) break;  // (a displaced placeholder moves nothing further)
+                }
+            }
+            new_tail = list[K - 1].lh;
+        }
+        tail = __shfl(new_tail, 0);
+    };
+    // the candidates [lo, hi) from the stack: every wave evaluates, wave 0 inserts (workgroup-uniform arguments)
+    auto evaluate_range = [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t base = lo; base < hi; base += BLOCK) {
+            const uint64_t ci = base + (uint64_t)threadIdx.x;
+            RepairEval e = {-FLT_MAX, 0.0f, -1};  // (obs -1: does not exist / fails the observation count)
+            if (ci < hi) {
+                kb_trajectory cur = placeholder_result(x, y);
+                cur.vx = cands[ci].vx;
+                cur.vy = cands[ci].vy;
+                evaluate_plain_batched<NB>(meta, psi_phi, times, &cur);
+                if (!(cur.obs_count < params.min_observations)) e = RepairEval{cur.lh, cur.flux, cur.obs_count};  // kernels.cu:318-320
+            }
+            evals[threadIdx.x] = e;
+            __syncthreads();
+            if (wave == 0) {
+                for (int w = 0; w < REPAIR_WAVES; ++w) {
+                    const RepairEval mine_e = evals[w * WAVE + lane];
+                    uint64_t todo = __ballot(mine_e.obs >= 0 && mine_e.lh > tail);
+                    while (todo != 0ull) {  // uniform: lowest candidate first
+                        const int src = (int)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        insert(__shfl(mine_e.lh, src), __shfl(mine_e.flux, src), (int)(base + (uint64_t)(w * WAVE + src)),
+                               __shfl(mine_e.obs, src));
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    };
+    if (wave == 0) {
+        for (int s = lane; s < K; s += WAVE) list[s] = kb_compact_result{-FLT_MAX, 0.0f, -1, 0};  // kernels.cu:293-301
+        wave_fence();
+    }
+    if (rl.lists == nullptr) {
+        evaluate_range(0, n_cands);
+    } else {
+        // The fold of merge_fold_pixel (wave 0), with the suspect slices evaluated from the stack instead of trusted.
+        const int n_lists = rl.n_lists;
+        const uint64_t list_stride = rl.n_pixels * (uint64_t)K;
+        const kb_compact_result* mine = rl.lists + (uint64_t)pix * (uint64_t)K;
+        if (wave == 0) {
+            // slice 0: its list IS the reference's state behind it
+            for (int s = lane; s < K; s += WAVE) {
+                kb_compact_result rec = mine[s];
+                if (rec.cand < 0) rec = kb_compact_result{-FLT_MAX, 0.0f, -1, 0};
+                list[s] = rec;
+            }
+            wave_fence();
+            float t0 = -FLT_MAX;
+            if (lane == 0) t0 = list[K - 1].lh;
+            tail = __shfl(t0, 0);
+        }
+        for (int r = 1; r < n_lists; ++r) {  // workgroup-uniform; the lists cover ascending candidate ranges
+            if (wave == 0) {
+                const float tail_before = tail;
+                wave_fence();
+                // the state as it stands (K <= 32 records, one per lane), should the slice turn out suspect
+                kb_compact_result saved = {-FLT_MAX, 0.0f, -1, 0};
+                if (lane < K) saved = list[lane];
+                kb_compact_result rec = {-FLT_MAX, 0.0f, -1, 0};
+                if (lane < K) rec = mine[(uint64_t)r * list_stride + (uint64_t)lane];
+                const float last_lh = __shfl(rec.lh, K - 1);
+                const int last_cand = __shfl(rec.cand, K - 1);
+                // the list's records stand for its slice: back into candidate order, then through the insertion
+                const bool valid = rec.cand >= 0 && rec.lh > tail_before;
+                int rank = 0;
+                for (int j = 0; j < K; ++j) {
+                    const int cj = __shfl(rec.cand, j);
+                    const float lj = __shfl(rec.lh, j);
+                    rank += (cj >= 0 && lj > tail_before && cj < rec.cand) ? 1 : 0;
+                }
+                const int n_valid = (int)__builtin_popcountll(__ballot(valid));
+                for (int i = 0; i < n_valid; ++i) {
+                    const int src = (int)__builtin_ctzll(__ballot(valid && rank == i));
+                    insert(__shfl(rec.lh, src), __shfl(rec.flux, src), __shfl(rec.cand, src), __shfl(rec.obs_count, src));
+                }
+                const bool suspect = last_cand >= 0 && last_lh > tail_before && last_lh == tail;
+                if (suspect) {
+                    // (merge_fold_pixel) a dropped candidate may tie with the last slot: the state goes back, the slice comes
+                    // from the stack instead
+                    wave_fence();
+                    if (lane < K) list[lane] = saved;
+                    wave_fence();
+                    tail = tail_before;
+                }
+                if (lane == 0) *decision = suspect ? 1 : 0;
+            }
+            __syncthreads();
+            const bool again = *decision != 0;
+            __syncthreads();
+            if (again) evaluate_range((uint64_t)rl.begin[r], (uint64_t)rl.begin[r + 1]);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        wave_fence();
+        for (int s = lane; s < K; s += WAVE) {
+            kb_trajectory res = placeholder_result(x, y);
+            const kb_compact_result rec = list[s];
+            if (rec.cand >= 0) {
+                res.vx = cands[rec.cand].vx;
+                res.vy = cands[rec.cand].vy;
+                res.lh = rec.lh;
+                res.flux = rec.flux;
+                res.obs_count = rec.obs_count;
+            }
+            out[(uint64_t)pix * (uint64_t)K + s] = res;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1575,6 +1940,114 @@ int kb_merge_compact_exact(const kb_compact_result* lists_dev, int32_t n_lists, 
     hipLaunchKernelGGL(kb_merge_compact_exact_kernel, dim3((unsigned)((n_pixels + 63) / 64)), dim3(64), 0, stream, lists_dev,
                        n_lists, n_pixels, (int)list_len, K, (int)sw, params.x_start_min, params.y_start_min, all_cands_dev,
                        n_all_cands, out_dev);
+    KB_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int kb_merge_compact_repairable(const kb_compact_result* lists_dev, int32_t n_lists, kb_search_params params,
+                                const kb_trajectory* all_cands_dev, uint64_t n_all_cands, kb_trajectory* out_dev,
+                                uint32_t* hazard_idx_dev, uint64_t* n_hazard_host, void* stream_v) {
+    using namespace kb;
+    if (n_hazard_host == nullptr) return fail("merge_compact_repairable: null count pointer");
+    *n_hazard_host = 0;
+    if (lists_dev == nullptr || out_dev == nullptr || all_cands_dev == nullptr || hazard_idx_dev == nullptr) {
+        return fail("merge_compact_repairable: null pointer");
+    }
+    if (n_lists <= 0 || n_lists > MERGE_MAX_LISTS) return fail("merge_compact_repairable: unsupported number of lists");
+    const int64_t sw = (int64_t)params.x_start_max - params.x_start_min;
+    const int64_t sh = (int64_t)params.y_start_max - params.y_start_min;
+    const int K = (int)params.results_per_pixel;
+    if (sw <= 0 || sh <= 0) return fail("merge_compact_repairable: invalid search bounds");
+    if (K <= 0 || K > MERGE_EXACT_MAX_K2) return fail("merge_compact_repairable: lists of 1 to 32 records per pixel");
+    const uint64_t n_pixels = (uint64_t)sw * (uint64_t)sh;
+    if (n_pixels > 0xffffffffull) return fail("merge_compact_repairable: more than 2^32 start pixels");
+    KB_REQUIRE_DEVICE("the list merge.");
+    (void)hipGetLastError();
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    // (the hazard counter: eight bytes per device, allocated once -- an allocation and a release per call were 0.5 of the
+    // 0.7 ms this entry point took)
+    static std::mutex counter_mutex;
+    static unsigned long long* counters[MAX_DEVICES] = {};
+    unsigned long long* counter = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(counter_mutex);
+        const int slot = current_device_slot();
+        if (counters[slot] == nullptr) KB_HIP_TRY(hipMalloc(&counters[slot], sizeof(unsigned long long)));
+        counter = counters[slot];
+    }
+    int rc = 0;
+    unsigned long long n_hazard = 0;
+    if (hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream) != hipSuccess) rc = fail("merge_compact_repairable: memset failed");
+    if (rc == 0) {
+        const dim3 grid((unsigned)((n_pixels + 255) / 256));
+#define KB_LAUNCH_MERGE(KT)                                                                                                     \
+    hipLaunchKernelGGL(kb_merge_compact_repairable_kernel<KT>, grid, dim3(256), 0, stream, lists_dev, n_lists, n_pixels, K,     \
+                       (int)sw, params.x_start_min, params.y_start_min, all_cands_dev, n_all_cands, out_dev, hazard_idx_dev, counter)
+        switch (K) {
+            case 1: KB_LAUNCH_MERGE(1); break;
+            case 2: KB_LAUNCH_MERGE(2); break;
+            case 3: KB_LAUNCH_MERGE(3); break;
+            case 4: KB_LAUNCH_MERGE(4); break;
+            case 5: KB_LAUNCH_MERGE(5); break;
+            case 6: KB_LAUNCH_MERGE(6); break;
+            case 7: KB_LAUNCH_MERGE(7); break;
+            case 8: KB_LAUNCH_MERGE(8); break;
+            default: KB_LAUNCH_MERGE(0); break;
+        }
+#undef KB_LAUNCH_MERGE
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(&n_hazard, counter, sizeof(n_hazard), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) {
+            rc = fail("merge_compact_repairable: launch failed");
+        }
+    }
+    *n_hazard_host = n_hazard;
+    return rc;
+}
+
+int kb_repair_pixels(const kb_psi_phi_meta* meta, const void* psi_phi_dev, const double* times_dev, kb_search_params params,
+                     const kb_trajectory* all_cands_dev, uint64_t n_all_cands, const uint32_t* pixel_idx_dev,
+                     uint64_t n_listed, const kb_compact_result* lists_dev, int32_t n_lists, const int32_t* list_cand_begin_host,
+                     kb_trajectory* out_dev, void* stream_v) {
+    using namespace kb;
+    if (n_listed == 0) return 0;
+    if (meta == nullptr || psi_phi_dev == nullptr || times_dev == nullptr || all_cands_dev == nullptr || pixel_idx_dev == nullptr ||
+        out_dev == nullptr) {
+        return fail("repair_pixels: null pointer");
+    }
+    if (meta->num_times == 0 || meta->num_times > KB_MAX_NUM_IMAGES) return fail("repair_pixels: unsupported number of images");
+    if (params.do_sigmag_filter) return fail("repair_pixels: the in-search sigma-G filter is not covered (exchange stable lists of 2 K)");
+    const int64_t sw = (int64_t)params.x_start_max - params.x_start_min;
+    const int64_t sh = (int64_t)params.y_start_max - params.y_start_min;
+    const int K = (int)params.results_per_pixel;
+    if (sw <= 0 || sh <= 0 || K <= 0 || K > MERGE_EXACT_MAX_K2) return fail("repair_pixels: invalid bounds or list length");
+    RepairLists rl{};
+    rl.lists = nullptr;
+    if (lists_dev != nullptr && list_cand_begin_host != nullptr && n_lists > 0 && n_lists <= REPAIR_MAX_LISTS) {
+        bool ascending = list_cand_begin_host[0] == 0 && (uint64_t)list_cand_begin_host[n_lists] == n_all_cands;
+        for (int r = 0; r < n_lists; ++r) ascending = ascending && list_cand_begin_host[r] <= list_cand_begin_host[r + 1];
+        if (!ascending) return fail("repair_pixels: the lists' candidate ranges must tile [0, n_all_cands) in ascending order");
+        rl.lists = lists_dev;
+        rl.n_pixels = (uint64_t)sw * (uint64_t)sh;
+        rl.n_lists = n_lists;
+        for (int r = 0; r <= n_lists; ++r) rl.begin[r] = list_cand_begin_host[r];
+    }
+    KB_REQUIRE_DEVICE("the pixel repair.");
+    (void)hipGetLastError();
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (n_listed > 0x7fffffffull) return fail("repair_pixels: too many pixels listed");
+    const unsigned blocks = (unsigned)n_listed;  // one workgroup per pixel
+    const size_t lds = (size_t)REPAIR_WAVES * WAVE * sizeof(RepairEval) + (size_t)K * sizeof(kb_compact_result) + 16;
+    if (meta->num_bytes == 1) {
+        hipLaunchKernelGGL(kb_repair_pixels_kernel<1>, dim3(blocks), dim3(REPAIR_WAVES * WAVE), lds, stream, *meta, psi_phi_dev,
+                           times_dev, params, all_cands_dev, n_all_cands, pixel_idx_dev, n_listed, rl, out_dev);
+    } else if (meta->num_bytes == 2) {
+        hipLaunchKernelGGL(kb_repair_pixels_kernel<2>, dim3(blocks), dim3(REPAIR_WAVES * WAVE), lds, stream, *meta, psi_phi_dev,
+                           times_dev, params, all_cands_dev, n_all_cands, pixel_idx_dev, n_listed, rl, out_dev);
+    } else {
+        hipLaunchKernelGGL(kb_repair_pixels_kernel<4>, dim3(blocks), dim3(REPAIR_WAVES * WAVE), lds, stream, *meta, psi_phi_dev,
+                           times_dev, params, all_cands_dev, n_all_cands, pixel_idx_dev, n_listed, rl, out_dev);
+    }
     KB_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -400,119 +400,64 @@ KB_HD int merge_exact_pixel(const ReadRecord& read, int n_lists, int K2, int K, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The exchange with K records per device (kb_merge_compact_repairable and its host twin; round 6).  Every list is what
-// the reference's insertion (kernels.cu:304-331) leaves over ITS slice of the candidates -- K slots, likelihoods
-// non-increasing, runs of equal values in whatever order the rotations left them -- and no device pays for stable lists of
-// 2 K.  With v = the pixel's K-th largest likelihood over the union (every one of the K largest values is in its device's
-// list, so v is the true one) the final list is, as above, the reference's insertion over
-//     G = { candidates with lh > v }  +  { the first K candidates, by index, with lh == v }
-// in candidate order, and the lists hold ALL of G unless one of them may have DROPPED a member of it: a list that is not
-// full holds every candidate its device let through; a full list whose last likelihood is below v holds every candidate
-// of its slice at or above v (the insertion loses values only at a list's own last value).  What remains is a full list
-// that ends AT v -- candidates equal to v may have fallen off it, or the wrong ones of a tie may have stayed --: the
-// pixel is a HAZARD, the caller re-makes it from the stack (kb_repair_pixels).  Also a hazard: more records at or above v
-// than `merged` holds.  A full list cannot end above v (its K records would be K values above the K-th largest).
-// merged / heads / slots as for merge_exact_pixel; returns the slots filled (meaningless for a hazard).
+// The exchange with K records per device (kb_merge_compact_repairable and its host twin; round 6): a FOLD over the
+// devices in candidate order.  Device r searched the candidates [begin_r, begin_{r+1}) of the job-wide list -- the slices
+// tile the list in ascending order -- and its list L_r is what the reference's insertion (kernels.cu:304-331) leaves over
+// that slice alone: K slots, likelihoods non-increasing, runs of equal values in whatever order the rotations left them.
+//   * The reference walks the candidates in order, so after slice 0 its list IS L_0: the fold starts there, exactly.
+//   * Slice r >= 1 is then inserted into that state.  Of its candidates only L_r is known; the ones that fell off L_r (or
+//     never entered it) have lh <= m_r = L_r's last likelihood when L_r is full, and do not exist when it is not.  A
+//     candidate at or below the state's last likelihood moves nothing (the swaps need a strict '>'), and one that does
+//     enter sits below every entry above it and is itself pushed out again once K entries at or above m_r are in -- which
+//     L_r's own K records guarantee by the end of the slice --, disturbing on its way only entries that leave with it.  So
+//     inserting L_r's records, put back into candidate order, gives the reference's state after slice r UNLESS a dropped
+//     candidate EQUAL to m_r can both enter (m_r above the state's last likelihood before the slice) and stay (m_r is the
+//     state's last likelihood after it): then which members of that tie the reference keeps is not in the records.
+//     That slice is SUSPECT and the pixel a hazard: the caller re-makes it (kb_repair_pixels evaluates the suspect slices).
+// Nothing else can go wrong: a pixel whose candidates all tie (a start pixel at the image's edge: every trajectory leaves
+// over the same few samples) folds exactly -- L_0, and nothing after it is strictly above its last slot.
+// state / recs: caller's scratch of K entries each; returns true for a hazard (bit r of *suspects: slice r; r < 64).
 // ---------------------------------------------------------------------------------------------------------------
 template <typename ReadRecord>
-KB_HD int merge_repairable_pixel(const ReadRecord& read, int n_lists, int K, MergedEntry* merged, int* heads, int* slots,
-                                 bool* hazard) {
-    *hazard = false;
-    for (int r = 0; r < n_lists; ++r) heads[r] = 0;
-    // (1) the records at or above v, largest first: K of them, then every further one EQUAL to the K-th
-    int n = 0;
-    float v = 0.0f;
-    while (true) {
-        int best = -1;
-        float best_lh = 0.0f;
-        int best_cand = 0;
-        for (int r = 0; r < n_lists; ++r) {
-            if (heads[r] >= K) continue;
-            const kb_compact_result rec = read(r, heads[r]);
-            if (rec.cand < 0) {  // placeholders close a list
-                heads[r] = K + 1;  // (closed, not exhausted: the list was not full)
-                continue;
+KB_HD bool merge_fold_pixel(const ReadRecord& read, int n_lists, int K, kb_compact_result* state, kb_compact_result* recs,
+                            uint64_t* suspects) {
+    *suspects = 0;
+    for (int s = 0; s < K; ++s) {
+        state[s] = read(0, s);
+        if (state[s].cand < 0) state[s] = kb_compact_result{-FLT_MAX, 0.0f, -1, 0};  // kernels.cu:293-301
+    }
+    for (int r = 1; r < n_lists; ++r) {
+        const float tail_before = state[K - 1].lh;
+        const kb_compact_result last = read(r, K - 1);
+        const bool full = last.cand >= 0;
+        // the slice's records in candidate order (an insertion sort of K entries; placeholders last)
+        int n = 0;
+        for (int s = 0; s < K; ++s) {
+            const kb_compact_result rec = read(r, s);
+            if (rec.cand < 0) break;  // placeholders close a list
+            if (!(rec.lh > tail_before)) continue;  // (cannot enter now, and the state's last likelihood never falls)
+            int at = n;
+            while (at > 0 && recs[at - 1].cand > rec.cand) {
+                recs[at] = recs[at - 1];
+                at -= 1;
             }
-            if (best < 0 || rec.lh > best_lh || (rec.lh == best_lh && rec.cand < best_cand)) {
-                best = r;
-                best_lh = rec.lh;
-                best_cand = rec.cand;
-            }
+            recs[at] = rec;
+            n += 1;
         }
-        if (best < 0) break;
-        if (n >= K && !(best_lh == v)) break;  // below v: of no consequence
-        if (n >= MERGE_EXACT_MAX_K2) {         // more equal records than the scratch holds
-            *hazard = true;
-            break;
-        }
-        merged[n].lh = best_lh;
-        merged[n].cand = best_cand;
-        merged[n].at = (uint32_t)(best * K + heads[best]);
-        heads[best] += 1;
-        n += 1;
-        if (n == K) v = best_lh;
-    }
-    const bool full = n >= K;
-    // (2) a FULL list read to its end reached down to v (or, with fewer than K records in all, to the end of everything):
-    // it may have dropped what belongs here
-    if (full) {
-        for (int r = 0; r < n_lists; ++r) *hazard = *hazard || heads[r] == K;
-    }
-    const int n_out = n < K ? n : K;
-    if (*hazard) return n_out;
-    // (3) nothing equal among the records kept: the prefix is the list
-    bool strict = true;
-    for (int i = 0; i + 1 < n; ++i) strict = strict && (merged[i].lh > merged[i + 1].lh);
-    if (strict) {
-        for (int s = 0; s < n_out; ++s) slots[s] = s;
-        return n_out;
-    }
-    // (4) replay G in candidate order with the reference's insertion
-    int n_equal = 0;
-    uint32_t in_g = 0;  // bit i: merged[i] belongs to G
-    for (int pass = 0; pass < 2; ++pass) {
-        // (the first K of the records equal to v BY CANDIDATE INDEX: they sit in `merged` in (lh, cand) order only within one
-        // list's run -- count them in index order)
-        if (pass == 0) {
-            for (int i = 0; i < n; ++i) {
-                if (!full || merged[i].lh > v) in_g |= 1u << i;
-            }
-        } else if (full) {
-            uint32_t equal = 0;
-            for (int i = 0; i < n; ++i) {
-                if (merged[i].lh == v) equal |= 1u << i;
-            }
-            while (equal != 0u && n_equal < K) {
-                int pick = -1;
-                for (int i = 0; i < n; ++i) {
-                    if (((equal >> i) & 1u) && (pick < 0 || merged[i].cand < merged[pick].cand)) pick = i;
-                }
-                equal &= ~(1u << pick);
-                in_g |= 1u << pick;
-                n_equal += 1;
-            }
-        }
-    }
-    int filled = 0;
-    for (int s = 0; s < K; ++s) slots[s] = -1;
-    while (in_g != 0u) {
-        int pick = -1;
         for (int i = 0; i < n; ++i) {
-            if (((in_g >> i) & 1u) && (pick < 0 || merged[i].cand < merged[pick].cand)) pick = i;
-        }
-        in_g &= ~(1u << pick);
-        int cur = pick;
-        for (int s = 0; s < K; ++s) {  // kernels.cu:323-330: strict '>' against a slot, an empty slot loses
-            if (slots[s] < 0 || merged[cur].lh > merged[slots[s]].lh) {
-                const int t = slots[s];
-                slots[s] = cur;
-                cur = t;
-                if (cur < 0) break;
+            kb_compact_result in = recs[i];
+            for (int s = 0; s < K; ++s) {  // kernels.cu:323-330
+                if (in.lh > state[s].lh) {
+                    const kb_compact_result t = state[s];
+                    state[s] = in;
+                    in = t;
+                    if (in.cand < 0) break;  // (a displaced placeholder moves nothing further)
+                }
             }
         }
-        if (filled < K) filled += 1;
+        if (full && last.lh > tail_before && last.lh == state[K - 1].lh && r < 64) *suspects |= 1ull << r;
     }
-    return filled < n_out ? filled : n_out;
+    return *suspects != 0ull;
 }
 
 

@@ -34,6 +34,12 @@ Two forms of the exchange:
 * **plain** (``list_len = K``): per-rank lists as the single-GPU search builds them, ties
   to the lower candidate index: the same likelihoods in the same slots as a single-GPU
   search, possibly another member of a tie.  Half the records on the wire.
+* **K records + repair** (``list_len = K`` with ``repair_stack``; round 6): the same wire and the same per-rank search as
+  the plain form -- every rank runs the fastest single-GPU instance on its slice, no stable lists of 2 K --, and the result
+  of the tie-exact form.  The root's merge (``kb_merge_compact_repairable``) decides every pixel whose lists determine its
+  final list and names the others: a FULL list that ends at the pixel's K-th likelihood may have dropped a candidate that
+  ties with it.  Those pixels (a fraction of a percent on the BASELINE grids) are searched again over the whole candidate
+  list on the root, one wavefront per pixel (``kb_repair_pixels``: psi/phi is replicated, the root has it).
 
 And one way of putting either on the wire:
 
@@ -182,6 +188,107 @@ def merge_compact_exact(gathered, x_bounds, y_bounds, K, list_len, all_cands, ou
         res = kb.merge_compact_exact_host(raw, world, int(list_len), K, int(x_bounds[0]), int(x_bounds[1]),
                                           int(y_bounds[0]), int(y_bounds[1]), cands)
         out.copy_(torch.from_numpy(res.view(np.float32).reshape(out.shape)))
+    return out
+
+
+_last_repair = None
+
+
+def last_repair():
+    """{"hazards": pixels the last repairable merge of this process could not decide, "pixels": all of them} or None."""
+    return _last_repair
+
+
+def merge_compact_repair(gathered, x_bounds, y_bounds, K, all_cands, stack, out=None, min_obs=0, hazard_buf=None,
+                         list_begin=None):
+    """The merge of the exchange with K records per rank: ``gathered`` = [world, S*K, 4] per-rank lists, each the
+    reference's insertion over that rank's slice (``kb_device_search_compact`` with ``list_len = K``, no flag 512, no list
+    floor) -> [S*K, 7] trajectories equal to the single-device search on the whole candidate list.  Pixels the lists do
+    not decide are re-made from the stack: ``stack`` = ``(meta, psi_phi_ptr, times_ptr)`` of the root's replica for
+    device tensors (capi.Meta, two device addresses: ``kb_repair_pixels``); for CPU tensors (the gloo tests) a callable
+    ``stack(x, y, vx, vy) -> (lh, flux, obs_count)``, the evaluation of one trajectory, driven through the reference's
+    insertion here.  ``hazard_buf``: an int32/uint32 device tensor of S entries to reuse between calls.  ``list_begin``:
+    world + 1 candidate indices, list r = the candidates [list_begin[r], list_begin[r + 1]) of ``all_cands`` (ascending,
+    tiling the whole list: ``shard_bounds``) -- the repair then evaluates only the slices of the lists that may have dropped
+    something (same result, ``world`` times fewer evaluations); None: every candidate."""
+    global _last_repair
+    import torch
+
+    _check_exchange_tensors(gathered, all_cands)
+    world = gathered.shape[0]
+    n_pixels = _n_pixels(x_bounds, y_bounds)
+    K = int(K)
+    if gathered.shape[1] != n_pixels * K:
+        raise ValueError(f"gathered holds {gathered.shape[1]} records per list, the bounds say {n_pixels} pixels x {K}")
+    if out is None:
+        out = torch.empty((n_pixels * K, TRJ_FLOATS), dtype=torch.float32, device=gathered.device)
+    _check_out(out, n_pixels, K, gathered.device)
+    params = _bounds(x_bounds, y_bounds, K)
+    params.min_observations = int(min_obs)
+    if gathered.is_cuda:
+        import ctypes as C
+
+        lib = device_lib()
+        stream = torch.cuda.current_stream().cuda_stream
+        if hazard_buf is None:
+            hazard_buf = torch.empty(n_pixels, dtype=torch.int32, device=gathered.device)
+        if hazard_buf.numel() < n_pixels or hazard_buf.element_size() != 4 or hazard_buf.device != gathered.device:
+            raise ValueError("hazard_buf: expected a 4-byte integer tensor of at least S entries on the lists' device")
+        n_hazard = C.c_uint64(0)
+        with _MergeTimer(True):
+            rc = lib.kb_merge_compact_repairable(gathered.data_ptr(), world, params, all_cands.data_ptr(), all_cands.shape[0],
+                                                 out.data_ptr(), hazard_buf.data_ptr(), C.byref(n_hazard), stream)
+            if rc == 0 and n_hazard.value:
+                if stack is None or callable(stack):
+                    raise ValueError("merge_compact_repair: device lists need stack = (meta, psi_phi_ptr, times_ptr) for the repair")
+                meta, psi_phi_ptr, times_ptr = stack
+                begin = None
+                if list_begin is not None:
+                    if len(list_begin) != world + 1:
+                        raise ValueError("list_begin: expected world + 1 candidate indices")
+                    begin = (C.c_int32 * (world + 1))(*[int(b) for b in list_begin])
+                rc = lib.kb_repair_pixels(C.byref(meta), C.c_void_p(int(psi_phi_ptr)), C.c_void_p(int(times_ptr)), params,
+                                          all_cands.data_ptr(), all_cands.shape[0], hazard_buf.data_ptr(), n_hazard.value,
+                                          gathered.data_ptr() if begin is not None else None, world, begin, out.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError(lib.kb_last_error().decode())
+        _last_repair = {"hazards": int(n_hazard.value), "pixels": n_pixels}
+    else:
+        import kbmod_amd.search as kb
+
+        vel = all_cands.numpy()
+        cands = [kb.Trajectory(vx=float(v[0]), vy=float(v[1])) for v in vel]
+        raw = np.ascontiguousarray(gathered.numpy()).view(np.uint8).reshape(-1)
+        res, hazards = kb.merge_compact_repairable_host(raw, world, K, int(x_bounds[0]), int(x_bounds[1]), int(y_bounds[0]),
+                                                        int(y_bounds[1]), cands)
+        rows = np.array(res.view(np.float32).reshape(n_pixels * K, TRJ_FLOATS))
+        if len(hazards):
+            if not callable(stack):
+                raise ValueError("merge_compact_repair: CPU lists need stack = callable(x, y, vx, vy) -> (lh, flux, obs_count)")
+            sw = int(x_bounds[1]) - int(x_bounds[0])
+            words = rows.view(np.int32)
+            for pix in hazards:
+                y_i, x_i = divmod(int(pix), sw)
+                x, y = x_i + int(x_bounds[0]), y_i + int(y_bounds[0])
+                slots = [(np.float32(-3.4028234663852886e38), 0.0, -1, 0)] * K  # kernels.cu:293-301
+                for c in range(len(vel)):
+                    lh, flux, obs = stack(x, y, float(vel[c, 0]), float(vel[c, 1]))
+                    if obs < int(min_obs):
+                        continue
+                    cur = (np.float32(lh), np.float32(flux), c, int(obs))
+                    for s in range(K):  # kernels.cu:323-330
+                        if cur[0] > slots[s][0]:
+                            cur, slots[s] = slots[s], cur
+                for s, (lh, flux, c, obs) in enumerate(slots):
+                    row = int(pix) * K + s
+                    rows[row] = 0.0
+                    words[row, 4], words[row, 5] = x, y
+                    rows[row, 2] = lh
+                    if c >= 0:
+                        rows[row, 0], rows[row, 1], rows[row, 3] = vel[c, 0], vel[c, 1], flux
+                        words[row, 6] = obs
+        out.copy_(torch.from_numpy(rows))
+        _last_repair = {"hazards": int(len(hazards)), "pixels": n_pixels}
     return out
 
 
@@ -411,11 +518,21 @@ def _is_root(dst, group):
     return dist.get_rank() == dst
 
 
+def _merge_gathered(gathered, x_bounds, y_bounds, K, list_len, all_cands, out, repair_stack, min_obs, list_begin=None):
+    if list_len is None or int(list_len) == int(K):
+        if repair_stack is not None:
+            return merge_compact_repair(gathered, x_bounds, y_bounds, K, all_cands, repair_stack, out, min_obs,
+                                        list_begin=list_begin)
+        return merge_compact(gathered, x_bounds, y_bounds, K, all_cands, out)
+    return merge_compact_exact(gathered, x_bounds, y_bounds, K, list_len, all_cands, out)
+
+
 def gather_and_merge_compact(local_records, x_bounds, y_bounds, K, all_cands, group=None, gathered=None, out=None,
-                             dst=0, list_len=None):
+                             dst=0, list_len=None, repair_stack=None, min_obs=0, list_begin=None):
     """The multi-GPU exchange step: ONE gather of the per-rank compact record lists to global rank ``dst`` + the
     per-pixel merge there.  ``local_records``: [S*list_len, 4] int32 tensor on the rank's device; ``list_len`` = 2 K
-    (lists built with flag 512) selects the tie-exact merge, None / K the plain one.  Returns the merged [S*K, 7]
+    (lists built with flag 512) selects the tie-exact merge, None / K the plain one -- or, with ``repair_stack`` (see
+    ``merge_compact_repair``), the merge that re-makes the pixels K records do not decide.  Returns the merged [S*K, 7]
     float32 trajectories on rank ``dst`` and **None on every other rank**."""
     import torch
     import torch.distributed as dist
@@ -437,9 +554,7 @@ def gather_and_merge_compact(local_records, x_bounds, y_bounds, K, all_cands, gr
         gathered.copy_(staged)
     else:
         dist.gather(send, [gathered[r] for r in range(world)], dst=dst, group=group)
-    if list_len is None or int(list_len) == int(K):
-        return merge_compact(gathered, x_bounds, y_bounds, K, all_cands, out)
-    return merge_compact_exact(gathered, x_bounds, y_bounds, K, list_len, all_cands, out)
+    return _merge_gathered(gathered, x_bounds, y_bounds, K, list_len, all_cands, out, repair_stack, min_obs, list_begin)
 
 
 class ExchangeInFlight:
@@ -462,14 +577,12 @@ class ExchangeInFlight:
             return None
         if self._staged is not None:
             self._gathered.copy_(self._staged)
-        x_bounds, y_bounds, K, list_len, all_cands, out = self._merge_args
-        if list_len is None or int(list_len) == int(K):
-            return merge_compact(self._gathered, x_bounds, y_bounds, K, all_cands, out)
-        return merge_compact_exact(self._gathered, x_bounds, y_bounds, K, list_len, all_cands, out)
+        x_bounds, y_bounds, K, list_len, all_cands, out, repair_stack, min_obs, list_begin = self._merge_args
+        return _merge_gathered(self._gathered, x_bounds, y_bounds, K, list_len, all_cands, out, repair_stack, min_obs, list_begin)
 
 
 def start_gather_compact(local_records, x_bounds, y_bounds, K, all_cands, group=None, gathered=None, out=None, dst=0,
-                         list_len=None):
+                         list_len=None, repair_stack=None, min_obs=0, list_begin=None):
     """The exchange of ``gather_and_merge_compact`` in two halves: starts the ONE gather (asynchronously) and returns an
     ``ExchangeInFlight`` whose ``finish()`` completes it and merges on global rank ``dst`` (None elsewhere)."""
     import torch
@@ -479,7 +592,7 @@ def start_gather_compact(local_records, x_bounds, y_bounds, K, all_cands, group=
     local_records = local_records.contiguous()
     via_host = local_records.is_cuda and dist.get_backend(group) != "nccl"
     send = local_records.cpu() if via_host else local_records
-    merge_args = (x_bounds, y_bounds, K, list_len, all_cands, out)
+    merge_args = (x_bounds, y_bounds, K, list_len, all_cands, out, repair_stack, min_obs, list_begin)
     if not _is_root(dst, group):
         work = dist.gather(send, None, dst=dst, group=group, async_op=True)
         return ExchangeInFlight(work, None, None, merge_args, False, send)

@@ -93,6 +93,60 @@ def _exact_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _repair_worker(rank, world, port, out_dir):
+    """The exchange with K records per rank (round 6): every rank's list is the reference's insertion over ITS slice -- the
+    oracle's kernel-semantics search with results_per_pixel = K --, rank 0 folds the lists in candidate order with
+    kb_merge_compact_repairable's host twin and re-makes the pixels the records do not decide (the evaluator is the oracle's
+    here; on devices kb_repair_pixels)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kbmod_amd import distributed as kdist
+        from kbmod_amd import fake_data as fd
+        from oracle import oracle as orc
+        from tests import util
+
+        K, S = 4, 24 * 40
+        st = util.make_stack(12, 24, 40, seed=21, objects=[(8, 6, 14.0, 9.0, 200.0)], mask_fraction=0.02)
+        vx, vy = fd.kbmod_v1_candidates(7, 1.0, 40.0, 5, 0.0, 1.5)  # 35 candidates: uneven split, slow ones that coincide
+        pp = orc.PsiPhi.from_images(st.sci, st.var, st.psfs, st.zeroed_times)
+        lo, hi = kdist.shard_bounds(len(vx), rank, world)
+        mine = pp.search_kernel_semantics(orc.make_candidates(vx[lo:hi], vy[lo:hi]), pp.default_params(results_per_pixel=K))
+        index = {(float(a), float(b)): i for i, (a, b) in enumerate(zip(vx, vy))}
+        rec = np.zeros(S * K, dtype=[("lh", "<f4"), ("flux", "<f4"), ("cand", "<i4"), ("obs_count", "<i4")])
+        empty = mine["lh"] == np.float32(-3.4028234663852886e38)
+        rec["lh"], rec["flux"], rec["obs_count"] = mine["lh"], mine["flux"], mine["obs_count"]
+        rec["cand"] = [-1 if e else index[(float(a), float(b))] for e, a, b in zip(empty, mine["vx"], mine["vy"])]
+        local_t = torch.from_numpy(rec.view(np.int32).reshape(S * K, 4).copy())
+        all_np = np.zeros((len(vx), 7), dtype=np.float32)
+        all_np[:, 0], all_np[:, 1] = vx, vy
+        all_cands = torch.from_numpy(all_np)
+        params = pp.default_params(results_per_pixel=K)
+
+        def evaluate(x, y, cvx, cvy):
+            t = pp.evaluate_kernel(x, y, cvx, cvy, params)
+            return float(t["lh"]), float(t["flux"]), int(t["obs_count"])
+
+        begin = [kdist.shard_bounds(len(vx), r, world)[0] for r in range(world)] + [len(vx)]
+        if world == 3:
+            flight = kdist.start_gather_compact(local_t, (0, 40), (0, 24), K, all_cands, list_len=K, repair_stack=evaluate,
+                                                list_begin=begin)
+            merged = flight.finish()
+        else:
+            merged = kdist.gather_and_merge_compact(local_t, (0, 40), (0, 24), K, all_cands, list_len=K, repair_stack=evaluate,
+                                                    list_begin=begin)
+        assert (merged is None) == (rank != 0)
+        if rank == 0:
+            full = pp.search_kernel_semantics(orc.make_candidates(vx, vy), pp.default_params(results_per_pixel=K))
+            np.save(os.path.join(out_dir, "got.npy"), merged.numpy().reshape(-1).view(orc.TRJ_DTYPE))
+            np.save(os.path.join(out_dir, "full.npy"), full)
+            np.save(os.path.join(out_dir, "hazards.npy"), np.array([kdist.last_repair()["hazards"]]))
+    finally:
+        dist.destroy_process_group()
+
+
 def _sparse_worker(rank, world, port, out_dir, min_lh):
     """The sparse form of the tie-exact exchange (kbmod_amd.distributed.gather_and_merge_sparse): one count byte per pixel
     + the records that pass min_lh, one gather of the headers, one message per rank with records, merge on rank 0."""
@@ -236,6 +290,17 @@ def test_tie_exact_gather_and_merge(tmp_path, orc, kb, world):
     assert got.tobytes() == full.tobytes()  # every field of every slot, ties included
     more = np.load(tmp_path / "more_lh.npy")
     assert ((more[:, :-1] == more[:, 1:]) & (more[:, :-1] > np.float32(-3.0e38))).any()  # and there were ties to get right
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_k_record_exchange_with_repair(tmp_path, orc, kb, world):
+    """The ranks' NORMAL K-record lists (no stable lists of 2 K) folded in candidate order, hazards re-made: the unsharded
+    search, every field of every slot, ties included -- over gloo, world 2 and 3 (3: the exchange in two halves)."""
+    mp.spawn(_repair_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "got.npy")
+    full = np.load(tmp_path / "full.npy")
+    assert got.tobytes() == full.tobytes()
+    assert np.load(tmp_path / "hazards.npy")[0] < len(full) // 4 // 2  # most pixels are decided by the records alone
 
 
 @pytest.mark.parametrize("world,min_lh", [(2, 6.0), (3, 2.5), (2, None)])

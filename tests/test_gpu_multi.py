@@ -142,6 +142,81 @@ def test_tie_exact_sharded_search_equals_unsharded(kb, ds, grid, world, cfg):
     assert ((e[:, :-1] == e[:, 1:]) & (e[:, :-1] != EMPTY)).any()
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("cfg", [dict(K=8), dict(K=3, min_obs=5), dict(K=16), dict(K=1)])
+@pytest.mark.parametrize("num_bytes", [-1, 2])
+def test_k_record_exchange_with_repair_equals_unsharded(kb, ds, grid, world, cfg, num_bytes):
+    """The exchange with K records per rank (round 6): every slice searched with its NORMAL lists -- the reference's
+    insertion, no flag 512 --, merged by kb_merge_compact_repairable, the pixels the records do not decide re-made by
+    kb_repair_pixels: the result IS the unsharded search, field for field, at every pixel (ties included: the border pixels
+    of this stack tie among their K + 1 best, see the test above).  The merge kernel names the same hazards as its host twin."""
+    from kbmod_amd import distributed as kdist
+
+    d = ds if num_bytes == -1 else util.DeviceStack(util.make_stack(20, 60, 100, seed=100, noise=4.0, psf=1.0, objects=OBJ,
+                                                                    mask_fraction=0.01), num_bytes)
+    try:
+        vx, vy = grid
+        all_cands = d.candidates(vx, vy)
+        p = d.params(**cfg)
+        K = p.results_per_pixel
+        parts = []
+        for r in range(world):
+            lo, hi = kdist.shard_bounds(len(vx), r, world)
+            rec, _ = d.search_compact(p, all_cands[lo:hi], lo, 0)
+            parts.append(rec)
+        gathered = d.torch.stack(parts)
+        stack = (d.meta, d.arr.value, d.times.data_ptr())
+        merged = kdist.merge_compact_repair(gathered, (0, d.W), (0, d.H), K, all_cands, stack, min_obs=p.min_observations)
+        d.torch.cuda.synchronize()
+        hazards = kdist.last_repair()["hazards"]
+        full, _ = d.search(p, all_cands, 0)
+        assert d.torch.equal(merged.view(d.torch.int32), full.view(d.torch.int32))
+        # ... and with the repair told which candidates each list covers (only the suspect slices are evaluated again)
+        begin = [kdist.shard_bounds(len(vx), r, world)[0] for r in range(world)] + [len(vx)]
+        again = kdist.merge_compact_repair(gathered, (0, d.W), (0, d.H), K, all_cands, stack, min_obs=p.min_observations,
+                                           list_begin=begin)
+        d.torch.cuda.synchronize()
+        assert kdist.last_repair()["hazards"] == hazards
+        assert d.torch.equal(again.view(d.torch.int32), full.view(d.torch.int32))
+        # the host twin names the same pixels, and agrees wherever the lists decide
+        raw = np.ascontiguousarray(gathered.cpu().numpy()).view(np.uint8).reshape(-1)
+        cands = [kb.Trajectory(vx=float(a), vy=float(b)) for a, b in zip(vx, vy)]
+        host, hz = kb.merge_compact_repairable_host(raw, world, K, 0, d.W, 0, d.H, cands)
+        assert len(hz) == hazards
+        decided = np.ones(d.W * d.H, dtype=bool)
+        decided[np.asarray(hz, dtype=np.int64)] = False
+        got = merged.cpu().numpy().view(np.int32).reshape(d.W * d.H, K * 7)
+        want = np.asarray(host).view(np.int32).reshape(d.W * d.H, K * 7)
+        assert np.array_equal(got[decided], want[decided])
+        if world == 1:
+            assert hazards == 0  # one list IS the answer
+    finally:
+        if d is not ds:
+            d.close()
+
+
+def test_repair_pixels_alone_is_the_search(ds, grid):
+    """kb_repair_pixels over EVERY pixel of a sub-area == kb_device_search_filter (the batched evaluator has the bits of
+    evaluate_trajectory_full and the wave-ordered insertion is the reference's)."""
+    import ctypes as C
+
+    from kbmod_amd import capi
+
+    vx, vy = grid
+    all_cands = ds.candidates(vx, vy)
+    for cfg in (dict(K=8), dict(K=5, min_obs=12), dict(K=32)):
+        p = ds.params(**cfg, xb=(-3, 70), yb=(2, 40))
+        K = p.results_per_pixel
+        S = 73 * 38
+        full, _ = ds.search(p, all_cands, 0)
+        out = ds.torch.full((S * K, 7), float("nan"), dtype=ds.torch.float32, device="cuda")
+        pixels = ds.torch.arange(S, dtype=ds.torch.int32, device="cuda")
+        capi.check(ds.lib.kb_repair_pixels(C.byref(ds.meta), ds.arr, ds.times.data_ptr(), p, all_cands.data_ptr(), len(vx),
+                                           pixels.data_ptr(), S, None, 0, None, out.data_ptr(), ds.stream))
+        ds.torch.cuda.synchronize()
+        assert ds.torch.equal(out.view(ds.torch.int32), full.view(ds.torch.int32)), cfg
+
+
 def test_stable_lists_are_the_top_by_likelihood_then_candidate(ds, grid):
     """Flag 512 alone: the per-pixel list is the first K of the candidates ordered by (likelihood descending, index
     ascending) -- checked against a list long enough to hold every candidate."""
