@@ -44,7 +44,10 @@ constexpr int LDS_ROWS_WIDE_K = 8; // kb_search_lds, 8 < K <= 32; also small sea
 constexpr int TILE_GROUP_ROWS = KB_TILE_GROUP_ROWS;  // tile rows walked together by an XCD (tile_coords)
 __host__ __device__ constexpr int block_threads(int rows) { return rows * WAVE; }
 __host__ __device__ constexpr int stage_round(int rows) { return rows * WAVE * 16; }  // bytes one staging round moves
-__host__ __device__ constexpr int lds_group_bytes(int rows) { return 5120 * rows; }   // one of the two group buffers
+#ifndef KB_LDS_GROUP_PER_ROW
+#define KB_LDS_GROUP_PER_ROW 5120
+#endif
+__host__ __device__ constexpr int lds_group_bytes(int rows) { return KB_LDS_GROUP_PER_ROW * rows; }   // one of the two group buffers
 // Epochs per group: as many slabs of `stride` bytes as a group buffer holds.  The hand-scheduled instances (search_lds_asm.h)
 // take an even number when there are two or more: their run of whole groups works in pairs of epochs.
 __host__ __device__ inline int group_epochs(int T, int rows, int stride, bool even) {

@@ -1,0 +1,11 @@
+# usage: ab2.sh "libs" [bench args]; prints ms_per_step kernel_ms kernel
+LIBS="$1"; shift
+for rep in 1 2; do for l in $LIBS; do
+  if [ "$l" = main ]; then unset KBMOD_HIP_LIB; else export KBMOD_HIP_LIB=tools/probe_bin/libkbmod_$l.so; fi
+  timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --no-masked "$@" 2>/dev/null | python -c "
+import sys,json
+for line in sys.stdin:
+    if line.startswith('{'):
+        d=json.loads(line); print('$l', round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],3), d['roofline']['kernel'][-28:])
+"
+done; done
