@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's profile set (run on the GPU box): tools/profile_all.sh r05
-R=${1:-r05}
+R=${1:-r06}
 tools/profile_round.sh ${R}_f32
 tools/profile_round.sh ${R}_cfg3 --num-bytes 1 --sigmag
 STEPS=3 WARMUP=1 tools/profile_round.sh ${R}_cfg4 --frames 128 --size 4096 --vel-steps 32 --ang-steps 2
@@ -31,6 +31,11 @@ python tools/exchange_budget.py --counted > gpurun_out/${R}_exchange_budget_cfg4
 python tools/exchange_budget.py --frames 64 --size 512 --vel-steps 32 --ang-steps 32 --counted > gpurun_out/${R}_exchange_budget_cfg2_lh10_counted.json 2>/dev/null
 python tools/exchange_budget.py --rank-flags 0 > gpurun_out/${R}_exchange_budget_cfg4_nofloor.json 2>/dev/null
 python tools/exchange_budget.py --frames 64 --size 512 --vel-steps 32 --ang-steps 32 --dense > gpurun_out/${R}_exchange_budget_cfg2_lh10.json 2>/dev/null
+# round 6: the dense exchange with K records per rank + repair, against the 2 K stable lists (8 ranks played on this GPU)
+python tools/exchange_repair_budget.py --ang-steps 32 > gpurun_out/${R}_exchange_repair_cfg2_1024_per_rank.json 2>/dev/null
+python tools/exchange_repair_budget.py --ang-steps 4 > gpurun_out/${R}_exchange_repair_cfg2_128_per_rank.json 2>/dev/null
+python tools/exchange_repair_budget.py --frames 128 --size 4096 --vel-steps 32 --ang-steps 2 --reps 3 > gpurun_out/${R}_exchange_repair_cfg4.json 2>/dev/null
+python tools/cold_start_timing.py > gpurun_out/${R}_cold_start_timing.log 2>&1
 KBMOD_FORCE_DIST=1 python bench.py --gpus 1 --frames 128 --size 4096 --vel-steps 32 --ang-steps 2 --min-lh 10 --steps 5 --verify --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${R}_cfg4_rccl_world1_bench_line.json
 KBMOD_FORCE_DIST=1 python bench.py --gpus 1 --steps 10 --verify --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${R}_cfg2_rccl_world1_bench_line.json
 (cd tools/ubench && ./ubench) > gpurun_out/${R}_ubench_issue_model.log 2>&1
