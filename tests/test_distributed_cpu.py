@@ -89,6 +89,7 @@ def _exact_worker(rank, world, port, out_dir):
             np.save(os.path.join(out_dir, "full.npy"), full)
             more = pp.search_kernel_semantics(orc.make_candidates(vx, vy), pp.default_params(results_per_pixel=K + 1))
             np.save(os.path.join(out_dir, "more_lh.npy"), more["lh"].reshape(S, K + 1))
+        dist.barrier()  # (nobody leaves -- rank 0 holds the rendezvous store -- before everybody is through)
     finally:
         dist.destroy_process_group()
 
@@ -143,6 +144,7 @@ def _repair_worker(rank, world, port, out_dir):
             np.save(os.path.join(out_dir, "got.npy"), merged.numpy().reshape(-1).view(orc.TRJ_DTYPE))
             np.save(os.path.join(out_dir, "full.npy"), full)
             np.save(os.path.join(out_dir, "hazards.npy"), np.array([kdist.last_repair()["hazards"]]))
+        dist.barrier()  # (nobody leaves -- rank 0 holds the rendezvous store -- before everybody is through)
     finally:
         dist.destroy_process_group()
 
@@ -172,6 +174,7 @@ def _sparse_worker(rank, world, port, out_dir, min_lh):
             np.save(os.path.join(out_dir, "dense.npy"), dense.numpy().reshape(-1).view(orc.TRJ_DTYPE))
             np.save(os.path.join(out_dir, "full.npy"), full)
             np.save(os.path.join(out_dir, "wire.npy"), np.array([stats["wire_bytes"], local_t.numel() * 4]))
+        dist.barrier()  # (nobody leaves -- rank 0 holds the rendezvous store -- before everybody is through)
     finally:
         dist.destroy_process_group()
 
@@ -188,18 +191,20 @@ def _subgroup_worker(rank, world, port, out_dir):
         from oracle import oracle as orc
 
         group = dist.new_group([1, 2])   # (every rank of the world calls this)
-        if rank == 0:
-            return
-        K = 4
-        pp, vx, vy, local_t, all_cands = _stable_rank_lists(dist.get_rank(group), 2, K)
-        sparse = kdist.gather_and_merge_sparse(local_t, (0, 40), (0, 24), K, 2 * K, 2.5, all_cands, group=group, dst=1)
-        dense = kdist.gather_and_merge_compact(local_t, (0, 40), (0, 24), K, all_cands, list_len=2 * K, group=group, dst=1)
-        assert (sparse is None) == (rank != 1) and (dense is None) == (rank != 1)
-        if rank == 1:
-            full = pp.search_kernel_semantics(orc.make_candidates(vx, vy), pp.default_params(results_per_pixel=K))
-            np.save(os.path.join(out_dir, "sparse.npy"), sparse.numpy().reshape(-1).view(orc.TRJ_DTYPE))
-            np.save(os.path.join(out_dir, "dense.npy"), dense.numpy().reshape(-1).view(orc.TRJ_DTYPE))
-            np.save(os.path.join(out_dir, "full.npy"), full)
+        if rank != 0:
+            K = 4
+            pp, vx, vy, local_t, all_cands = _stable_rank_lists(dist.get_rank(group), 2, K)
+            sparse = kdist.gather_and_merge_sparse(local_t, (0, 40), (0, 24), K, 2 * K, 2.5, all_cands, group=group, dst=1)
+            dense = kdist.gather_and_merge_compact(local_t, (0, 40), (0, 24), K, all_cands, list_len=2 * K, group=group, dst=1)
+            assert (sparse is None) == (rank != 1) and (dense is None) == (rank != 1)
+            if rank == 1:
+                full = pp.search_kernel_semantics(orc.make_candidates(vx, vy), pp.default_params(results_per_pixel=K))
+                np.save(os.path.join(out_dir, "sparse.npy"), sparse.numpy().reshape(-1).view(orc.TRJ_DTYPE))
+                np.save(os.path.join(out_dir, "dense.npy"), dense.numpy().reshape(-1).view(orc.TRJ_DTYPE))
+                np.save(os.path.join(out_dir, "full.npy"), full)
+        # rank 0 hosts the rendezvous store: it stays until the sub-group is through (leaving early took the store away under
+        # the other two now and then)
+        dist.barrier()
     finally:
         dist.destroy_process_group()
 
@@ -243,6 +248,7 @@ def _worker(rank, world, port, out_dir):
             # every candidate's likelihood per pixel (a list as long as the candidate list keeps them all)
             every = pp.search_kernel_semantics(orc.make_candidates(vx, vy), pp.default_params(results_per_pixel=len(vx)))
             np.save(os.path.join(out_dir, "every_lh.npy"), every["lh"].reshape(S, len(vx)))
+        dist.barrier()  # (nobody leaves -- rank 0 holds the rendezvous store -- before everybody is through)
     finally:
         dist.destroy_process_group()
 
