@@ -1966,15 +1966,13 @@ int kb_merge_compact_repairable(const kb_compact_result* lists_dev, int32_t n_li
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     // (the hazard counter: eight bytes per device, allocated once -- an allocation and a release per call were 0.5 of the
     // 0.7 ms this entry point took)
-    static std::mutex counter_mutex;
+    // (held until the count is back: two merges on one device would share the counter; the call waits for its stream anyway)
+    static std::mutex counter_mutex[MAX_DEVICES];
     static unsigned long long* counters[MAX_DEVICES] = {};
-    unsigned long long* counter = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(counter_mutex);
-        const int slot = current_device_slot();
-        if (counters[slot] == nullptr) KB_HIP_TRY(hipMalloc(&counters[slot], sizeof(unsigned long long)));
-        counter = counters[slot];
-    }
+    const int slot = current_device_slot();
+    std::lock_guard<std::mutex> lock(counter_mutex[slot]);
+    if (counters[slot] == nullptr) KB_HIP_TRY(hipMalloc(&counters[slot], sizeof(unsigned long long)));
+    unsigned long long* const counter = counters[slot];
     int rc = 0;
     unsigned long long n_hazard = 0;
     if (hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream) != hipSuccess) rc = fail("merge_compact_repairable: memset failed");
