@@ -515,6 +515,29 @@ struct TopKPacked {
             ci = g ? ti : ci;
         }
     }
+    // The same insertion with every slot finished before the next is looked at (the empty statement pins the order): left to
+    // itself the compiler computes the eight carried triples first and applies them afterwards, twenty more live registers
+    // than the three that travel -- next to the 64 sums of a chunk of 32 that put list registers into scratch memory, stored
+    // and reloaded by every round.
+    __device__ __forceinline__ void insert_in_sequence(float cand_lh, float cand_flux, uint32_t cand_io, bool stable = false) {
+        float cl = cand_lh, cf = cand_flux;
+        uint32_t ci = cand_io;
+        bool placed = false;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bool g = (cl > lh[s]) || (stable && placed);
+            placed = placed || g;
+            const float tl = lh[s], tf = flux[s];
+            const uint32_t ti = io[s];
+            lh[s] = g ? cl : tl;
+            flux[s] = g ? cf : tf;
+            io[s] = g ? ci : ti;
+            cl = g ? tl : cl;
+            cf = g ? tf : cf;
+            ci = g ? ti : ci;
+            asm volatile("" : "+v"(cl), "+v"(cf), "+v"(ci), "+v"(lh[s]), "+v"(flux[s]), "+v"(io[s]));
+        }
+    }
 };
 
 // What kb_search_lds keeps in registers of a thread's list while it sums the next chunk: the likelihood a candidate

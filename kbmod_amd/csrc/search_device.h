@@ -217,8 +217,8 @@ __device__ __forceinline__ void select_by_bits(const float (&ps)[C], const float
 template <int KS, int C>
 __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int cand_base, const float (&ps)[C], const float (&ph)[C],
                                                     const int (&cnt)[C], TopKPacked<KS>& top) {
-    static_assert(C <= 16, "chunks of 32 are finished as two halves of 16 (lds_search_tile): the selection out of 32 register "
-                           "sets next to 64 live sums put the sums into scratch memory, reloaded in every round");
+    static_assert(C <= 16, "chunks of 32 have their own finish (finish_chunk32_packed, search_lds.h): the compiler's selection "
+                           "out of 32 register sets next to 64 live sums put the sums into scratch memory");
     const float floor_lh = screen_key(fmaxf(top.lh[KS - 1], a.min_lh));  // (min_lh: the lists' floor, flag 1024; else -FLT_MAX)
     uint32_t pending = 0;
 #pragma unroll
@@ -242,59 +242,6 @@ __device__ __forceinline__ void finish_chunk_packed(const SearchArgs& a, int can
         pending &= pending - 1u;
     }
 }
-// finish_chunk_packed for one half (16 candidates) of a chunk of 32, with the observation counts left PACKED two to a word
-// (candidate c in half c & 1 of cw[c >> 1]): sixteen count registers unpacked to thirty-two, next to 64 live sums and the
-// lists, were what pushed the rounds of such a chunk into scratch memory.
-// COUNTS = false: every candidate has all a.T observations (an interior tile: no count registers at all).
-template <int KS, bool COUNTS>
-__device__ __forceinline__ void finish_half_packed(const SearchArgs& a, int cand_base, const float (&ps)[16], const float (&ph)[16],
-                                                   const uint32_t (&cw)[8], TopKPacked<KS>& top) {
-    constexpr int C = 16;
-    const float floor_lh = screen_key(fmaxf(top.lh[KS - 1], a.min_lh));
-    uint32_t pending = 0;
-#pragma unroll
-    for (int c = C - 1; c >= 0; --c) {
-        const int n = COUNTS ? (int)((cw[c >> 1] >> (16 * (c & 1))) & 0xffffu) : a.T;
-        const bool out = (n < a.min_obs) | screened_out(ps[c], ph[c], floor_lh);
-        pending = (pending << 1) | (out ? 0u : 1u);
-    }
-    {
-        const int left = a.n_cands - cand_base;  // uniform
-        if (left < C) pending &= left > 0 ? (1u << left) - 1u : 0u;
-    }
-    while (__ballot(pending != 0u) != 0ull) {  // uniform
-        const uint32_t sel = (uint32_t)__builtin_ctz(pending | (1u << C));
-        float p[C], f[C];
-        uint32_t w[C / 2];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            p[c] = ps[c];
-            f[c] = ph[c];
-        }
-#pragma unroll
-        for (int j = 0; j < C / 2; ++j) w[j] = COUNTS ? cw[j] : 0u;
-#pragma unroll
-        for (int width = C / 2, bit = 1; width >= 1; width >>= 1, bit <<= 1) {
-            const bool odd = (sel & (uint32_t)bit) != 0u;
-#pragma unroll
-            for (int i = 0; i < width; ++i) {
-                p[i] = odd ? p[2 * i + 1] : p[2 * i];
-                f[i] = odd ? f[2 * i + 1] : f[2 * i];
-            }
-            if (COUNTS && bit >= 2) {  // (the words are indexed by sel >> 1)
-#pragma unroll
-                for (int i = 0; i < width; ++i) w[i] = odd ? w[2 * i + 1] : w[2 * i];
-            }
-        }
-        const uint32_t n = COUNTS ? (w[0] >> (16u * (sel & 1u))) & 0xffffu : (uint32_t)a.T;
-        const float lh = lh_from_sums(p[0], f[0]);
-        if (pending != 0u && lh > top.lh[KS - 1]) {
-            top.insert(lh, flux_from_sums(p[0], f[0]), (uint32_t)(cand_base + (int)sel) | (n << 16), a.stable_lists != 0);
-        }
-        pending &= pending - 1u;
-    }
-}
-
 // The K result records of every lane of a wave -- 64 consecutive start pixels of one row, hence one contiguous run of
 // 64 * K records in the result array -- leave as coalesced stores: each half of the wave lays its records down in the wave's
 // own patch of LDS (the group buffers are dead by the epilogue), then all 64 lanes write the patch out linearly, 256

@@ -1287,9 +1287,10 @@ static int search_filter_impl(const kb_psi_phi_meta* meta, const void* psi_phi_d
         // on 64 x 16 tiles.  The instance is count-free: it takes stacks without NO_DATA pixels whose border tiles get their
         // counts from the edge tables; everything else that the tables must confirm is checked below.
         const uint64_t float_copy = (uint64_t)a.T * (uint64_t)a.H * (uint64_t)a.W * 8ull;
-        // Measured (profiles/r05_chunk_width.log): per chunk of 32 the finish runs in two halves with the second half's sums parked
-        // in scratch memory, a fixed cost the sums of a deep stack amortise -- 512 epochs -13 %, 384 -10 %, 256 -5 ... -7 %, 128
-        // epochs +7 ... +11 % against chunks of 16; hence from 192 epochs on.
+        // Measured (profiles/r05_chunk_width.log; round 6's finish with the generated selection tree moves none of it by more than
+        // 1 %): the finish of a chunk of 32 costs 2.5 x that of a chunk of 16 (list registers in scratch memory, stored and
+        // reloaded by every round), a fixed cost the sums of a deep stack amortise -- 512 epochs -13 %, 384 -10 %, 256
+        // -5 ... -7 %, 128 epochs +7 ... +11 % against chunks of 16; hence from 192 epochs on.
         bool xwide = wide && !emitting && a.K <= 8 && n_cands >= (uint64_t)XWIDE_CHUNK && float_copy > (256ull << 20) && a.T >= 192 &&
                      tall_tiles >= 128 && (flags & (16u | 32u | 128u)) == 0 && params.x_start_min >= 0 && params.y_start_min >= 0 &&
                      params.x_start_max <= a.W && params.y_start_max <= a.H;

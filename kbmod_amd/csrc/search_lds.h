@@ -121,6 +121,59 @@ __device__ __forceinline__ void copy_slab_tail(const SearchArgs& a, const StageL
 
 typedef float PairF __attribute__((ext_vector_type(2)));
 
+// finish_chunk_packed (search_device.h) for a whole chunk of 32 candidates: ONE screen, then rounds whose selection out of the
+// 32 register pairs is the generated tree KB_SELECT_TREE_32 (search_lds_asm.h: depth first, one temporary per level), and
+// an insertion that finishes a slot before it looks at the next (TopKPacked::insert_in_sequence).  Round 5 ran it as two
+// halves of 16 with the compiler's own trees, the second half's sums parked in scratch memory by hand; this form measures
+// within 1 % of that on deep stacks and 6 % better where border tiles decide (cfg2 forced: 2.83 vs 3.06 ms) -- in either the
+// allocator keeps a handful of list registers in scratch memory, stored and reloaded by every round (an interior tile's round:
+// 3 loads + 2 stores; phase ticks of the finish 0.79 M per wave against 0.97 M as halves and 0.32 M for chunks of 16 on a
+// 128 x 2048 x 2048 stack, LABNOTES r6.6).  Screening all 32 against the list as it stands at the start of the chunk lets a few
+// more candidates into the rounds than screening the second half against what the first half left; the exact test in the round
+// decides either way, the lists are the same.
+// cw: observation counts packed two to a word (candidate c in half c & 1 of cw[c >> 1]); COUNTS = false: every candidate
+// has all a.T observations (an interior tile).
+template <int KS, bool COUNTS>
+__device__ __forceinline__ void finish_chunk32_packed(const SearchArgs& a, int cand_base, const PairF (&acc)[32],
+                                                      const uint32_t (&cw)[16], TopKPacked<KS>& top) {
+    constexpr int C = 32;
+    const float floor_lh = screen_key(fmaxf(top.lh[KS - 1], a.min_lh));
+    uint32_t pending = 0;
+#pragma unroll
+    for (int c = C - 1; c >= 0; --c) {  // (downwards: the mask is built by shifting)
+        const int n = COUNTS ? (int)((cw[c >> 1] >> (16 * (c & 1))) & 0xffffu) : a.T;
+        const bool out = (n < a.min_obs) | screened_out(acc[c].x, acc[c].y, floor_lh);
+        pending = (pending << 1) | (out ? 0u : 1u);
+    }
+    {
+        const int left = a.n_cands - cand_base;  // uniform: candidates of this chunk that exist
+        if (left < C) pending &= left > 0 ? (1u << left) - 1u : 0u;
+    }
+    while (__ballot(pending != 0u) != 0ull) {  // uniform
+        const uint32_t sel = (uint32_t)__builtin_ctz(pending | 0x80000000u);  // (a lane with nothing left selects candidate 31 and drops it)
+        float p, f;
+        KB_SELECT_TREE_32(p, f, sel, acc)
+        uint32_t n = (uint32_t)a.T;
+        if constexpr (COUNTS) {
+            uint32_t w[C / 2];
+#pragma unroll
+            for (int j = 0; j < C / 2; ++j) w[j] = cw[j];
+#pragma unroll
+            for (int width = C / 4, bit = 2; width >= 1; width >>= 1, bit <<= 1) {  // (the words are indexed by sel >> 1)
+                const bool odd = (sel & (uint32_t)bit) != 0u;
+#pragma unroll
+                for (int i = 0; i < width; ++i) w[i] = odd ? w[2 * i + 1] : w[2 * i];
+            }
+            n = (w[0] >> (16u * (sel & 1u))) & 0xffffu;
+        }
+        const float lh = lh_from_sums(p, f);
+        if (pending != 0u && lh > top.lh[KS - 1]) {
+            top.insert_in_sequence(lh, flux_from_sums(p, f), (uint32_t)(cand_base + (int)sel) | (n << 16), a.stable_lists != 0);
+        }
+        pending &= pending - 1u;
+    }
+}
+
 // One epoch whose samples cannot be read at lane base + scalar offset: either staged with slack because
 // some candidate's shift sits on a rounding boundary (every lane predicts its own pixel with the
 // reference's arithmetic and reads it from the slab), or not staged at all (a footprint larger than a
@@ -739,7 +792,7 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
             } else if (tc.row_active) {
                 float ps[C], ph[C];
                 int cnt[C];
-                // (chunks of 32 keep their counts packed two to a word all the way into the rounds: finish_half_packed)
+                // (chunks of 32 keep their counts packed two to a word all the way into the rounds: finish_chunk32_packed)
                 constexpr bool PACKED_COUNTS = TileLists<KS, LM>::PACKED && C == XWIDE_CHUNK;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
@@ -771,41 +824,13 @@ __device__ __forceinline__ void lds_search_tile(const SearchArgs& a, const TileC
                                                                       TileLists<KS, LM>::SLOT_BYTES * threadIdx.x,
                                                                       ROWS * WAVE * TileLists<KS, LM>::SLOT_BYTES);
                 } else if constexpr (TileLists<KS, LM>::PACKED && C == XWIDE_CHUNK) {
-                    // Two halves of 16, in candidate order (the second half is screened against what the first left).  The
-                    // second half's 32 sums are PARKED in scratch memory while the first half's rounds run (handing the array's
-                    // address to an empty asm statement is what makes it a block of memory instead of registers again), and an
-                    // interior tile -- every candidate has all T observations -- carries no count registers at all: next to 64
-                    // live sums, the lists and sixteen count words the rounds reloaded a dozen spilled registers each.
-                    constexpr int HC = C / 2;
-                    float park[2 * HC];
-#pragma unroll
-                    for (int c = 0; c < HC; ++c) {
-                        park[c] = ps[HC + c];
-                        park[HC + c] = ph[HC + c];
-                    }
-                    asm volatile("" ::"v"(&park[0]) : "memory");
-                    auto halves = [&](auto counts_tag, const uint32_t (&cw)[C / 2]) {
-                        constexpr bool COUNTS = decltype(counts_tag)::value;
-                        finish_half_packed<KS, COUNTS>(a, chunk * C, reinterpret_cast<const float(&)[HC]>(ps[0]),
-                                                       reinterpret_cast<const float(&)[HC]>(ph[0]),
-                                                       reinterpret_cast<const uint32_t(&)[HC / 2]>(cw[0]), lists.packed);
-                        asm volatile("" ::"v"(&park[0]) : "memory");
-                        float ps2[HC], ph2[HC];
-#pragma unroll
-                        for (int c = 0; c < HC; ++c) {
-                            ps2[c] = park[c];
-                            ph2[c] = park[HC + c];
-                        }
-                        finish_half_packed<KS, COUNTS>(a, chunk * C + HC, ps2, ph2, reinterpret_cast<const uint32_t(&)[HC / 2]>(cw[HC / 2]),
-                                                       lists.packed);
-                    };
                     if (edge_tab != nullptr) {  // (uniform) a tile at the image's edge: counts out of the tables
                         uint32_t cnte[C / 2];
                         edge_counts<C>(a, tq, chunk, edge_tab, edge_D, cnte);
-                        halves(std::true_type{}, cnte);
+                        finish_chunk32_packed<KS, true>(a, chunk * C, acc, cnte, lists.packed);
                     } else {
                         const uint32_t none[C / 2] = {};
-                        halves(std::false_type{}, none);
+                        finish_chunk32_packed<KS, false>(a, chunk * C, acc, none, lists.packed);
                     }
                 } else if constexpr (TileLists<KS, LM>::PACKED) {
                     finish_chunk_packed<KS, C>(a, chunk * C, ps, ph, cnt, lists.packed);

@@ -481,6 +481,49 @@ def clobbers(p, fast):
     return ", ".join(v + [f'"s{i}"' for i in p.sregs] + ['"vcc"', '"scc"', '"memory"'])
 
 
+def select_tree(n):
+    """KB_SELECT_TREE_<n>(P, F, SEL, ACC): the (psi, phi) sums of candidate SEL (per lane, 0 .. n - 1) out of the n accumulator
+    pairs ACC[0 .. n - 1] (.x, .y), halving by the bits of SEL like select_by_bits (search_device.h) -- written out because next
+    to 64 live sums the compiler's own tree keeps a level's worth of intermediate values alive and puts the sums into scratch
+    memory.  Depth first: one temporary per level, the two fields one after the other through the same temporaries."""
+    levels = n.bit_length() - 1
+    text = []
+    for k in range(levels):  # m<k>: lanes whose SEL has bit k set
+        text.append(f"v_and_b32 %[t0], {1 << k}, %[sel]\\n\\tv_cmp_ne_u32 %[m{k}], 0, %[t0]")
+
+    def field(prefix, dest):
+        free = [f"%[t{i}]" for i in range(levels + 1)]
+
+        def sub(lo, size, out=None):
+            if size == 1:
+                return f"%[{prefix}{lo}]", False
+            half = size // 2
+            a, a_tmp = sub(lo, half)
+            b, b_tmp = sub(lo + half, half)
+            d = out if out is not None else (a if a_tmp else free.pop())
+            text.append(f"v_cndmask_b32 {d}, {a}, {b}, %[m{half.bit_length() - 1}]")
+            if b_tmp:
+                free.append(b)
+            if a_tmp and d != a:
+                free.append(a)
+            return d, True
+
+        sub(0, n, dest)
+
+    field("a", "%[p]")
+    field("b", "%[f]")
+    outs = ['[p] "=&v"(P)', '[f] "=&v"(F)'] + [f'[t{i}] "=&v"(kb_t{i})' for i in range(levels + 1)] + \
+           [f'[m{k}] "=&s"(kb_m{k})' for k in range(levels)]
+    ins = ['[sel] "v"(SEL)'] + [f'[a{c}] "v"((ACC)[{c}].x)' for c in range(n)] + [f'[b{c}] "v"((ACC)[{c}].y)' for c in range(n)]
+    out = [f'#define KB_SELECT_TREE_{n}(P, F, SEL, ACC) \\', '    { \\',
+           '        float ' + ", ".join(f"kb_t{i}" for i in range(levels + 1)) + '; \\',
+           '        unsigned long long ' + ", ".join(f"kb_m{k}" for k in range(levels)) + '; \\',
+           '        asm( \\']
+    out += [f'            "{t}\\n\\t" \\' for t in text]
+    out += [f'            : {", ".join(outs)} \\', f'            : {", ".join(ins)}); \\', '    }', '']
+    return out
+
+
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = ['// GENERATED by tools/gen_lds_loop.py -- the hand-scheduled summing loops of kb_search_lds (search_lds.h: asm_run and the',
@@ -532,6 +575,7 @@ def main():
             out.append(f'        if constexpr (FAST) {{ KB_LDS_{family}_FAST_C16 }} else {{ KB_LDS_{family}_COUNT_C16 }} \\')
         out.append('    }')
         out.append('')
+    out += select_tree(32)
     out.append('#endif')
     with open(os.environ.get("KB_GEN_OUT", os.path.join(root, "kbmod_amd", "csrc", "search_lds_asm.h")), "w") as fh:
         fh.write("\n".join(out) + "\n")
