@@ -15,6 +15,7 @@
 // (j outer, i inner), separate multiply and add (no FMA), invalid taps skipped,
 // result = (sum * psf_total) / psf_portion, invalid centre passed through.
 #include <cfloat>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <mutex>
@@ -273,7 +274,12 @@ __device__ __forceinline__ void prepare_pixel(float sci, float var, float* psi0,
 // NaN or an infinity).  MASKED: every sample read becomes (value or 0, 1 or 0) once, for all the outputs it is a tap of.
 typedef float Pair2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) Pair2* ConstWeightPairs;  // (k, k^2) pairs in global memory: scalar loads
-template <int DIM, bool MASKED>
+// VSYM: kernel rows j and DIM - 1 - j hold the same bits (every Gaussian PSF; the host checks each epoch's kernel).  The
+// weights of row j are then read from row min(j, DIM - 1 - j): an input sample's product with a weight is the same expression
+// for the two outputs of the strip that meet it in mirrored kernel rows, and is multiplied once -- 44 instead of 56 packed
+// multiplies per column of a strip of eight (7 x 7), the adds and their order untouched -- and 28 weight pairs instead of 49
+// sit in scalar registers.
+template <int DIM, bool MASKED, bool VSYM>
 __device__ __forceinline__ void strip_pass(const Pair2* tile, int pitch,  // (no __restrict__: the row fence below must order the reads)
                                            ConstWeightPairs k, Pair2 (&acc)[STRIP_OUT], Pair2 (&part)[STRIP_OUT]) {
 #pragma unroll
@@ -293,15 +299,37 @@ __device__ __forceinline__ void strip_pass(const Pair2* tile, int pitch,  // (no
                 v[i] = Pair2{d0 ? v[i].x : 0.0f, d1 ? v[i].y : 0.0f};
             }
         }
+        if constexpr (!VSYM) {
 #pragma unroll
-        for (int r = 0; r < STRIP_OUT; ++r) {
-            const int j = yy - r;  // kernel row of input row yy for output r
-            if (j >= 0 && j < DIM) {
+            for (int r = 0; r < STRIP_OUT; ++r) {
+                const int j = yy - r;  // kernel row of input row yy for output r
+                if (j >= 0 && j < DIM) {
 #pragma unroll
-                for (int i = 0; i < DIM; ++i) {
-                    const Pair2 kk = k[j * DIM + i];  // compile-time index into the constant address space: a scalar register pair
-                    if (MASKED) part[r] += m[i] * kk;
-                    acc[r] += v[i] * kk;
+                    for (int i = 0; i < DIM; ++i) {
+                        const Pair2 kk = k[j * DIM + i];  // compile-time index into the constant address space: a scalar register pair
+                        if (MASKED) part[r] += m[i] * kk;
+                        acc[r] += v[i] * kk;
+                    }
+                }
+            }
+        } else {
+            // column by column (an output still receives this row's products left to right): the products of ONE sample -- at
+            // most (DIM + 1) / 2 different ones -- are all that is alive between two columns
+#pragma unroll
+            for (int i = 0; i < DIM; ++i) {
+#pragma unroll
+                for (int r = 0; r < STRIP_OUT; ++r) {
+                    const int j = yy - r;
+                    if (j >= 0 && j < DIM) {
+                        const Pair2 kk = k[(j < DIM - 1 - j ? j : DIM - 1 - j) * DIM + i];
+                        if (MASKED) part[r] += m[i] * kk;
+                        acc[r] += v[i] * kk;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < STRIP_OUT; ++r) {
+                    asm volatile("" : "+v"(acc[r]));
+                    if (MASKED) asm volatile("" : "+v"(part[r]));
                 }
             }
         }
@@ -411,7 +439,7 @@ __device__ __forceinline__ bool stage_strip_tile(const ConvArgs& a, int tiles_x,
 }
 
 
-template <int DIM>
+template <int DIM, bool VSYM>
 // (second launch bound = waves per SIMD: four 4-wave workgroups per CU, 128 registers a lane)
 __global__ __launch_bounds__(256, 4) void kb_psi_phi_strip_kernel(const ConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -433,14 +461,14 @@ __global__ __launch_bounds__(256, 4) void kb_psi_phi_strip_kernel(const ConvArgs
     Pair2 acc[STRIP_OUT], part[STRIP_OUT];
     if (clean) {
         // every tap counts: the weights seen add up, in this very order, to the kernel total (kb_conv_kernel's clean path)
-        strip_pass<DIM, false>(tile + corner, PITCH, k, acc, part);
+        strip_pass<DIM, false, VSYM>(tile + corner, PITCH, k, acc, part);
 #pragma unroll
         for (int r = 0; r < STRIP_OUT; ++r) {
             psi[r] = (tot0 == 0.0f) ? empty : (acc[r].x * tot0) / tot0;
             phi[r] = (tot1 == 0.0f) ? empty : (acc[r].y * tot1) / tot1;
         }
     } else {
-        strip_pass<DIM, true>(tile + corner, PITCH, k, acc, part);
+        strip_pass<DIM, true, VSYM>(tile + corner, PITCH, k, acc, part);
 #pragma unroll
         for (int r = 0; r < STRIP_OUT; ++r) {
             psi[r] = (part[r].x == 0.0f) ? empty : (acc[r].x * tot0) / part[r].x;
@@ -882,6 +910,17 @@ static int build_psi_phi(const float* sci_dev, const float* var_dev, const float
         if (psf_dims[t] != strip_dim) strip_dim = 0;
     }
     if (strip_dim < 3 || strip_dim > 9 || (build_flags & KB_BUILD_GENERAL_TILES) != 0) strip_dim = 0;
+    // every epoch's kernel reads the same top to bottom as bottom to top, bit for bit: the strip kernel multiplies a sample once
+    // for the two kernel rows that mirror each other (strip_pass, VSYM)
+    bool rows_mirror = strip_dim != 0;
+    for (int t = 0; t < num_times && rows_mirror; ++t) {
+        const float* kt = packed.data() + offs[t];
+        for (int j = 0; j < strip_dim / 2 && rows_mirror; ++j) {
+            rows_mirror = std::memcmp(kt + (size_t)j * strip_dim, kt + (size_t)(strip_dim - 1 - j) * strip_dim,
+                                      sizeof(float) * (size_t)strip_dim) == 0;
+        }
+    }
+    if (std::getenv("KBMOD_BUILD_NO_MIRROR") != nullptr) rows_mirror = false;  // (timing comparisons, tests)
     const int pitch = CONV_BX + 2 * max_radius, rows = CONV_BY + 2 * max_radius;
     const size_t lds = separable ? sizeof(float) * ((size_t)4 * pitch * rows + (size_t)4 * rows * CONV_BX + 4 * DM)
                                  : conv_lds_bytes(max_radius, true);
@@ -978,8 +1017,12 @@ static int build_psi_phi(const float* sci_dev, const float* var_dev, const float
             constexpr int D = decltype(dim_tag)::value;
             if (separable) {
                 hipLaunchKernelGGL(kb_psi_phi_strip_sep_kernel<D>, grid, dim3(256), strip_lds, s, c, tiles_x, tiles_y, n_tiles);
+            } else if (rows_mirror && D <= 7) {  // (9 x 9: the allocator puts the mirrored form's sums into scratch memory)
+                if constexpr (D <= 7) {
+                    hipLaunchKernelGGL((kb_psi_phi_strip_kernel<D, true>), grid, dim3(256), strip_lds, s, c, tiles_x, tiles_y, n_tiles);
+                }
             } else {
-                hipLaunchKernelGGL(kb_psi_phi_strip_kernel<D>, grid, dim3(256), strip_lds, s, c, tiles_x, tiles_y, n_tiles);
+                hipLaunchKernelGGL((kb_psi_phi_strip_kernel<D, false>), grid, dim3(256), strip_lds, s, c, tiles_x, tiles_y, n_tiles);
             }
         };
         switch (strip_dim) {

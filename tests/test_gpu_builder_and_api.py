@@ -48,7 +48,8 @@ def test_device_builder_per_epoch_psfs(kb, orc):
 
 
 def _device_build(sci, var, psf, num_bytes, build_flags):
-    """kb_build_psi_phi_from_device_ex on [T][H][W] stacks -> (meta, host copy of the array bytes)."""
+    """kb_build_psi_phi_from_device_ex on [T][H][W] stacks -> (meta, host copy of the array bytes).  psf: one kernel for
+    every epoch, or a list of T kernels."""
     import ctypes as C
 
     import torch
@@ -58,8 +59,9 @@ def _device_build(sci, var, psf, num_bytes, build_flags):
     lib = capi.load_lib()
     T, H, W = sci.shape
     d_sci, d_var = torch.from_numpy(sci).cuda(), torch.from_numpy(var).cuda()
-    psf_all = np.ascontiguousarray(np.tile(np.asarray(psf, np.float32).ravel(), T))
-    dims = np.full(T, psf.shape[0], dtype=np.int32)
+    psfs = list(psf) if isinstance(psf, (list, tuple)) else [psf] * T
+    psf_all = np.ascontiguousarray(np.concatenate([np.asarray(k, np.float32).ravel() for k in psfs]))
+    dims = np.array([k.shape[0] for k in psfs], dtype=np.int32)
     meta, arr = capi.Meta(), C.c_void_p()
     capi.check(lib.kb_build_psi_phi_from_device_ex(d_sci.data_ptr(), d_var.data_ptr(), psf_all.ctypes.data, dims.ctypes.data, T, H,
                                                    W, num_bytes, build_flags, C.byref(meta), C.byref(arr),
@@ -100,6 +102,38 @@ def test_strip_builder_variances_over_many_decades(orc, sigma, num_bytes):
     for name in ("psi_min_val", "psi_max_val", "psi_scale", "phi_min_val", "phi_max_val", "phi_scale"):
         assert np.float32(getattr(meta_s, name)).tobytes() == np.float32(getattr(pp.meta, name)).tobytes(), name
         assert np.float32(getattr(meta_s, name)).tobytes() == np.float32(getattr(meta_g, name)).tobytes(), name
+
+
+@pytest.mark.parametrize("kind", ["mirrored_rows_only", "no_symmetry", "one_epoch_breaks_it"])
+@pytest.mark.parametrize("dim", [3, 5, 7])
+def test_strip_builder_shares_products_only_between_mirrored_kernel_rows(orc, kind, dim):
+    """The strip kernel multiplies a sample once for two kernel rows that hold the same bits (strip_pass, VSYM) -- when EVERY
+    epoch's kernel reads the same top to bottom as bottom to top.  Kernels that mirror top-bottom but not left-right, kernels
+    without any symmetry, and a stack in which one epoch's kernel differs from its mirror image in a single bit: the array
+    equals the oracle's and the general tile kernel's byte for byte either way."""
+    rng = np.random.default_rng(100 * dim + len(kind))
+    T, H, W = 4, 70, 140
+    sci = rng.normal(0, 3, (T, H, W)).astype(np.float32)
+    var = rng.uniform(0.5, 8.0, (T, H, W)).astype(np.float32)
+    sci[1, 10:14, 60:75] = np.nan     # tiles with and without NO_DATA
+    var[2, 40, ::9] = 0.0
+    kernels = []
+    for t in range(T):
+        k = rng.uniform(0.0, 1.0, (dim, dim)).astype(np.float32)
+        if kind != "no_symmetry":
+            k[dim // 2 + 1:] = k[:dim // 2][::-1]   # row j == row dim - 1 - j, columns unrelated
+        kernels.append(k / k.sum(dtype=np.float32))
+    if kind != "no_symmetry":
+        for k in kernels:
+            k[dim // 2 + 1:] = k[:dim // 2][::-1]   # (the normalisation kept the rows equal; make sure of the bits)
+    if kind == "one_epoch_breaks_it":
+        kernels[2][0, 1] = np.nextafter(kernels[2][0, 1], np.float32(2.0))
+    times = np.arange(T, dtype=np.float64)
+    pp = orc.PsiPhi.from_images([x for x in sci], [v for v in var], kernels, times, 4)
+    _, strip = _device_build(sci, var, kernels, -1, 0)
+    _, general = _device_build(sci, var, kernels, -1, 4)  # KB_BUILD_GENERAL_TILES
+    assert np.array_equal(strip, pp.array.view(np.uint8).ravel())
+    assert np.array_equal(strip, general)
 
 
 def test_all_nan_stack_is_an_error_when_encoding(kb):
