@@ -57,6 +57,23 @@ __device__ __forceinline__ bool screened_out(float psi_sum, float phi_sum, float
     return trusted & (s <= t);                                                     // NaN compares false: left to the exact test
 }
 
+// The other side of the screen, for the emitting instances (a threshold that is the same for every candidate): a candidate
+// the products put ABOVE the threshold raised by a relative 2^-18 and one smallest normal also passes the exact test
+// `!(lh < threshold)`, so the correctly rounded sqrt and divide run only when some lane lies in the band between the two keys
+// (or has sums the products cannot be trusted with).  Same argument, same guards, mirrored; tests/test_screen_property.py.
+__device__ __forceinline__ float sure_key(float threshold) {
+    float f = threshold + fabsf(threshold) * 3.814697265625e-06f + 1.17549435e-38f;  // FLT_MAX -> inf, NaN stays NaN
+    if (fabsf(f) < 0x1p-40f) f = 0x1p-40f;  // (higher is always safe)
+    const float k = f * fabsf(f);
+    return __builtin_amdgcn_classf(k, 0x108) ? k : __builtin_nanf("");
+}
+__device__ __forceinline__ bool surely_in(float psi_sum, float phi_sum, float key_hi) {
+    const float s = psi_sum * fabsf(psi_sum);
+    const float t = key_hi * phi_sum;
+    const bool trusted = (phi_sum > 0.0f) & __builtin_amdgcn_classf(t, 0x108);  // +-normal
+    return trusted & (s > t);                                                     // NaN compares false: left to the exact test
+}
+
 // Threshold / insertion of one chunk's C finished candidates.  With the sigma-G filter on nothing is
 // inserted here: the ballot of the lanes that pass the unclipped thresholds (kernels.cu:201-203 and
 // :318-320; this includes the obs_count == 0 corner, which the clip leaves alone) becomes one work item
@@ -71,26 +88,33 @@ __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoor
     // loop with their registers.
     if constexpr (SIGMAG) {
         const bool live = tc.x_i < a.sw;  // lanes past the right edge of the search area own no pixel
-        // two passes over the candidates (count, then write): the ballots are cheap to form again and C
-        // 64-bit masks kept alive would cost the surrounding loop its scalar registers
-        // `lh < min_lh` is decided on the approximate likelihood wherever that is safe (screened_out: a candidate it rejects
-        // also fails the exact test); the correctly rounded sqrt and divide run only for candidates some lane cannot
-        // decide that way -- a fraction of a percent of cfg3's
-        const float floor_lh = screen_key(a.min_lh);
-        uint32_t pass_bits = 0;
+        // `lh < min_lh` is decided on the approximate likelihood wherever that is safe: a candidate screened_out rejects also
+        // fails the exact test, one surely_in accepts also passes it, and the correctly rounded sqrt and divide run only when
+        // some lane lies in the band between the two (or has sums the products cannot be trusted with).  Around a bright mover
+        // most candidates of a wave pass in SOME lane: with the lower screen alone the exact likelihoods of all 1024 of them
+        // made such a wave -- and with it its tile, and with one tile per CU the launch -- a fifth slower than the rest.
+        // One pass: the ballot of candidate c is parked in lane c of a register pair (C 64-bit masks kept in scalar registers
+        // would cost the surrounding loop its own), and the chunk's work items leave in ONE store by the lanes
+        // that hold one (sixteen entries written one after the other by lane 0 were a tenth of such a wave's instructions).
+        static_assert(C <= WAVE, "one lane per candidate of the chunk");
+        const float floor_lh = screen_key(a.min_lh), ceil_lh = sure_key(a.min_lh);
+        int need_lo = 0, need_hi = 0;  // lane c: the ballot of candidate c
         int n_items = 0;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             float p = ps[c], f = ph[c];
-            asm volatile("" : "+v"(p), "+v"(f), "+v"(pass_bits));
+            asm volatile("" : "+v"(p), "+v"(f), "+v"(need_lo), "+v"(need_hi));
             const bool real = (chunk * C + c) < a.n_cands;  // uniform
             bool pass = real & live & !(cnt[c] < a.min_obs) & !screened_out(p, f, floor_lh);
-            if (__ballot(pass) != 0) {  // uniform
+            const bool sure = surely_in(p, f, ceil_lh);  // (straight-line: under a branch on the ballot of `pass` the launch was 2 % slower)
+            if (__ballot(pass & !sure) != 0) {  // uniform
                 const float lh = lh_from_sums(p, f);
-                pass = pass & !(lh < a.min_lh);
+                pass = pass & (sure | !(lh < a.min_lh));
             }
-            pass_bits |= pass ? (1u << c) : 0u;
-            n_items += (__ballot(pass) != 0) ? 1 : 0;
+            const uint64_t b = __ballot(pass);
+            need_lo = (tc.lane == c) ? (int)(uint32_t)b : need_lo;
+            need_hi = (tc.lane == c) ? (int)(uint32_t)(b >> 32) : need_hi;
+            n_items += (b != 0) ? 1 : 0;
         }
         if (n_items == 0) return;  // uniform
         const SigmaGWork& sg = a.cold->sg;
@@ -99,21 +123,18 @@ __device__ __forceinline__ void finish_chunk(const SearchArgs& a, const TileCoor
         base = __builtin_amdgcn_readfirstlane(base);
         const uint32_t row = (uint32_t)(tc.y_i * a.tiles_x + tc.tx);
         uint32_t* slot_row = sg.slots + (size_t)row * sg.batch_cands + (chunk - a.chunk_lo) * C;
-        SgEntry* entries = sg.entries;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const uint64_t need = __ballot(((pass_bits >> c) & 1u) != 0u);
-            if (need != 0) {  // uniform
-                if (tc.lane == 0) {
-                    SgEntry e;
-                    e.row = row;
-                    e.cand = (uint32_t)(chunk * C + c);
-                    e.mask = need;
-                    entries[base] = e;
-                    slot_row[c] = base + 1;
-                }
-                base += 1;
-            }
+        const bool has = (need_lo | need_hi) != 0;  // (lanes from C on hold nothing)
+        const uint64_t holders = __ballot(has);
+        // entries in candidate order, like the items' numbers before: lane c's is behind those of the lanes below it
+        const uint32_t at = base + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(holders >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)holders, 0u));
+        if (has) {
+            SgEntry e;
+            e.row = row;
+            e.cand = (uint32_t)(chunk * C) + (uint32_t)tc.lane;
+            e.mask = ((uint64_t)(uint32_t)need_hi << 32) | (uint64_t)(uint32_t)need_lo;
+            sg.entries[at] = e;
+            slot_row[tc.lane] = at + 1;
         }
     } else {
 #pragma unroll

@@ -7,6 +7,7 @@ import numpy as np
 
 F32 = np.float32
 FLT_MIN = F32(1.17549435e-38)
+SURE_SEEN = [0]
 FTZ = [False]   # emulate a multiplier that flushes denormal results to zero (either behaviour of the device must be safe)
 
 
@@ -40,6 +41,23 @@ def screened_out(psi, phi, key):
         return (phi > 0) & normal & (s <= t)
 
 
+def sure_key(thr):
+    with np.errstate(all="ignore"):
+        f = (thr + np.abs(thr) * F32(3.814697265625e-06) + FLT_MIN).astype(F32)
+        f = np.where(np.abs(f) < F32(2.0 ** -40), F32(2.0 ** -40), f).astype(F32)   # (NaN compares false: stays NaN)
+        k = _mul(f, np.abs(f))
+        normal = np.isfinite(k) & (np.abs(k) >= FLT_MIN)
+    return np.where(normal, k, F32(np.nan)).astype(F32)
+
+
+def surely_in(psi, phi, key_hi):
+    with np.errstate(all="ignore"):
+        s = _mul(psi, np.abs(psi))
+        t = _mul(key_hi, phi)
+        normal = np.isfinite(t) & (np.abs(t) >= FLT_MIN)
+        return (phi > 0) & normal & (s > t)
+
+
 def exact_lh(psi, phi):
     with np.errstate(all="ignore"):
         lh = (psi / np.sqrt(phi, dtype=F32)).astype(F32)   # IEEE sqrt and divide: correctly rounded, like the kernels'
@@ -54,6 +72,15 @@ def _check(psi, phi, thr):
         enters = lh > thr
     bad = out & enters
     assert not bad.any(), (psi[bad][:5], phi[bad][:5], thr[bad][:5], lh[bad][:5])
+    # the other side (the emitting instances, search_device.h: sure_key / surely_in): what the products put above the raised
+    # threshold passes the exact test `!(lh < threshold)` of kernels.cu:201-203
+    sure = surely_in(psi, phi, sure_key(thr))
+    with np.errstate(invalid="ignore"):
+        fails = lh < thr
+    bad = sure & fails
+    assert not bad.any(), (psi[bad][:5], phi[bad][:5], thr[bad][:5], lh[bad][:5])
+    assert not (sure & out).any()
+    SURE_SEEN[0] += int(sure.sum())
     return out
 
 
@@ -77,6 +104,8 @@ def test_rejected_candidates_fail_the_exact_test_random():
     thr = (lh * (1 + rng.standard_normal(n).astype(F32) * F32(1e-3))).astype(F32)
     out = _check(psi, phi, thr)
     assert 0.3 < out.mean() < 0.7          # and the screen does reject: about half of these lie below their threshold
+    sure = surely_in(psi, phi, sure_key(thr))
+    assert 0.3 < sure.mean() < 0.7 and (out | sure).mean() > 0.98   # ... decides the other half, and leaves a thin band
     # thresholds within a few ulps of the likelihood, both sides, both signs
     for k in (-4, -2, -1, 0, 1, 2, 4):
         t = lh.copy()
