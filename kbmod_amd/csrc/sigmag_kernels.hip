@@ -492,11 +492,22 @@ __global__ __launch_bounds__(256) void kb_sigmag_select_kernel(const ResolveArgs
     }
 
     const uint32_t* slot_row = a.sg.slots + (size_t)row * a.sg.batch_cands;
-    // entries whose mask and likelihoods are fetched together: a row that crosses a bright mover holds hundreds of entries, walked
-    // one group after the other -- the launch ends with those rows, so the depth of a group is what its duration follows
+    // A row that crosses a bright mover holds hundreds of entries, and the launch ends with those rows: what its duration
+    // follows is the chain of dependent round trips of ONE wave.  A row's slot words are fetched 1024 at a time (sixteen loads in
+    // flight); the entries they name are compacted, in candidate order, into the wave's list in LDS; then batches of AHEAD
+    // entries run through a two-stage pipeline -- the masks and likelihoods of the next batch are requested before this batch
+    // is inserted (round 6; until then request -> wait -> insert, batch after batch: 0.28 ms at cfg3).
     constexpr int AHEAD = KS <= 8 ? 16 : 8;
-    constexpr int BLOCKS = 16;  // blocks of 64 slot words fetched together (one dependent load per block was most of this
-                                // kernel's time: a row's 1024 slots are 16 round trips when fetched one after the other)
+    constexpr int BLOCKS = 16;  // blocks of 64 slot words fetched together
+    __shared__ uint32_t row_items[4][BLOCKS * WAVE];
+    typedef __attribute__((address_space(3))) uint32_t* LdsWords;
+    const LdsWords items = (LdsWords)(uint32_t)(uintptr_t)row_items[threadIdx.x >> 6];
+    const uint32_t* mask_words = reinterpret_cast<const uint32_t*>(a.sg.entries);  // entry e: words 4 e + 2 (lanes 0-31), 4 e + 3
+    struct Batch {
+        int e[AHEAD];        // (uniform) entry numbers, -1 past the end
+        uint32_t mw[AHEAD];  // this lane's half of the entry's mask
+        float lh[AHEAD];
+    };
     for (int c_base = 0; c_base < a.sg.batch_cands; c_base += BLOCKS * WAVE) {
         uint32_t slots[BLOCKS];
 #pragma unroll
@@ -504,34 +515,46 @@ __global__ __launch_bounds__(256) void kb_sigmag_select_kernel(const ResolveArgs
             const int idx = c_base + j * WAVE + lane;
             slots[j] = (idx < a.sg.batch_cands) ? slot_row[idx] : 0u;
         }
+        int n = 0;  // (uniform) entries of these 1024 candidates
 #pragma unroll
         for (int j = 0; j < BLOCKS; ++j) {
-            const uint32_t slot = slots[j];
-            uint64_t m = __ballot(slot != 0u);
-            while (m != 0) {  // candidate order
-                int e[AHEAD];
-                uint64_t mask[AHEAD];
-                float lh[AHEAD];
+            const uint64_t m = __ballot(slots[j] != 0u);
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (slots[j] != 0u) items[n + below] = slots[j] - 1u;
+            n += __popcll(m);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the list is written
+        __builtin_amdgcn_wave_barrier();
+        auto request = [&](int b, Batch& x) {
+            const int idx = b * AHEAD + (lane & (AHEAD - 1));
+            const int ev = (idx < n) ? (int)items[idx] : -1;
 #pragma unroll
-                for (int k = 0; k < AHEAD; ++k) {
-                    e[k] = -1;
-                    mask[k] = 0;
-                    lh[k] = 0.0f;
-                    if (m != 0) {  // uniform
-                        const int b = __ffsll((unsigned long long)m) - 1;
-                        m &= m - 1;
-                        e[k] = __builtin_amdgcn_readlane((int)slot, b) - 1;
-                        mask[k] = a.sg.entries[e[k]].mask;
-                        lh[k] = a.sg.lh[(size_t)e[k] * WAVE + lane];
-                    }
-                }
+            for (int k = 0; k < AHEAD; ++k) {
+                x.e[k] = __builtin_amdgcn_readlane(ev, k);
+                const size_t es = (size_t)max(x.e[k], 0);  // (past the end: entry 0's words, never looked at)
+                x.mw[k] = mask_words[4 * es + 2 + (size_t)(lane >> 5)];
+                x.lh[k] = a.sg.lh[es * WAVE + lane];
+            }
+        };
+        auto insert_batch = [&](const Batch& x) {
 #pragma unroll
-                for (int k = 0; k < AHEAD; ++k) {
-                    // kernels.cu:318-320 on the clipped value (obs_count was tested before the clip and is unchanged)
-                    if (e[k] >= 0 && ((mask[k] >> lane) & 1) && !(lh[k] < a.params.min_lh)) top.insert(lh[k], e[k], a.stable_lists != 0);
+            for (int k = 0; k < AHEAD; ++k) {
+                // kernels.cu:318-320 on the clipped value (obs_count was tested before the clip and is unchanged)
+                if (x.e[k] >= 0 && ((x.mw[k] >> (lane & 31)) & 1u) && !(x.lh[k] < a.params.min_lh)) {
+                    top.insert(x.lh[k], x.e[k], a.stable_lists != 0);
                 }
             }
+        };
+        const int n_batches = (n + AHEAD - 1) / AHEAD;
+        Batch even, odd;
+        if (n_batches > 0) request(0, even);
+        for (int b = 0; b < n_batches; b += 2) {
+            if (b + 1 < n_batches) request(b + 1, odd);
+            insert_batch(even);
+            if (b + 2 < n_batches) request(b + 2, even);
+            if (b + 1 < n_batches) insert_batch(odd);
         }
+        __builtin_amdgcn_wave_barrier();  // (the list is rewritten by the next 1024 candidates)
     }
 
     // every entry of a list has passed min_lh: the list's length is the count ResultSink::counts asks for

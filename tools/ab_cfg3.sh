@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-for rep in 1 2; do for l in main base2 base; do
+for rep in 1 2; do for l in main base; do
   if [ "$l" = main ]; then unset KBMOD_HIP_LIB; else export KBMOD_HIP_LIB=tools/probe_bin/libkbmod_$l.so; fi
   timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-live-traffic --no-masked --num-bytes 1 --sigmag "$@" 2>/dev/null | python -c "
 import sys,json
