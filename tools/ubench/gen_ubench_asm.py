@@ -77,6 +77,58 @@ def class_macro(name, jumps=True):
             + ", ".join(f'"s"(o[{c}])' for c in range(16)) + f" : {clob}, \"s60\", \"s62\", \"s63\", \"s64\", \"s65\", \"s66\", \"s67\", \"s68\", \"s69\", \"scc\", \"memory\");\n")
 
 
+def fixed_macro(name, n_updates):
+    """The addresses of the 16 candidates live in v[16:31] across the loop (set up once); an iteration updates n_updates of
+    them (a candidate whose shift changed between two epochs) and reads every sample at address + immediate offset: what a
+    statement costs when the slot of an epoch is an immediate and most candidates keep their shift from one epoch to the next."""
+    lines = ["s_mov_b32 s60, %2"] + [f"v_mov_b32 v{32 + i}, 0" for i in range(32)]
+    lines += [f"v_add_u32 v{16 + c}, %{3 + c}, %0" for c in range(16)]
+    lines.append("1:")
+    for u in range(n_updates):
+        lines.append(f"v_add_u32 v{16 + (3 * u) % 16}, %{3 + u}, %0")
+    for c in range(16):
+        lines.append(f"ds_read_b64 v[{96 + 2 * c}:{97 + 2 * c}], v{16 + c} offset:{64 * (c % 4)}")
+    lines.append("s_waitcnt lgkmcnt(0)")
+    for c in range(16):
+        lines.append(f"v_pk_add_f32 v[{32 + 2 * c}:{33 + 2 * c}], v[{32 + 2 * c}:{33 + 2 * c}], v[{96 + 2 * c}:{97 + 2 * c}]")
+    lines += ["s_sub_u32 s60, s60, 1", "s_cmp_lg_u32 s60, 0", "s_cbranch_scc1 1b"]
+    for i in range(1, 32):
+        lines.append(f"v_add_f32 v32, v32, v{32 + i}")
+    lines.append("v_mov_b32 %1, v32")
+    text = " \\\n    ".join('"' + l + '\\n\\t"' for l in lines)
+    clob = ", ".join(f'"v{i}"' for i in list(range(32, 64)) + list(range(96, 128)) + list(range(16, 32)))
+    return (f"#define {name}(base, iters, o, result) \\\n  asm volatile( \\\n    {text} \\\n    : \"+v\"(base), \"=&v\"(result) : \"s\"(iters), "
+            + ", ".join(f'"s"(o[{c}])' for c in range(16)) + f" : {clob}, \"s60\", \"scc\", \"memory\");\n")
+
+
+def branchy_macro(name, mask):
+    """KB_UB_FIXED* with the updates chosen per candidate at run time: bit c of a scalar mask says whether candidate c's address
+    changes this epoch; the update sits out of line (s_cbranch_scc1 there, s_branch back): what the kept-address statement
+    costs with its control flow.  The mask alternates between `mask` and its rotation, so that no branch is always (not) taken."""
+    lines = ["s_mov_b32 s60, %2", f"s_mov_b32 s61, {mask}"] + [f"v_mov_b32 v{32 + i}, 0" for i in range(32)]
+    lines += [f"v_add_u32 v{16 + c}, %{3 + c}, %0" for c in range(16)]
+    lines.append("1:")
+    for c in range(16):
+        lines += [f"s_bitcmp1_b32 s61, {c}", f"s_cbranch_scc1 kb_ub_u{c}_%=", f"kb_ub_b{c}_%=:"]
+    for c in range(16):
+        lines.append(f"ds_read_b64 v[{96 + 2 * c}:{97 + 2 * c}], v{16 + c} offset:{64 * (c % 4)}")
+    lines.append("s_waitcnt lgkmcnt(0)")
+    for c in range(16):
+        lines.append(f"v_pk_add_f32 v[{32 + 2 * c}:{33 + 2 * c}], v[{32 + 2 * c}:{33 + 2 * c}], v[{96 + 2 * c}:{97 + 2 * c}]")
+    lines += ["s_lshl_b32 s62, s61, 3", "s_lshr_b32 s61, s61, 13", "s_or_b32 s61, s61, s62", "s_and_b32 s61, s61, 0xffff"]  # rotate the 16-bit mask by 3
+    lines += ["s_sub_u32 s60, s60, 1", "s_cmp_lg_u32 s60, 0", "s_cbranch_scc1 1b", "s_branch kb_ub_end_%="]
+    for c in range(16):
+        lines += [f"kb_ub_u{c}_%=:", f"v_add_u32 v{16 + c}, %{3 + c}, %0", f"s_branch kb_ub_b{c}_%="]
+    lines.append("kb_ub_end_%=:")
+    for i in range(1, 32):
+        lines.append(f"v_add_f32 v32, v32, v{32 + i}")
+    lines.append("v_mov_b32 %1, v32")
+    text = " \\\n    ".join('"' + l + '\\n\\t"' for l in lines)
+    clob = ", ".join(f'"v{i}"' for i in list(range(32, 64)) + list(range(96, 128)) + list(range(16, 32)))
+    return (f"#define {name}(base, iters, o, result) \\\n  asm volatile( \\\n    {text} \\\n    : \"+v\"(base), \"=&v\"(result) : \"s\"(iters), "
+            + ", ".join(f'"s"(o[{c}])' for c in range(16)) + f" : {clob}, \"s60\", \"s61\", \"s62\", \"scc\", \"memory\");\n")
+
+
 print("// generated by gen_ubench_asm.py -- do not edit")
 print(macro("KB_UB_TODAY", 16, 1, 1))
 print(macro("KB_UB_ROWS2", 8, 2, 1))
@@ -84,3 +136,8 @@ print(macro("KB_UB_ROWS2W", 16, 2, 2))
 print(macro("KB_UB_ROWS4", 8, 2, 2, shared_addr=True))
 print(class_macro("KB_UB_CLASS"))
 print(class_macro("KB_UB_CLASS16", jumps=False))
+print(fixed_macro("KB_UB_FIXED0", 0))
+print(fixed_macro("KB_UB_FIXED5", 5))
+print(fixed_macro("KB_UB_FIXED16", 16))
+print(branchy_macro("KB_UB_BRANCHY5", 0x1249))
+print(branchy_macro("KB_UB_BRANCHY0", 0))

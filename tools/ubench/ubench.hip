@@ -182,7 +182,7 @@ __global__ __launch_bounds__(1024) void loop_kernel(float* out, const int* table
         }
 #pragma unroll
         for (int c = 0; c < NA; ++c) acc[c & 7] += acc2[c];
-    } else if constexpr (MODE >= 11 && MODE <= 16) {
+    } else if constexpr (MODE >= 11 && MODE <= 21) {
         // asm-exact loops (ubench_asm.h): 11 today's mix, 12 two rows x 8 candidates, 13 two rows x 16 candidates, 14 four rows x 8
         int so[16];
 #pragma unroll
@@ -197,6 +197,12 @@ __global__ __launch_bounds__(1024) void loop_kernel(float* out, const int* table
         // prefix sharing: 1 + (iteration & 15) of the 16 units per iteration, entered by computed jumps; 16: the jumps with all 16 units
         if constexpr (MODE == 15) { KB_UB_CLASS(b, n, so, r) }
         if constexpr (MODE == 16) { KB_UB_CLASS16(b, n, so, r) }
+        // addresses kept in registers, slots as immediates: no / 5 / 16 address updates per 16 samples
+        if constexpr (MODE == 17) { KB_UB_FIXED0(b, n, so, r) }
+        if constexpr (MODE == 18) { KB_UB_FIXED5(b, n, so, r) }
+        if constexpr (MODE == 19) { KB_UB_FIXED16(b, n, so, r) }
+        if constexpr (MODE == 20) { KB_UB_BRANCHY5(b, n, so, r) }
+        if constexpr (MODE == 21) { KB_UB_BRANCHY0(b, n, so, r) }
         acc[0].x += r;
     } else if constexpr (MODE == 6) {
         PairF one = PairF{1.0f, (float)lane};
@@ -264,6 +270,12 @@ int main() {
     run<14>("14 asm: 8 cand x 4 rows (2 batches), 16 waves", 1024, iters / 4, 576, out, table, cyc);
     run<15>("15 asm: classes, mean 8.5 of 16 units, 2 jumps", 1024, iters / 2, 576, out, table, cyc);
     run<16>("16 asm: all 16 units + the 2 jumps", 1024, iters / 2, 576, out, table, cyc);
+    run<17>("17 asm: addresses kept, 0 updates per 16", 1024, iters / 2, 576, out, table, cyc);
+    run<18>("18 asm: addresses kept, 5 updates per 16", 1024, iters / 2, 576, out, table, cyc);
+    run<19>("19 asm: addresses kept, 16 updates per 16", 1024, iters / 2, 576, out, table, cyc);
+    run<20>("20 asm: kept, 5 of 16 updated by branches", 1024, iters / 2, 576, out, table, cyc);
+    run<21>("21 asm: kept, 16 tests, no update taken", 1024, iters / 2, 576, out, table, cyc);
+    run<11>("11 asm: 16 cand x 1 row (today), 16 waves", 1024, iters / 2, 576, out, table, cyc);
     run<12>("12 asm: 8 cand x 2 rows, 8 waves", 512, iters, 576, out, table, cyc);
     run<13>("13 asm: 16 cand x 2 rows (2 batches), 8 waves", 512, iters / 2, 576, out, table, cyc);
     run<9>("9  8 cand x 2 rows, 16 waves/CU", 1024, iters / 2, 576, out, table, cyc);
