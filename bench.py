@@ -418,7 +418,11 @@ def main():
     # bytes on the wire), the root folds the lists in candidate order and re-makes the few pixels the records do not decide
     # from its replica of the stack.  Same result as the 2 K stable lists, bit for bit (--verify).  Not with the in-search
     # sigma-G filter (the repair evaluates plain trajectories) -- those searches exchange sparsely anyway.
-    repair = want_exact and not sparse and not args.stable_lists and not args.sigmag and K <= 32
+    # ... and not for short candidate lists per rank (unless K > 16, where it is the only exact form): the pixels whose
+    # trajectories mostly leave the image tie in bulk, and with 64 candidates per rank on a 4096 x 4096 grid 4 % of the
+    # pixels went to the repair (100 ms against a 20 ms search, profiles/r06_exchange_repair_cfg4.json).
+    repair = (want_exact and not sparse and not args.stable_lists and not args.sigmag and K <= 32 and
+              (n_local >= 256 or K > 16))
     exact_ties = want_exact and not repair and K <= 16   # 2 K stable lists (flag 512) + kb_merge_compact_exact
     list_len = 2 * K if exact_ties else K
     wire = {}

@@ -294,15 +294,17 @@ def test_two_ranks_on_one_gpu_through_gloo(tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, KBMOD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (256 candidates per rank: from there on the dense exchange is K records per rank + repair; below, 2 K stable lists)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "16",
-           "--size", "128", "--vel-steps", "8", "--ang-steps", "4", "--verify", "--no-cpu-baseline"]
+           "--size", "128", "--vel-steps", "16", "--ang-steps", "16", "--verify", "--no-cpu-baseline"]
     run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stderr[-2000:]
     line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
     assert line["verify"] == {"merged_equals_single_device_ok": True, "merged_likelihoods_equal_ok": True, "tie_exact": True,
                               "backend": "gloo", "exchange": "dense", "world": 2}
-    assert line["config"]["candidates_per_gpu"] == 32
+    assert line["config"]["candidates_per_gpu"] == 256
+    assert line["exchange"]["lists"] == "K records + repair" and line["exchange"]["repair"]["pixels"] == 128 * 128
 
 
 def _bench_line(extra_args, env_extra, timeout=900):
